@@ -1,0 +1,170 @@
+/*
+ * mer.h -- C-ABI of libmer.so: the MI355X-native refractive volumetric path-tracing hot path.
+ *
+ * This is the drop-in boundary.  The reference (cmu-ci-lab/MitsubaER) has no
+ * C-ABI for this path: its plugins are C++ classes behind `extern "C" CreateInstance(const Properties&)`
+ * (include/mitsuba/core/cobject.h:99-107).  Each entry point below names the reference interface it
+ * replaces.  Signatures use plain pointers, sizes and POD structs only -- no C++ / torch types.
+ *
+ * Conventions: every call returns 0 on success, non-zero on failure (reference: Log(EError) throws
+ * std::runtime_error, src/libcore/logger.cpp:100-147; the message is kept for mer_last_error()).
+ * The caller owns host buffers; the library owns device buffers behind handles.  One context per
+ * (process, GPU); a context is single-threaded.  Grids are dense, x fastest:
+ * data[((z*yres+y)*xres+x)*channels+c] (VOL v3 payload order, src/volume/gridvolume.cpp:54-89).
+ * Pointers named *_dev are DEVICE pointers (e.g. a torch tensor's data_ptr()); all others are host.
+ */
+#ifndef MER_H
+#define MER_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MER_ABI_VERSION 1
+
+typedef struct mer_context mer_context;
+typedef int32_t mer_volume;            /* handle, > 0; 0 = none */
+
+/* VOL v3 type codes (src/volume/gridvolume.cpp:54-89) */
+enum { MER_VOL_F32 = 1, MER_VOL_U8 = 3 };
+enum { MER_SIGMA_HOMOGENEOUS = 0, MER_SIGMA_GRID = 1 };       /* medium `homogeneous` | `heterogeneous` */
+enum { MER_RIF_CONST = 0, MER_RIF_TRILINEAR = 1, MER_RIF_BSPLINE3 = 2 };  /* none | gridvolume | splinevolume */
+enum { MER_STEP_VERLET = 0, MER_STEP_RK4 = 1 };
+enum { MER_BOUNDARY_AABB = 0, MER_BOUNDARY_SPHERE = 1 };
+enum { MER_PHASE_ISOTROPIC = 0, MER_PHASE_HG = 1 };
+enum { MER_TR_WOODCOCK2 = 0, MER_TR_RATIO = 1 };
+enum { MER_STRATEGY_BALANCE = 0, MER_STRATEGY_SINGLE = 1, MER_STRATEGY_MANUAL = 2 };
+enum { MER_FILTER_BOX = 0, MER_FILTER_GAUSSIAN = 1 };
+enum { MER_ALBEDO_CONST = 0, MER_ALBEDO_GRID = 1 };
+/* device memory layout of an uploaded grid (the integer index contract stays (x,y,z)) */
+enum { MER_LAYOUT_DENSE = 0, MER_LAYOUT_CELL8 = 1 };
+
+/* replaces GridDataSource::loadFromFile header fields (src/volume/gridvolume.cpp:217-287) */
+typedef struct {
+    int32_t res[3];
+    int32_t channels;               /* 1 or 3 */
+    int32_t dtype;                  /* MER_VOL_F32 | MER_VOL_U8 */
+    float   aabb_min[3], aabb_max[3];
+} mer_grid_desc;
+
+/* Flat scene: what Integrator::render() (include/mitsuba/render/integrator.h:74) sees through
+   Scene/Sensor/Film/Medium/PhaseFunction/VolumeDataSource/Emitter objects. */
+typedef struct {
+    /* sensor `perspective` + film `hdrfilm` (src/sensors/perspective.cpp:130-158,247-269) */
+    int32_t width, height;
+    float   fov_x_deg, near_clip, far_clip;
+    float   cam_to_world[12];       /* row-major 3x4, columns (left,newUp,dir,origin): Transform::lookAt */
+    int32_t rfilter; float rfilter_param;   /* box radius | gaussian stddev (src/rfilters) */
+    /* integrator `volpath` (src/librender/integrator.cpp:190-225) */
+    int32_t max_depth, rr_depth, hide_emitters;
+    /* shape with `interior` medium, null BSDF (src/librender/shape.cpp:48-70) */
+    int32_t boundary;
+    float   bmin[3], bmax[3];
+    float   sph_center[3], sph_radius;
+    /* medium */
+    int32_t sigma_mode;
+    float   sigma_a[3], sigma_s[3]; /* homogeneous sigmaA / sigmaS */
+    int32_t strategy, channel; float sampling_density, medium_sampling_weight;  /* homogeneous.cpp:156-228 */
+    mer_volume density; float density_scale;     /* heterogeneous `density`, `scale` */
+    int32_t albedo_mode; float albedo[3]; mer_volume albedo_grid;
+    int32_t rif_mode; float rif_const; mer_volume rif;   /* heterogeneousrefractive `rif` */
+    int32_t stepper; float stepsize;             /* `stepsize` (heterogeneousrefractive.cpp:208) */
+    /* phase `hg` / `isotropic` */
+    int32_t phase; float g;
+    int32_t tr_estimator;
+    /* emitter `constant` radiance; medium emission per unit density (config 5) */
+    float   env_radiance[3];
+    float   emission[3];
+} mer_scene_desc;
+
+/* which part of the image-sample space this call renders (multi-GPU sharding):
+   sample indices spp_begin + k*spp_stride, k in [0, spp_count); 32x32 image tiles t with
+   t % tile_count == tile_rank. */
+typedef struct {
+    int32_t spp_begin, spp_count, spp_stride;
+    int32_t tile_rank, tile_count;
+} mer_shard;
+
+enum {
+    MER_C_PATHS = 0, MER_C_STEPS, MER_C_RIF_EVALS, MER_C_TENTATIVE, MER_C_REAL,
+    MER_C_SEGMENTS, MER_C_NEE, MER_C_LOOP_ITERS, MER_C_ACTIVE_LANES, MER_C_COUNT = 16
+};
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int  mer_abi_version(void);
+/* replaces PluginManager::createObject + Scheduler worker setup (src/libcore/plugin.cpp:180-196) */
+int  mer_context_create(int32_t device_id, mer_context **out);
+void mer_context_destroy(mer_context *ctx);
+const char *mer_last_error(mer_context *ctx);       /* ctx may be NULL: error of a failed create */
+/* run kernels on this hipStream_t (NULL = default stream) */
+int  mer_context_set_stream(mer_context *ctx, void *hip_stream);
+int  mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu_count, int64_t *hbm_bytes);
+
+/* ---- volumes: replaces GridDataSource / SplineDataSource construction
+        (src/volume/gridvolume.cpp:108-198, src/volume/splinevolume.cpp:204-317) ------------------------- */
+int  mer_volume_upload(mer_context *ctx, const mer_grid_desc *desc, const void *host_data,
+                       int32_t layout, mer_volume *out);
+/* same, from a device-resident dense grid (generated on the GPU) */
+int  mer_volume_upload_dev(mer_context *ctx, const mer_grid_desc *desc, const void *data_dev,
+                           int32_t layout, mer_volume *out);
+/* builds cubic-B-spline coefficients on the GPU (Spline<3>::build3d, include/mitsuba/core/basisspline.h:812-890) */
+int  mer_volume_build_spline(mer_context *ctx, mer_volume v);
+int  mer_volume_download_spline(mer_context *ctx, mer_volume v, float *coeff_host);
+int  mer_volume_destroy(mer_context *ctx, mer_volume v);
+
+/* ---- film (ImageBlock, include/mitsuba/render/imageblock.h:124-205): float[height][width][5] ------ */
+int  mer_film_alloc(mer_context *ctx, int32_t width, int32_t height, float **film_dev);
+int  mer_film_zero(mer_context *ctx, float *film_dev, int32_t width, int32_t height);
+int  mer_film_download(mer_context *ctx, const float *film_dev, int32_t width, int32_t height, float *film_host);
+int  mer_film_free(mer_context *ctx, float *film_dev);
+
+/* ---- the hot path: replaces SamplingIntegrator::render -> renderBlock -> Li -> ImageBlock::put
+        (src/librender/integrator.cpp:95-188, src/integrators/path/volpath.cpp:84-343).
+        Accumulates (R,G,B,alpha,weight) splats into film_dev.  Asynchronous on the context stream. ---- */
+int  mer_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard,
+                uint64_t seed, float *film_dev);
+int  mer_synchronize(mer_context *ctx);
+/* HIP-event time of the last mer_render kernel in ms (synchronizes) */
+int  mer_last_kernel_ms(mer_context *ctx, float *ms);
+int  mer_counters_read(mer_context *ctx, uint64_t out[MER_C_COUNT]);    /* StatsCounter analogue */
+int  mer_counters_reset(mer_context *ctx);
+
+/* ---- leaf entry points for parity tests (host pointers, batched SoA) ------------------------------ */
+/* GridDataSource::lookupFloat (gridvolume.cpp:337-388); out_idx[4*i..] = x1,y1,z1,linear index or -1 */
+int  mer_lookup_trilinear(mer_context *ctx, mer_volume v, const float *pts, int64_t n, float *out_val, int32_t *out_idx);
+/* GridDataSource::lookupSpectrum (gridvolume.cpp:390-421) */
+int  mer_lookup_trilinear_rgb(mer_context *ctx, mer_volume v, const float *pts, int64_t n, float *out_rgb);
+/* VolumeDataSource::valueAndGradient (splinevolume.cpp:354-360) for rif_interp in {TRILINEAR,BSPLINE3} */
+int  mer_rif_value_grad(mer_context *ctx, mer_volume v, int32_t rif_interp, const float *pts, int64_t n,
+                        float *out_val, float *out_grad);
+/* HeterogeneousRefractiveMedium::trace / traceTillBoundary (heterogeneousrefractive.cpp:671-691,742-776);
+   dist[i] = +inf selects traceTillBoundary */
+int  mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0, const float *d0, const float *dist,
+                  int64_t n, float *out_p, float *out_v, float *out_dist_surf, float *out_opt, int32_t *out_success);
+/* Medium::sampleDistance (heterogeneous.cpp:589-663, homogeneous.cpp:275-352, heterogeneousrefractive.cpp:402-568);
+   rec stride 20: success,t,p[3],sigmaS[3],transmittance[3],pdfSuccess,pdfFailure,refRatioSq,d[3],0,0,0;
+   RNG stream of item i = (seed, pixel=i, sample=0) */
+int  mer_sample_distance(mer_context *ctx, const mer_scene_desc *scene, const float *o, const float *d,
+                         const float *maxt, int64_t n, uint64_t seed, float *rec);
+/* Medium::evalTransmittance (heterogeneous.cpp:546-587 / ratio tracking) */
+int  mer_eval_transmittance(mer_context *ctx, const mer_scene_desc *scene, const float *o, const float *d,
+                            const float *maxt, int64_t n, uint64_t seed, float *out_tr);
+/* PhaseFunction::sample / eval (src/phase/hg.cpp:74-110, src/phase/isotropic.cpp:62-78) */
+int  mer_phase_sample(mer_context *ctx, int32_t phase, float g, const float *wi, const float *u2, int64_t n, float *wo, float *pdf);
+int  mer_phase_eval(mer_context *ctx, int32_t phase, float g, const float *wi, const float *wo, int64_t n, float *val);
+/* PerspectiveCamera::sampleRay (src/sensors/perspective.cpp:247-269) */
+int  mer_camera_rays(mer_context *ctx, const mer_scene_desc *scene, const float *pos2, int64_t n, float *o, float *d);
+/* per-path radiance Li of sample `sample_index` for every pixel: out[(y*w+x)*3] (no filter) */
+int  mer_render_paths(mer_context *ctx, const mer_scene_desc *scene, int32_t sample_index, uint64_t seed, float *out_rgb);
+/* sampler stream known answers */
+int  mer_rng_floats(mer_context *ctx, uint64_t seed, uint32_t pixel, uint32_t sample, int32_t n, float *out);
+/* synthetic fields of BASELINE.json's configs generated on the device:
+   kind 0 = sigma_t density, 1 = linear RIF (y), 2 = radial RIF; returns a device pointer the caller frees
+   with mer_device_free */
+int  mer_synth_field_dev(mer_context *ctx, int32_t kind, int32_t N, float **data_dev);
+int  mer_device_free(mer_context *ctx, void *ptr_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MER_H */

@@ -1,0 +1,609 @@
+// mer_api.hip -- libmer.so: C-ABI (include/mer.h) over the gfx950 kernels in mer_kernels.hpp.
+// Host side is plain HIP runtime: device memory, one stream, HIP events.  No CPU compute path exists:
+// every entry point that computes launches a kernel, and fails loudly when no device is present.
+#include "mer_kernels.hpp"
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <map>
+#include <limits>
+
+using namespace mer;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct Volume {
+    mer_grid_desc desc;
+    void  *dense = nullptr;     // device, dense layout
+    float *cell8 = nullptr;     // device, CELL8 layout (optional)
+    float *coeff = nullptr;     // device, B-spline coefficients (optional)
+    int layout = MER_LAYOUT_DENSE;
+    bool owns_dense = true;
+    size_t bytes_dense = 0;
+};
+}  // namespace
+
+struct mer_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    std::map<int, Volume> volumes;
+    int next_handle = 1;
+    unsigned long long *counters = nullptr;      // MER_C_COUNT + 1 (work counter)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    hipDeviceProp_t prop;
+};
+
+#define HIP_CHECK(ctx, call)                                                                              \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            (ctx)->error = std::string(#call) + " failed: " + hipGetErrorString(e_);                      \
+            return 1;                                                                                     \
+        }                                                                                                 \
+    } while (0)
+
+static int fail(mer_context *ctx, const std::string &msg) { ctx->error = msg; return 1; }
+
+// worldToGrid = scale((res-1)/extents) * translate(-min) * toWorld^-1 with toWorld = identity
+// (GridDataSource::configure, src/volume/gridvolume.cpp:188-195).  Float arithmetic as in the reference.
+static void fill_dgrid(const Volume &v, DGrid &g) {
+    std::memset(&g, 0, sizeof(g));
+    g.data = v.dense; g.cell8 = v.cell8; g.coeff = v.coeff;
+    g.layout = v.cell8 ? MER_LAYOUT_CELL8 : MER_LAYOUT_DENSE;
+    g.channels = v.desc.channels; g.dtype = v.desc.dtype;
+    for (int i = 0; i < 3; i++) {
+        g.res[i] = v.desc.res[i];
+        g.bmin[i] = v.desc.aabb_min[i]; g.bmax[i] = v.desc.aabb_max[i];
+        const float extent = g.bmax[i] - g.bmin[i];
+        const float s = (float) (g.res[i] - 1) / extent;
+        g.s[i] = s;
+        g.t[i] = s * (-g.bmin[i]);
+        // SplineDataSource interpolatable limits (src/volume/splinevolume.cpp:280-281): stride = 1/xres
+        const float stride = (float) (1.0 / s);
+        g.lim_min[i] = g.bmin[i] + (2.0f * stride + MER_EPSILON);
+        g.lim_max[i] = g.bmax[i] + (-2.0f * stride - MER_EPSILON);
+    }
+}
+
+static void filter_table(int kind, float param, float *values, float &radius, float &scale) {
+    // ReconstructionFilter::configure (src/libcore/rfilter.cpp:40-55), MTS_FILTER_RESOLUTION = 31
+    const int RES = 31;
+    radius = kind == MER_FILTER_BOX ? param + 1e-5f : 4 * param;      // box.cpp:39, gaussian.cpp:42
+    float sum = 0.0f;
+    for (int i = 0; i < RES; ++i) {
+        const float x = (radius * i) / RES;
+        float v;
+        if (kind == MER_FILTER_BOX) v = std::fabs(x) <= radius ? 1.0f : 0.0f;
+        else {
+            const float alpha = -1.0f / (2.0f * param * param);
+            v = std::max(0.0f, std::exp(alpha * x * x) - std::exp(alpha * radius * radius));
+        }
+        values[i] = v; sum += v;
+    }
+    values[RES] = 0.0f; values[RES + 1] = 0.0f;
+    scale = RES / radius;
+    sum *= 2 * radius / RES;
+    const float normalization = 1.0f / sum;
+    for (int i = 0; i < RES; ++i) values[i] *= normalization;
+}
+
+// Validate the scene the way the reference plugins' constructors / configure() do, and flatten it.
+static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P) {
+    std::memset(&P, 0, sizeof(P));
+    P.sc = *sc;
+    if (sc->width <= 0 || sc->height <= 0) return fail(ctx, "film: width/height must be positive");
+    if (sc->rr_depth <= 0) return fail(ctx, "'rrDepth' must be set to a value greater than zero!");                 // integrator.cpp:217
+    if (sc->max_depth <= 0 && sc->max_depth != -1)
+        return fail(ctx, "'maxDepth' must be set to -1 (infinite) or a value greater than zero!");                  // integrator.cpp:220
+    if (sc->phase == MER_PHASE_HG && (sc->g >= 1 || sc->g <= -1))
+        return fail(ctx, "The asymmetry parameter must lie in the interval (-1, 1)!");                              // hg.cpp:52-53
+    if (sc->sigma_mode == MER_SIGMA_GRID) {
+        auto it = ctx->volumes.find(sc->density);
+        if (it == ctx->volumes.end()) return fail(ctx, "No density specified!");                                    // heterogeneous.cpp:229-230
+        if (it->second.desc.channels != 1) return fail(ctx, "density volume must support float lookups");           // :270
+        fill_dgrid(it->second, P.density);
+        if (!(sc->density_scale > 0)) return fail(ctx, "heterogeneous medium: 'scale' must be positive");
+        // m_maxDensity = m_scale * getMaximumFloatValue() (= 1.0 for gridvolume): heterogeneous.cpp:239-242
+        P.inv_max_density = 1.0f / (sc->density_scale * 1.0f);
+    }
+    if (sc->albedo_mode == MER_ALBEDO_GRID) {
+        auto it = ctx->volumes.find(sc->albedo_grid);
+        if (it == ctx->volumes.end()) return fail(ctx, "No albedo specified!");                                     // heterogeneous.cpp:231-232
+        if (it->second.desc.channels != 3) return fail(ctx, "albedo volume must support spectrum lookups");
+        Volume tmp = it->second; tmp.cell8 = nullptr;
+        fill_dgrid(tmp, P.albedo);
+    }
+    if (sc->rif_mode != MER_RIF_CONST) {
+        auto it = ctx->volumes.find(sc->rif);
+        if (it == ctx->volumes.end()) return fail(ctx, "No RIF specified!");                                        // heterogeneousrefractive.cpp:368-369
+        if (it->second.desc.channels != 1 || it->second.desc.dtype != MER_VOL_F32)
+            return fail(ctx, "RIF volume must be a 1-channel float32 grid");
+        if (sc->rif_mode == MER_RIF_BSPLINE3 && !it->second.coeff)
+            return fail(ctx, "RIF volume has no spline coefficients (call mer_volume_build_spline)");
+        if (!(sc->stepsize > 0)) return fail(ctx, "heterogeneousrefractive: 'stepsize' must be positive");
+        fill_dgrid(it->second, P.rif);
+        if (sc->rif_mode == MER_RIF_BSPLINE3) {
+            for (int i = 0; i < 3; i++) if (P.rif.res[i] < 5) return fail(ctx, "splinevolume needs at least 5 nodes per axis");
+            // the medium must lie inside the spline-safe box (gate: heterogeneousrefractive.cpp:461-466)
+        }
+    }
+    for (int i = 0; i < 3; i++) {
+        if (sc->sigma_a[i] < 0 || sc->sigma_s[i] < 0) return fail(ctx, "sigmaA / sigmaS must be non-negative");
+    }
+    P.sigA = f3(sc->sigma_a[0], sc->sigma_a[1], sc->sigma_a[2]);
+    P.sigS = f3(sc->sigma_s[0], sc->sigma_s[1], sc->sigma_s[2]);
+    P.sigT = f3(sc->sigma_a[0] + sc->sigma_s[0], sc->sigma_a[1] + sc->sigma_s[1], sc->sigma_a[2] + sc->sigma_s[2]);
+    const float sT[3] = {P.sigT.x, P.sigT.y, P.sigT.z}, sS[3] = {P.sigS.x, P.sigS.y, P.sigS.z};
+    // mediumSamplingWeight: homogeneous.cpp:172-190 == heterogeneousrefractive.cpp:239-255
+    float w = sc->medium_sampling_weight;
+    if (w == -1) {
+        for (int i = 0; i < 3; ++i) {
+            const float albedo = sS[i] / sT[i];
+            if (albedo > w && sT[i] != 0) w = albedo;
+        }
+        if (w > 0) w = std::max(w, 0.5f);
+    }
+    P.medium_sampling_weight = w;
+    P.sampling_density = 0;
+    if (sc->strategy == MER_STRATEGY_SINGLE) {
+        int channel = 0; float smallest = std::numeric_limits<float>::infinity();
+        for (int i = 0; i < 3; ++i) if (sT[i] < smallest) { smallest = sT[i]; channel = i; }
+        if (sc->channel >= 0) { if (sc->channel > 2) return fail(ctx, "channel out of range"); channel = sc->channel; }
+        P.sampling_density = sT[channel];
+    } else if (sc->strategy == MER_STRATEGY_MANUAL) {
+        P.sampling_density = sc->sampling_density;
+    } else if (sc->strategy != MER_STRATEGY_BALANCE) {
+        return fail(ctx, "Specified an unknown sampling strategy");                                                 // homogeneous.cpp:226
+    }
+    if (sc->sigma_mode == MER_SIGMA_HOMOGENEOUS && !(sT[0] > 0 && sT[1] > 0 && sT[2] > 0) && sc->strategy == MER_STRATEGY_BALANCE)
+        return fail(ctx, "homogeneous medium: sigmaT must be positive in every channel for the balance strategy");
+    for (int i = 0; i < 12; i++) P.cam[i] = sc->cam_to_world[i];
+    P.aspect = (float) sc->width / (float) sc->height;
+    P.cot_half_fov = 1.0f / std::tan((sc->fov_x_deg / 2.0f) * (MER_PI / 180.0f));
+    P.inv_res_x = 1.0f / sc->width; P.inv_res_y = 1.0f / sc->height;
+    if (sc->rfilter != MER_FILTER_BOX && sc->rfilter != MER_FILTER_GAUSSIAN) return fail(ctx, "unknown reconstruction filter");
+    if (!(sc->rfilter_param > 0)) return fail(ctx, "reconstruction filter radius/stddev must be positive");
+    filter_table(sc->rfilter, sc->rfilter_param, P.fvalues, P.fradius, P.fscale);
+    if (P.fradius > 7.0f) return fail(ctx, "reconstruction filter radius too large");
+    if (sc->boundary == MER_BOUNDARY_AABB) {
+        for (int i = 0; i < 3; i++) if (!(sc->bmin[i] < sc->bmax[i])) return fail(ctx, "medium shape: empty bounding box");
+    } else if (sc->boundary == MER_BOUNDARY_SPHERE) {
+        if (!(sc->sph_radius > 0)) return fail(ctx, "medium shape: sphere radius must be positive");
+    } else return fail(ctx, "unknown medium boundary");
+    P.counters = ctx->counters;
+    P.work_counter = ctx->counters + MER_C_COUNT;
+    return 0;
+}
+
+template <typename F> static int dispatch_modes(mer_context *ctx, const mer_scene_desc *sc, F &&f) {
+    const bool curved = sc->rif_mode != MER_RIF_CONST;
+    const bool grid = sc->sigma_mode == MER_SIGMA_GRID;
+    if (!curved) {
+        if (grid) return f(std::integral_constant<bool, false>(), std::integral_constant<int, MER_RIF_TRILINEAR>(),
+                           std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_GRID>());
+        return f(std::integral_constant<bool, false>(), std::integral_constant<int, MER_RIF_TRILINEAR>(),
+                 std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_HOMOGENEOUS>());
+    }
+#define MER_CASE(R, S, G)                                                                                         \
+    if (sc->rif_mode == R && sc->stepper == S && (int) grid == G)                                                 \
+        return f(std::integral_constant<bool, true>(), std::integral_constant<int, R>(), std::integral_constant<int, S>(), \
+                 std::integral_constant<int, G>());
+    MER_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET, 1) MER_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4, 1)
+    MER_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET, 1) MER_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4, 1)
+    MER_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET, 0) MER_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4, 0)
+    MER_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET, 0) MER_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4, 0)
+#undef MER_CASE
+    return fail(ctx, "unsupported rif_mode / stepper combination");
+}
+
+// staging helpers for the leaf entry points -------------------------------------------------------------
+struct DevBuf {
+    mer_context *ctx; void *p = nullptr;
+    DevBuf(mer_context *c) : ctx(c) {}
+    ~DevBuf() { if (p) (void) hipFree(p); }
+    int alloc(size_t bytes) { HIP_CHECK(ctx, hipMalloc(&p, bytes ? bytes : 4)); return 0; }
+    int upload(const void *host, size_t bytes) {
+        if (alloc(bytes)) return 1;
+        if (bytes) HIP_CHECK(ctx, hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    }
+    int download(void *host, size_t bytes) {
+        if (bytes) HIP_CHECK(ctx, hipMemcpyAsync(host, p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
+    template <typename T> T *as() { return (T *) p; }
+};
+static inline unsigned nblocks(int64_t n, int bs = 256) { return (unsigned) std::max<int64_t>(1, (n + bs - 1) / bs); }
+
+extern "C" {
+
+int mer_abi_version(void) { return MER_ABI_VERSION; }
+
+int mer_context_create(int32_t device_id, mer_context **out) {
+    if (!out) return 1;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = "mer_context_create: no HIP device available (libmer has no CPU path)";
+        return 1;
+    }
+    if (device_id < 0 || device_id >= ndev) { g_create_error = "mer_context_create: device id out of range"; return 1; }
+    mer_context *ctx = new mer_context();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess) {
+        g_create_error = "mer_context_create: hipSetDevice failed"; delete ctx; return 1;
+    }
+    if (hipMalloc((void **) &ctx->counters, sizeof(unsigned long long) * (MER_C_COUNT + 8)) != hipSuccess ||
+        hipMemset(ctx->counters, 0, sizeof(unsigned long long) * (MER_C_COUNT + 8)) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        g_create_error = "mer_context_create: device allocation failed"; delete ctx; return 1;
+    }
+    *out = ctx;
+    return 0;
+}
+
+void mer_context_destroy(mer_context *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    for (auto &kv : ctx->volumes) {
+        if (kv.second.dense && kv.second.owns_dense) (void) hipFree(kv.second.dense);
+        if (kv.second.cell8) (void) hipFree(kv.second.cell8);
+        if (kv.second.coeff) (void) hipFree(kv.second.coeff);
+    }
+    if (ctx->counters) (void) hipFree(ctx->counters);
+    if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+const char *mer_last_error(mer_context *ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int mer_context_set_stream(mer_context *ctx, void *hip_stream) { ctx->stream = (hipStream_t) hip_stream; return 0; }
+
+int mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu_count, int64_t *hbm_bytes) {
+    if (name && name_len > 0) { std::strncpy(name, ctx->prop.name, name_len - 1); name[name_len - 1] = 0; }
+    if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t) ctx->prop.totalGlobalMem;
+    return 0;
+}
+
+static int volume_finish(mer_context *ctx, Volume &v, int32_t layout, mer_volume *out) {
+    if (layout == MER_LAYOUT_CELL8) {
+        if (v.desc.channels != 1 || v.desc.dtype != MER_VOL_F32) return fail(ctx, "CELL8 layout needs a 1-channel float32 grid");
+        const size_t ncell = (size_t) (v.desc.res[0] - 1) * (v.desc.res[1] - 1) * (v.desc.res[2] - 1);
+        HIP_CHECK(ctx, hipMalloc((void **) &v.cell8, ncell * 8 * sizeof(float)));
+        hipLaunchKernelGGL(relayout_cell8_kernel, dim3(4096), dim3(256), 0, ctx->stream, (const float *) v.dense, v.cell8,
+                           v.desc.res[0], v.desc.res[1], v.desc.res[2]);
+        HIP_CHECK(ctx, hipGetLastError());
+        HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    } else if (layout != MER_LAYOUT_DENSE) return fail(ctx, "unknown volume layout");
+    v.layout = layout;
+    const int h = ctx->next_handle++;
+    ctx->volumes[h] = v;
+    *out = h;
+    return 0;
+}
+
+static int check_desc(mer_context *ctx, const mer_grid_desc *d) {
+    // GridDataSource::loadFromFile checks (src/volume/gridvolume.cpp:243-268)
+    if (d->dtype != MER_VOL_F32 && d->dtype != MER_VOL_U8) {
+        char buf[160];
+        std::snprintf(buf, sizeof(buf), "Encountered a volume data file of unknown type (type=%i, channels=%i)!", d->dtype, d->channels);
+        return fail(ctx, buf);
+    }
+    if (d->channels != 1 && d->channels != 3) {
+        char buf[160];
+        std::snprintf(buf, sizeof(buf), "Encountered an unsupported volume data file (%i channels, only 1 and 3 are supported)", d->channels);
+        return fail(ctx, buf);
+    }
+    for (int i = 0; i < 3; i++) {
+        if (d->res[i] < 2) return fail(ctx, "volume resolution must be at least 2 along every axis");
+        if (!(d->aabb_min[i] < d->aabb_max[i])) return fail(ctx, "volume bounding box is empty");
+    }
+    if ((int64_t) d->res[0] * d->res[1] * d->res[2] > (int64_t) 1 << 31) return fail(ctx, "volume too large for the int32 index contract");
+    return 0;
+}
+
+int mer_volume_upload(mer_context *ctx, const mer_grid_desc *desc, const void *host_data, int32_t layout, mer_volume *out) {
+    if (!ctx || !desc || !host_data || !out) return 1;
+    if (check_desc(ctx, desc)) return 1;
+    HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    Volume v; v.desc = *desc;
+    const size_t n = (size_t) desc->res[0] * desc->res[1] * desc->res[2] * desc->channels;
+    v.bytes_dense = n * (desc->dtype == MER_VOL_F32 ? 4 : 1);
+    HIP_CHECK(ctx, hipMalloc(&v.dense, v.bytes_dense));
+    HIP_CHECK(ctx, hipMemcpy(v.dense, host_data, v.bytes_dense, hipMemcpyHostToDevice));
+    return volume_finish(ctx, v, layout, out);
+}
+
+int mer_volume_upload_dev(mer_context *ctx, const mer_grid_desc *desc, const void *data_dev, int32_t layout, mer_volume *out) {
+    if (!ctx || !desc || !data_dev || !out) return 1;
+    if (check_desc(ctx, desc)) return 1;
+    HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    Volume v; v.desc = *desc;
+    const size_t n = (size_t) desc->res[0] * desc->res[1] * desc->res[2] * desc->channels;
+    v.bytes_dense = n * (desc->dtype == MER_VOL_F32 ? 4 : 1);
+    HIP_CHECK(ctx, hipMalloc(&v.dense, v.bytes_dense));
+    HIP_CHECK(ctx, hipMemcpyAsync(v.dense, data_dev, v.bytes_dense, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return volume_finish(ctx, v, layout, out);
+}
+
+int mer_volume_build_spline(mer_context *ctx, mer_volume h) {
+    auto it = ctx->volumes.find(h);
+    if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
+    Volume &v = it->second;
+    if (v.desc.channels != 1 || v.desc.dtype != MER_VOL_F32) return fail(ctx, "splinevolume needs a 1-channel float32 grid");
+    if (v.coeff) return 0;
+    const int nx = v.desc.res[0], ny = v.desc.res[1], nz = v.desc.res[2];
+    const size_t n = (size_t) nx * ny * nz;
+    float *a = nullptr, *b = nullptr;
+    HIP_CHECK(ctx, hipMalloc((void **) &a, n * 4));
+    HIP_CHECK(ctx, hipMalloc((void **) &b, n * 4));
+    // along y (lines indexed by x and z), then x (by y and z), then z (by x and y): basisspline.h:868-887
+    hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) nx * nz)), dim3(256), 0, ctx->stream,
+                       (const float *) v.dense, a, nx, nz, (int64_t) 1, (int64_t) nx * ny, (int64_t) nx, ny);
+    hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) ny * nz)), dim3(256), 0, ctx->stream,
+                       (const float *) a, b, ny, nz, (int64_t) nx, (int64_t) nx * ny, (int64_t) 1, nx);
+    hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) nx * ny)), dim3(256), 0, ctx->stream,
+                       (const float *) b, a, nx, ny, (int64_t) 1, (int64_t) nx, (int64_t) nx * ny, nz);
+    HIP_CHECK(ctx, hipGetLastError());
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void) hipFree(b);
+    v.coeff = a;
+    return 0;
+}
+
+int mer_volume_download_spline(mer_context *ctx, mer_volume h, float *coeff_host) {
+    auto it = ctx->volumes.find(h);
+    if (it == ctx->volumes.end() || !it->second.coeff) return fail(ctx, "volume has no spline coefficients");
+    const size_t n = (size_t) it->second.desc.res[0] * it->second.desc.res[1] * it->second.desc.res[2];
+    HIP_CHECK(ctx, hipMemcpy(coeff_host, it->second.coeff, n * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mer_volume_destroy(mer_context *ctx, mer_volume h) {
+    auto it = ctx->volumes.find(h);
+    if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
+    if (it->second.dense && it->second.owns_dense) (void) hipFree(it->second.dense);
+    if (it->second.cell8) (void) hipFree(it->second.cell8);
+    if (it->second.coeff) (void) hipFree(it->second.coeff);
+    ctx->volumes.erase(it);
+    return 0;
+}
+
+int mer_film_alloc(mer_context *ctx, int32_t width, int32_t height, float **film_dev) {
+    HIP_CHECK(ctx, hipMalloc((void **) film_dev, (size_t) width * height * 5 * sizeof(float)));
+    HIP_CHECK(ctx, hipMemsetAsync(*film_dev, 0, (size_t) width * height * 5 * sizeof(float), ctx->stream));
+    return 0;
+}
+int mer_film_zero(mer_context *ctx, float *film_dev, int32_t width, int32_t height) {
+    HIP_CHECK(ctx, hipMemsetAsync(film_dev, 0, (size_t) width * height * 5 * sizeof(float), ctx->stream));
+    return 0;
+}
+int mer_film_download(mer_context *ctx, const float *film_dev, int32_t width, int32_t height, float *film_host) {
+    HIP_CHECK(ctx, hipMemcpyAsync(film_host, film_dev, (size_t) width * height * 5 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int mer_film_free(mer_context *ctx, float *film_dev) { HIP_CHECK(ctx, hipFree(film_dev)); return 0; }
+int mer_device_free(mer_context *ctx, void *p) { HIP_CHECK(ctx, hipFree(p)); return 0; }
+
+static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed,
+                         float *film_dev, float *path_out_dev) {
+    Params P;
+    if (make_params(ctx, scene, P)) return 1;
+    if (!shard || shard->spp_count < 0 || shard->spp_stride <= 0 || shard->tile_count <= 0 || shard->tile_rank < 0 ||
+        shard->tile_rank >= shard->tile_count || shard->spp_begin < 0)
+        return fail(ctx, "invalid shard");
+    P.seed = seed;
+    P.spp_begin = shard->spp_begin; P.spp_count = shard->spp_count; P.spp_stride = shard->spp_stride;
+    P.tile_rank = shard->tile_rank; P.tile_count = shard->tile_count;
+    P.tiles_x = (scene->width + MER_TILE - 1) / MER_TILE; P.tiles_y = (scene->height + MER_TILE - 1) / MER_TILE;
+    const int ntiles = P.tiles_x * P.tiles_y;
+    P.ntiles_mine = (ntiles - shard->tile_rank + shard->tile_count - 1) / shard->tile_count;
+    P.total_work = (uint64_t) P.ntiles_mine * MER_TILE * MER_TILE * (uint64_t) shard->spp_count;
+    P.film = film_dev; P.path_out = path_out_dev;
+    HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    HIP_CHECK(ctx, hipMemsetAsync(P.work_counter, 0, sizeof(unsigned long long), ctx->stream));
+    if (P.total_work == 0) return 0;
+    return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
+        auto kern = render_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
+        int per_cu = 0;
+        HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, MER_BLOCK, 0));
+        if (per_cu < 1) per_cu = 1;
+        int64_t blocks = (int64_t) per_cu * ctx->prop.multiProcessorCount;
+        const int64_t need = (int64_t) ((P.total_work + MER_BLOCK - 1) / MER_BLOCK);
+        if (blocks > need) blocks = need;
+        HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        hipLaunchKernelGGL(kern, dim3((unsigned) blocks), dim3(MER_BLOCK), 0, ctx->stream, P);
+        HIP_CHECK(ctx, hipGetLastError());
+        HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        ctx->timed = true;
+        return 0;
+    });
+}
+
+int mer_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed, float *film_dev) {
+    if (!ctx || !scene || !film_dev) return 1;
+    return launch_render(ctx, scene, shard, seed, film_dev, nullptr);
+}
+
+int mer_render_paths(mer_context *ctx, const mer_scene_desc *scene, int32_t sample_index, uint64_t seed, float *out_rgb) {
+    if (!ctx || !scene || !out_rgb) return 1;
+    const size_t n = (size_t) scene->width * scene->height * 3;
+    DevBuf buf(ctx);
+    if (buf.alloc(n * 4)) return 1;
+    HIP_CHECK(ctx, hipMemsetAsync(buf.p, 0, n * 4, ctx->stream));
+    mer_shard sh = {sample_index, 1, 1, 0, 1};
+    if (launch_render(ctx, scene, &sh, seed, buf.as<float>(), buf.as<float>())) return 1;
+    return buf.download(out_rgb, n * 4);
+}
+
+int mer_synchronize(mer_context *ctx) { HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return 0; }
+
+int mer_last_kernel_ms(mer_context *ctx, float *ms) {
+    if (!ctx->timed) return fail(ctx, "no render has been launched");
+    HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+    HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
+int mer_counters_read(mer_context *ctx, uint64_t out[MER_C_COUNT]) {
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_CHECK(ctx, hipMemcpy(out, ctx->counters, sizeof(uint64_t) * MER_C_COUNT, hipMemcpyDeviceToHost));
+    return 0;
+}
+int mer_counters_reset(mer_context *ctx) {
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(uint64_t) * MER_C_COUNT, ctx->stream));
+    return 0;
+}
+
+// ---- leaf entry points ------------------------------------------------------------------------------
+int mer_lookup_trilinear(mer_context *ctx, mer_volume h, const float *pts, int64_t n, float *out_val, int32_t *out_idx) {
+    auto it = ctx->volumes.find(h);
+    if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
+    if (it->second.desc.channels != 1) return fail(ctx, "lookupFloat(): volume does not support float lookups");
+    DGrid g; fill_dgrid(it->second, g);
+    DevBuf dp(ctx), dv(ctx), di(ctx);
+    if (dp.upload(pts, n * 12) || dv.alloc(n * 4) || di.alloc(n * 16)) return 1;
+    hipLaunchKernelGGL(lookup_trilinear_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, g, dp.as<float>(), n, dv.as<float>(),
+                       out_idx ? di.as<int32_t>() : (int32_t *) nullptr);
+    HIP_CHECK(ctx, hipGetLastError());
+    if (dv.download(out_val, n * 4)) return 1;
+    if (out_idx && di.download(out_idx, n * 16)) return 1;
+    return 0;
+}
+int mer_lookup_trilinear_rgb(mer_context *ctx, mer_volume h, const float *pts, int64_t n, float *out_rgb) {
+    auto it = ctx->volumes.find(h);
+    if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
+    if (it->second.desc.channels != 3) return fail(ctx, "lookupSpectrum(): volume does not support spectrum lookups");
+    Volume tmp = it->second; tmp.cell8 = nullptr;
+    DGrid g; fill_dgrid(tmp, g);
+    DevBuf dp(ctx), dv(ctx);
+    if (dp.upload(pts, n * 12) || dv.alloc(n * 12)) return 1;
+    hipLaunchKernelGGL(lookup_rgb_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, g, dp.as<float>(), n, dv.as<float>());
+    HIP_CHECK(ctx, hipGetLastError());
+    return dv.download(out_rgb, n * 12);
+}
+int mer_rif_value_grad(mer_context *ctx, mer_volume h, int32_t interp, const float *pts, int64_t n, float *out_val, float *out_grad) {
+    auto it = ctx->volumes.find(h);
+    if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
+    if (it->second.desc.channels != 1 || it->second.desc.dtype != MER_VOL_F32) return fail(ctx, "value(): not implemented for this volume type"); // volume.cpp:57-80
+    if (interp != MER_RIF_TRILINEAR && interp != MER_RIF_BSPLINE3) return fail(ctx, "unknown rif_interp");
+    if (interp == MER_RIF_BSPLINE3 && !it->second.coeff) return fail(ctx, "volume has no spline coefficients");
+    DGrid g; fill_dgrid(it->second, g);
+    DevBuf dp(ctx), dv(ctx), dg(ctx);
+    if (dp.upload(pts, n * 12) || dv.alloc(n * 4) || dg.alloc(n * 12)) return 1;
+    hipLaunchKernelGGL(rif_value_grad_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, g, interp, dp.as<float>(), n, dv.as<float>(), dg.as<float>());
+    HIP_CHECK(ctx, hipGetLastError());
+    if (dv.download(out_val, n * 4)) return 1;
+    return dg.download(out_grad, n * 12);
+}
+
+int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0, const float *d0, const float *dist, int64_t n,
+                 float *out_p, float *out_v, float *out_dist_surf, float *out_opt, int32_t *out_success) {
+    Params P;
+    if (make_params(ctx, scene, P)) return 1;
+    if (scene->rif_mode == MER_RIF_CONST) return fail(ctx, "mer_er_trace needs a RIF volume");
+    DevBuf a(ctx), b(ctx), c(ctx), op(ctx), ov(ctx), od(ctx), oo(ctx), ok(ctx);
+    if (a.upload(p0, n * 12) || b.upload(d0, n * 12) || c.upload(dist, n * 4) || op.alloc(n * 12) || ov.alloc(n * 12) ||
+        od.alloc(n * 4) || oo.alloc(n * 4) || ok.alloc(n * 4)) return 1;
+#define MER_TRACE_CASE(R, S)                                                                                       \
+    if (scene->rif_mode == R && scene->stepper == S)                                                               \
+        hipLaunchKernelGGL((er_trace_kernel<R, S>), dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), \
+                           c.as<float>(), n, op.as<float>(), ov.as<float>(), od.as<float>(), oo.as<float>(), ok.as<int32_t>());
+    MER_TRACE_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET) MER_TRACE_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4)
+    MER_TRACE_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET) MER_TRACE_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4)
+#undef MER_TRACE_CASE
+    HIP_CHECK(ctx, hipGetLastError());
+    if (op.download(out_p, n * 12) || ov.download(out_v, n * 12) || od.download(out_dist_surf, n * 4) || oo.download(out_opt, n * 4) ||
+        ok.download(out_success, n * 4)) return 1;
+    return 0;
+}
+
+int mer_sample_distance(mer_context *ctx, const mer_scene_desc *scene, const float *o, const float *d, const float *maxt, int64_t n,
+                        uint64_t seed, float *rec) {
+    Params P;
+    if (make_params(ctx, scene, P)) return 1;
+    P.seed = seed;
+    DevBuf a(ctx), b(ctx), c(ctx), r(ctx);
+    if (a.upload(o, n * 12) || b.upload(d, n * 12) || c.upload(maxt, n * 4) || r.alloc(n * 80)) return 1;
+    int rc = dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
+        hipLaunchKernelGGL((sample_distance_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>),
+                           dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), c.as<float>(), n, r.as<float>());
+        HIP_CHECK(ctx, hipGetLastError());
+        return 0;
+    });
+    if (rc) return rc;
+    return r.download(rec, n * 80);
+}
+
+int mer_eval_transmittance(mer_context *ctx, const mer_scene_desc *scene, const float *o, const float *d, const float *maxt, int64_t n,
+                           uint64_t seed, float *out_tr) {
+    Params P;
+    if (make_params(ctx, scene, P)) return 1;
+    P.seed = seed;
+    DevBuf a(ctx), b(ctx), c(ctx), r(ctx);
+    if (a.upload(o, n * 12) || b.upload(d, n * 12) || c.upload(maxt, n * 4) || r.alloc(n * 12)) return 1;
+    int rc = dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
+        hipLaunchKernelGGL((eval_transmittance_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>),
+                           dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), c.as<float>(), n, r.as<float>());
+        HIP_CHECK(ctx, hipGetLastError());
+        return 0;
+    });
+    if (rc) return rc;
+    return r.download(out_tr, n * 12);
+}
+
+int mer_phase_sample(mer_context *ctx, int32_t phase, float g, const float *wi, const float *u2, int64_t n, float *wo, float *pdf) {
+    if (phase == MER_PHASE_HG && (g >= 1 || g <= -1)) return fail(ctx, "The asymmetry parameter must lie in the interval (-1, 1)!");
+    DevBuf a(ctx), b(ctx), c(ctx), e(ctx);
+    if (a.upload(wi, n * 12) || b.upload(u2, n * 8) || c.alloc(n * 12) || e.alloc(n * 4)) return 1;
+    hipLaunchKernelGGL(phase_sample_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, phase, g, a.as<float>(), b.as<float>(), n, c.as<float>(), e.as<float>());
+    HIP_CHECK(ctx, hipGetLastError());
+    if (c.download(wo, n * 12)) return 1;
+    return e.download(pdf, n * 4);
+}
+int mer_phase_eval(mer_context *ctx, int32_t phase, float g, const float *wi, const float *wo, int64_t n, float *val) {
+    DevBuf a(ctx), b(ctx), c(ctx);
+    if (a.upload(wi, n * 12) || b.upload(wo, n * 12) || c.alloc(n * 4)) return 1;
+    hipLaunchKernelGGL(phase_eval_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, phase, g, a.as<float>(), b.as<float>(), n, c.as<float>());
+    HIP_CHECK(ctx, hipGetLastError());
+    return c.download(val, n * 4);
+}
+int mer_camera_rays(mer_context *ctx, const mer_scene_desc *scene, const float *pos2, int64_t n, float *o, float *d) {
+    Params P;
+    mer_scene_desc sc = *scene; sc.sigma_mode = MER_SIGMA_HOMOGENEOUS; sc.rif_mode = MER_RIF_CONST; sc.albedo_mode = MER_ALBEDO_CONST;
+    if (make_params(ctx, &sc, P)) return 1;
+    DevBuf a(ctx), b(ctx), c(ctx);
+    if (a.upload(pos2, n * 8) || b.alloc(n * 12) || c.alloc(n * 12)) return 1;
+    hipLaunchKernelGGL(camera_rays_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, P, a.as<float>(), n, b.as<float>(), c.as<float>());
+    HIP_CHECK(ctx, hipGetLastError());
+    if (b.download(o, n * 12)) return 1;
+    return c.download(d, n * 12);
+}
+int mer_rng_floats(mer_context *ctx, uint64_t seed, uint32_t pixel, uint32_t sample, int32_t n, float *out) {
+    DevBuf a(ctx);
+    if (a.alloc((size_t) n * 4)) return 1;
+    hipLaunchKernelGGL(rng_kernel, dim3(1), dim3(64), 0, ctx->stream, seed, pixel, sample, n, a.as<float>());
+    HIP_CHECK(ctx, hipGetLastError());
+    return a.download(out, (size_t) n * 4);
+}
+int mer_synth_field_dev(mer_context *ctx, int32_t kind, int32_t N, float **data_dev) {
+    if (kind < 0 || kind > 2 || N < 2) return fail(ctx, "mer_synth_field_dev: bad arguments");
+    HIP_CHECK(ctx, hipMalloc((void **) data_dev, (size_t) N * N * N * 4));
+    hipLaunchKernelGGL(synth_field_kernel, dim3(8192), dim3(256), 0, ctx->stream, kind, N, *data_dev);
+    HIP_CHECK(ctx, hipGetLastError());
+    HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

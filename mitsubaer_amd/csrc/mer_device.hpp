@@ -1,0 +1,415 @@
+// mer_device.hpp -- gfx950 device functions of the refractive volumetric path-tracing hot path.
+// Written for wave64 CDNA4; compiled with -ffp-contract=off so the arithmetic is the one written here.
+// Reference citations (file:line) are into cmu-ci-lab/MitsubaER.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mer.h"
+
+#define MER_EPSILON 1e-4f                 // include/mitsuba/core/constants.h:25-31 (single precision)
+#define MER_PI 3.14159265358979323846f
+#define MER_INV_FOURPI 0.07957747154594766788f
+#define MER_INF __builtin_huge_valf()
+
+namespace mer {
+
+struct f3 {
+    float x, y, z;
+    __host__ __device__ __forceinline__ f3() {}
+    __host__ __device__ __forceinline__ f3(float a, float b, float c) : x(a), y(b), z(c) {}
+};
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return f3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+// TVector3::operator/(T): reciprocal then multiply (include/mitsuba/core/vector.h:548-557)
+__device__ __forceinline__ f3 operator/(f3 a, float s) { float r = 1.0f / s; return f3(a.x * r, a.y * r, a.z * r); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ __forceinline__ f3 normalize(f3 a) { return a / sqrtf(dot(a, a)); }
+__device__ __forceinline__ float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
+__device__ __forceinline__ bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+
+// ------------------------------------------------------------------------------------------------
+// Sampler: counter-based PCG32 stream per (pixel, sample); float conversion as Random::nextFloat
+// (src/libcore/random.cpp:630-639: 23 mantissa bits in [1,2) minus 1).
+struct Rng {
+    uint64_t state, inc;
+    __device__ __forceinline__ static uint64_t splitmix64(uint64_t x) {
+        x += 0x9E3779B97F4A7C15ULL;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+        return x ^ (x >> 31);
+    }
+    __device__ __forceinline__ void seed(uint64_t seedv, uint32_t pixel, uint32_t sample) {
+        uint64_t initseq = ((uint64_t) sample << 32) | (uint64_t) pixel;
+        state = 0; inc = (initseq << 1) | 1ULL;
+        next();
+        state += splitmix64(seedv);
+        next();
+    }
+    __device__ __forceinline__ uint32_t next() {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        uint32_t xorshifted = (uint32_t) (((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t) (old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+    }
+    __device__ __forceinline__ float next1D() { return __uint_as_float((next() >> 9) | 0x3f800000u) - 1.0f; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Device view of an uploaded grid (GridDataSource / SplineDataSource).
+struct DGrid {
+    const void  *data;        // dense: x fastest [z][y][x][c]
+    const float *cell8;       // MER_LAYOUT_CELL8: 8 corner values per cell, [z][y][x][8] over (res-1)^3 cells
+    const float *coeff;       // cubic B-spline coefficients (dense) or NULL
+    int32_t res[3];
+    int32_t channels, dtype, layout;
+    float   s[3], t[3];       // worldToGrid diagonal + translation (gridvolume.cpp:188-195, toWorld = identity)
+    float   bmin[3], bmax[3];
+    float   lim_min[3], lim_max[3];   // spline interpolatable limits (splinevolume.cpp:280-281)
+};
+
+// include/mitsuba/core/aabb.h:308-339 (dRcp = 1/d as Ray::setDirection)
+__device__ __forceinline__ bool aabb_intersect(const float mn[3], const float mx[3], f3 o, f3 d, float &nearT, float &farT) {
+    nearT = -MER_INF; farT = MER_INF;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (dd[i] == 0.0f) {
+            if (oo[i] < mn[i] || oo[i] > mx[i]) return false;
+        } else {
+            const float dRcp = 1.0f / dd[i];
+            float t1 = (mn[i] - oo[i]) * dRcp, t2 = (mx[i] - oo[i]) * dRcp;
+            if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; }
+            nearT = fmaxf(t1, nearT);
+            farT = fminf(t2, farT);
+            if (!(nearT <= farT)) return false;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ float grid_fetch(const DGrid &g, long long idx) {
+    if (g.dtype == MER_VOL_F32) return ((const float *) g.data)[idx];
+    return (float) ((const uint8_t *) g.data)[idx] / 255.0f;      // m_densityMap, gridvolume.cpp:204-214
+}
+
+// GridDataSource::lookupFloat (gridvolume.cpp:337-388).  The integer part (x1,y1,z1, bounds test, linear
+// index) is the bit-exact contract; the blend keeps the reference's operation order.
+__device__ __forceinline__ float lookup_float(const DGrid &g, f3 p, int *idx4 = nullptr) {
+    const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
+    const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
+    if (idx4) { idx4[0] = x1; idx4[1] = y1; idx4[2] = z1; idx4[3] = -1; }
+    if (x1 < 0 || y1 < 0 || z1 < 0 || x1 + 1 >= g.res[0] || y1 + 1 >= g.res[1] || z1 + 1 >= g.res[2]) return 0.0f;
+    const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
+                _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
+    const int base = (z1 * g.res[1] + y1) * g.res[0] + x1;
+    if (idx4) idx4[3] = base;
+    float d000, d001, d010, d011, d100, d101, d110, d111;
+    if (g.layout == MER_LAYOUT_CELL8) {
+        const int cell = (z1 * (g.res[1] - 1) + y1) * (g.res[0] - 1) + x1;
+        const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
+        const float4 a = c[0], b = c[1];
+        d000 = a.x; d001 = a.y; d010 = a.z; d011 = a.w; d100 = b.x; d101 = b.y; d110 = b.z; d111 = b.w;
+    } else {
+        const int sy = g.res[0], sz = g.res[0] * g.res[1];
+        d000 = grid_fetch(g, base);          d001 = grid_fetch(g, base + 1);
+        d010 = grid_fetch(g, base + sy);     d011 = grid_fetch(g, base + sy + 1);
+        d100 = grid_fetch(g, base + sz);     d101 = grid_fetch(g, base + sz + 1);
+        d110 = grid_fetch(g, base + sz + sy); d111 = grid_fetch(g, base + sz + sy + 1);
+    }
+    return ((d000 * _fx + d001 * fx) * _fy + (d010 * _fx + d011 * fx) * fy) * _fz +
+           ((d100 * _fx + d101 * fx) * _fy + (d110 * _fx + d111 * fx) * fy) * fz;
+}
+
+// GridDataSource::lookupSpectrum (gridvolume.cpp:390-421), 3 channels
+__device__ __forceinline__ f3 lookup_spectrum(const DGrid &g, f3 p) {
+    const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
+    const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
+    if (x1 < 0 || y1 < 0 || z1 < 0 || x1 + 1 >= g.res[0] || y1 + 1 >= g.res[1] || z1 + 1 >= g.res[2]) return f3(0, 0, 0);
+    const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
+                _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
+    const int base = (z1 * g.res[1] + y1) * g.res[0] + x1, sy = g.res[0], sz = g.res[0] * g.res[1];
+    float out[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const long long b3 = (long long) base * 3 + c, y3 = (long long) sy * 3, z3 = (long long) sz * 3;
+        const float d000 = grid_fetch(g, b3), d001 = grid_fetch(g, b3 + 3),
+                    d010 = grid_fetch(g, b3 + y3), d011 = grid_fetch(g, b3 + y3 + 3),
+                    d100 = grid_fetch(g, b3 + z3), d101 = grid_fetch(g, b3 + z3 + 3),
+                    d110 = grid_fetch(g, b3 + z3 + y3), d111 = grid_fetch(g, b3 + z3 + y3 + 3);
+        out[c] = ((d000 * _fx + d001 * fx) * _fy + (d010 * _fx + d011 * fx) * fy) * _fz +
+                 ((d100 * _fx + d101 * fx) * _fy + (d110 * _fx + d111 * fx) * fy) * fz;
+    }
+    return f3(out[0], out[1], out[2]);
+}
+
+// Trilinear value + analytic gradient of the interpolant; cell clamped to the grid (new --
+// gridvolume has no value()/gradient(), src/librender/volume.cpp:57-80).  Value keeps lookupFloat's blend.
+__device__ __forceinline__ void trilinear_value_grad(const DGrid &g, f3 p, float &val, f3 &grad) {
+    const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
+    int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
+    x1 = min(max(x1, 0), g.res[0] - 2); y1 = min(max(y1, 0), g.res[1] - 2); z1 = min(max(z1, 0), g.res[2] - 2);
+    const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
+                _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
+    float d000, d001, d010, d011, d100, d101, d110, d111;
+    if (g.layout == MER_LAYOUT_CELL8) {
+        const int cell = (z1 * (g.res[1] - 1) + y1) * (g.res[0] - 1) + x1;
+        const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
+        const float4 a = c[0], b = c[1];
+        d000 = a.x; d001 = a.y; d010 = a.z; d011 = a.w; d100 = b.x; d101 = b.y; d110 = b.z; d111 = b.w;
+    } else {
+        const float *D = (const float *) g.data;
+        const int base = (z1 * g.res[1] + y1) * g.res[0] + x1, sy = g.res[0], sz = g.res[0] * g.res[1];
+        d000 = D[base]; d001 = D[base + 1]; d010 = D[base + sy]; d011 = D[base + sy + 1];
+        d100 = D[base + sz]; d101 = D[base + sz + 1]; d110 = D[base + sz + sy]; d111 = D[base + sz + sy + 1];
+    }
+    const float c00 = d000 * _fx + d001 * fx, c01 = d010 * _fx + d011 * fx,
+                c10 = d100 * _fx + d101 * fx, c11 = d110 * _fx + d111 * fx;
+    const float c0 = c00 * _fy + c01 * fy, c1 = c10 * _fy + c11 * fy;
+    val = c0 * _fz + c1 * fz;
+    const float gx = ((d001 - d000) * _fy + (d011 - d010) * fy) * _fz + ((d101 - d100) * _fy + (d111 - d110) * fy) * fz;
+    const float gy = (c01 - c00) * _fz + (c11 - c10) * fz;
+    const float gz = c1 - c0;
+    grad = f3(gx * g.s[0], gy * g.s[1], gz * g.s[2]);
+}
+
+// Cubic B-spline basis and derivative at the 4 taps around x (include/mitsuba/core/basisspline.h:40-72).
+// t = x - floor(x) in [0,1); tap distances t+1, t, t-1, t-2.
+__device__ __forceinline__ void bspline_weights(float t, float w[4], float dw[4]) {
+    const float a = 1.0f - t;              // 2 - (t+1)
+    // |x| in (1,2]: (1/6)(2-|x|)^3 ; |x| <= 1: 2/3 - x^2 + x^3/2
+    const float x0 = t + 1.0f, x3 = 2.0f - t, x2 = 1.0f - t;
+    w[0] = (1.0f / 6.0f) * (2.0f - x0) * (2.0f - x0) * (2.0f - x0);
+    w[1] = (2.0f / 3.0f) - t * t + 0.5f * t * t * t;
+    w[2] = (2.0f / 3.0f) - x2 * x2 + 0.5f * x2 * x2 * x2;
+    w[3] = (1.0f / 6.0f) * (2.0f - x3) * (2.0f - x3) * (2.0f - x3);
+    // derivative w.r.t. x of beta(x - i): sign(x-i) * {(-1/2)(2-|.|)^2 | (1.5|.| - 2)|.|}
+    dw[0] = -0.5f * a * a;                         // distance t+1 > 0, in (1,2]
+    dw[1] = (1.5f * t - 2.0f) * t;                 // distance t >= 0
+    dw[2] = -((1.5f * x2 - 2.0f) * x2);            // distance t-1 < 0
+    dw[3] = 0.5f * t * t;                          // distance t-2 < 0, |.| = 2-t in (1,2]
+}
+
+// Spline<3>::valueAndGradient (basisspline.h:438-471) with the per-axis weights hoisted.
+// Caller guarantees the point lies inside the interpolatable limits (splinevolume.cpp:319-324).
+__device__ __forceinline__ void bspline_value_grad(const DGrid &g, f3 p, float &val, f3 &grad) {
+    const float px = (p.x - g.bmin[0]) * g.s[0], py = (p.y - g.bmin[1]) * g.s[1], pz = (p.z - g.bmin[2]) * g.s[2];  // convertToX :655-658
+    const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+    float wx[4], dwx[4], wy[4], dwy[4], wz[4], dwz[4];
+    bspline_weights(px - flx, wx, dwx);
+    bspline_weights(py - fly, wy, dwy);
+    bspline_weights(pz - flz, wz, dwz);
+    int ix = (int) flx - 1, iy = (int) fly - 1, iz = (int) flz - 1;
+    ix = min(max(ix, 0), g.res[0] - 4); iy = min(max(iy, 0), g.res[1] - 4); iz = min(max(iz, 0), g.res[2] - 4);  // memory safety only
+    const float *C = g.coeff + ((size_t) iz * g.res[1] + iy) * g.res[0] + ix;
+    const int sy = g.res[0], sz = g.res[0] * g.res[1];
+    float f = 0.0f, gx = 0.0f, gy = 0.0f, gz = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float fk = 0.0f, gxk = 0.0f, gyk = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float *row = C + k * sz + j * sy;
+            const float c0 = row[0], c1 = row[1], c2 = row[2], c3 = row[3];
+            const float rx = c0 * wx[0] + c1 * wx[1] + c2 * wx[2] + c3 * wx[3];
+            const float rdx = c0 * dwx[0] + c1 * dwx[1] + c2 * dwx[2] + c3 * dwx[3];
+            fk += rx * wy[j]; gxk += rdx * wy[j]; gyk += rx * dwy[j];
+        }
+        f += fk * wz[k]; gx += gxk * wz[k]; gy += gyk * wz[k]; gz += fk * dwz[k];
+    }
+    val = f;
+    grad = f3(gx * g.s[0], gy * g.s[1], gz * g.s[2]);      // * dxres, basisspline.h:467-469
+}
+
+__device__ __forceinline__ bool inside_volume_limits(const DGrid &g, f3 p) {   // splinevolume.cpp:319-324
+    return p.x > g.lim_min[0] && p.x < g.lim_max[0] && p.y > g.lim_min[1] && p.y < g.lim_max[1] &&
+           p.z > g.lim_min[2] && p.z < g.lim_max[2];
+}
+
+template <int RIF> __device__ __forceinline__ void rif_value_grad(const DGrid &g, f3 p, float &n, f3 &gr) {
+    if (RIF == MER_RIF_TRILINEAR) trilinear_value_grad(g, p, n, gr);
+    else bspline_value_grad(g, p, n, gr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// er_step: velocity-Verlet (heterogeneousrefractive.cpp:653-661) or classic RK4 on
+// dp/ds = v/n, dv/ds = grad n, dopt/ds = n.  Returns the number of field evaluations.
+template <int RIF, int STEPPER>
+__device__ __forceinline__ void er_step(const DGrid &g, f3 &p, f3 &v, float h, float &opt) {
+    if (STEPPER == MER_STEP_VERLET) {
+        float n, n2; f3 G, G2;
+        rif_value_grad<RIF>(g, p, n, G);
+        v = v + 0.5f * h * G;
+        p = p + h * v / n;
+        rif_value_grad<RIF>(g, p, n2, G2);
+        v = v + 0.5f * h * G2;
+        opt += h * n;
+    } else {
+        float n1, n2, n3, n4; f3 g1, g2, g3, g4;
+        const float hh = 0.5f * h;
+        rif_value_grad<RIF>(g, p, n1, g1);
+        const f3 kp1 = v / n1;
+        const f3 v2 = v + hh * g1;
+        rif_value_grad<RIF>(g, p + hh * kp1, n2, g2);
+        const f3 kp2 = v2 / n2;
+        const f3 v3 = v + hh * g2;
+        rif_value_grad<RIF>(g, p + hh * kp2, n3, g3);
+        const f3 kp3 = v3 / n3;
+        const f3 v4 = v + h * g3;
+        rif_value_grad<RIF>(g, p + h * kp3, n4, g4);
+        const f3 kp4 = v4 / n4;
+        const float h6 = h / 6.0f;
+        p = p + h6 * (kp1 + 2.0f * kp2 + 2.0f * kp3 + kp4);
+        v = v + h6 * (g1 + 2.0f * g2 + 2.0f * g3 + g4);
+        opt += h6 * (n1 + 2.0f * n2 + 2.0f * n3 + n4);
+    }
+}
+template <int STEPPER> __device__ __forceinline__ constexpr int evals_per_step() { return STEPPER == MER_STEP_VERLET ? 2 : 4; }
+
+// ------------------------------------------------------------------------------------------------
+// Phase functions (src/phase/hg.cpp:74-110, src/phase/isotropic.cpp:62-78); wi points away from the vertex.
+__device__ __forceinline__ float safe_sqrt(float v) { return sqrtf(fmaxf(0.0f, v)); }      // math.h:260-267
+__device__ __forceinline__ f3 square_to_uniform_sphere(float sx, float sy) {                  // warp.cpp:25-31
+    const float z = 1.0f - 2.0f * sy;
+    const float r = safe_sqrt(1.0f - z * z);
+    const float phi = 2.0f * MER_PI * sx;
+    return f3(r * cosf(phi), r * sinf(phi), z);
+}
+__device__ __forceinline__ void coordinate_system(f3 a, f3 &b, f3 &c) {                       // util.cpp:606-615
+    if (fabsf(a.x) > fabsf(a.y)) {
+        const float invLen = 1.0f / sqrtf(a.x * a.x + a.z * a.z);
+        c = f3(a.z * invLen, 0.0f, -a.x * invLen);
+    } else {
+        const float invLen = 1.0f / sqrtf(a.y * a.y + a.z * a.z);
+        c = f3(0.0f, a.z * invLen, -a.y * invLen);
+    }
+    b = cross(c, a);
+}
+__device__ __forceinline__ float phase_eval(int kind, float g, f3 wi, f3 wo) {
+    if (kind == MER_PHASE_ISOTROPIC) return MER_INV_FOURPI;
+    const float temp = 1.0f + g * g + 2.0f * g * dot(wi, wo);
+    return MER_INV_FOURPI * (1 - g * g) / (temp * sqrtf(temp));
+}
+__device__ __forceinline__ float phase_sample(int kind, float g, f3 wi, float sx, float sy, f3 &wo, float &pdf) {
+    if (kind == MER_PHASE_ISOTROPIC) { wo = square_to_uniform_sphere(sx, sy); pdf = MER_INV_FOURPI; return 1.0f; }
+    float cosTheta;
+    if (fabsf(g) < MER_EPSILON) cosTheta = 1 - 2 * sx;
+    else {
+        const float sqrTerm = (1 - g * g) / (1 - g + 2 * g * sx);
+        cosTheta = (1 + g * g - sqrTerm * sqrTerm) / (2 * g);
+    }
+    const float sinTheta = safe_sqrt(1.0f - cosTheta * cosTheta);
+    const float phi = 2 * MER_PI * sy, sinPhi = sinf(phi), cosPhi = cosf(phi);
+    const f3 n = -wi; f3 s, t;
+    coordinate_system(n, s, t);                                    // Frame(n), frame.h:55-57
+    const f3 l(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+    wo = s * l.x + t * l.y + n * l.z;                              // frame.h:83-85
+    pdf = phase_eval(kind, g, wi, wo);
+    return 1.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Everything a render / leaf kernel needs, passed by value as the kernel argument.
+struct Params {
+    mer_scene_desc sc;
+    DGrid density, albedo, rif;
+    // derived
+    f3    sigA, sigS, sigT;
+    float medium_sampling_weight, sampling_density;
+    float inv_max_density;
+    float cam[12], aspect, cot_half_fov, inv_res_x, inv_res_y;
+    float fvalues[33], fradius, fscale;
+    // work
+    uint64_t seed;
+    int32_t spp_begin, spp_count, spp_stride, tile_rank, tile_count;
+    int32_t tiles_x, tiles_y, ntiles_mine;
+    uint64_t total_work;
+    float *film;
+    float *path_out;                    // per-path radiance (mer_render_paths) or NULL
+    unsigned long long *counters;       // MER_C_COUNT
+    unsigned long long *work_counter;
+};
+
+__device__ __forceinline__ bool inside_shape(const mer_scene_desc &s, f3 p) {   // heterogeneousrefractive.cpp:707-726 as data (D5)
+    if (s.boundary == MER_BOUNDARY_SPHERE) {
+        const f3 q(p.x - s.sph_center[0], p.y - s.sph_center[1], p.z - s.sph_center[2]);
+        return dot(q, q) < s.sph_radius * s.sph_radius;
+    }
+    return p.x >= s.bmin[0] && p.x <= s.bmax[0] && p.y >= s.bmin[1] && p.y <= s.bmax[1] && p.z >= s.bmin[2] && p.z <= s.bmax[2];
+}
+
+// ray / boundary-shape intersection restricted to [mint,maxt]; returns t or -1
+__device__ __forceinline__ float intersect_shape(const mer_scene_desc &s, f3 o, f3 d, float mint, float maxt) {
+    float nearT, farT;
+    if (s.boundary == MER_BOUNDARY_SPHERE) {
+        // src/shapes/sphere.cpp rayIntersect: double-precision quadratic
+        const double ox = (double) o.x - s.sph_center[0], oy = (double) o.y - s.sph_center[1], oz = (double) o.z - s.sph_center[2];
+        const double dx = d.x, dy = d.y, dz = d.z;
+        const double A = dx * dx + dy * dy + dz * dz, B = 2 * (dx * ox + dy * oy + dz * oz),
+                     C = ox * ox + oy * oy + oz * oz - (double) s.sph_radius * s.sph_radius;
+        const double disc = B * B - 4 * A * C;
+        if (disc < 0) return -1.0f;
+        const double root = sqrt(disc);
+        const double q = B < 0 ? -0.5 * (B - root) : -0.5 * (B + root);
+        double t0 = q / A, t1 = C / q;
+        if (t0 > t1) { double tmp = t0; t0 = t1; t1 = tmp; }
+        nearT = (float) t0; farT = (float) t1;
+    } else {
+        if (!aabb_intersect(s.bmin, s.bmax, o, d, nearT, farT)) return -1.0f;
+    }
+    if (!(nearT <= maxt && farT >= mint)) return -1.0f;
+    if (nearT >= mint) return nearT;
+    if (farT <= maxt) return farT;
+    return -1.0f;
+}
+
+// PerspectiveCamera::sampleRay (src/sensors/perspective.cpp:247-269) with the analytic inverse of
+// cameraToSample at the near plane (perspective.cpp:150-155, transform.cpp:99-123)
+__device__ __forceinline__ void sample_ray(const Params &P, float px, float py, f3 &o, f3 &d, float &mint, float &maxt) {
+    const float sx = px * P.inv_res_x, sy = py * P.inv_res_y;
+    const f3 nearP((1.0f - 2.0f * sx) * P.sc.near_clip / P.cot_half_fov,
+                   (1.0f - 2.0f * sy) / P.aspect * P.sc.near_clip / P.cot_half_fov, P.sc.near_clip);
+    const f3 dl = normalize(nearP);
+    const float invZ = 1.0f / dl.z;
+    mint = P.sc.near_clip * invZ; maxt = P.sc.far_clip * invZ;
+    o = f3(P.cam[3], P.cam[7], P.cam[11]);
+    d = f3(P.cam[0] * dl.x + P.cam[1] * dl.y + P.cam[2] * dl.z,
+           P.cam[4] * dl.x + P.cam[5] * dl.y + P.cam[6] * dl.z,
+           P.cam[8] * dl.x + P.cam[9] * dl.y + P.cam[10] * dl.z);
+}
+
+__device__ __forceinline__ f3 albedo_at(const Params &P, f3 p) {
+    if (P.sc.albedo_mode == MER_ALBEDO_GRID) return lookup_spectrum(P.albedo, p);
+    return f3(P.sc.albedo[0], P.sc.albedo[1], P.sc.albedo[2]);      // constvolume.cpp:57-64
+}
+
+__device__ __forceinline__ float mi_weight(float a, float b) { a *= a; b *= b; return a / (a + b); }   // volpath.cpp:430-433
+
+// ImageBlock::put (include/mitsuba/render/imageblock.h:124-205) with one block = the whole image;
+// accumulation by float atomics (replaces film->put under a mutex, renderproc.cpp:142-149)
+__device__ __forceinline__ void film_put(const Params &P, float px, float py, f3 L, float alpha) {
+    const float temp[5] = {L.x, L.y, L.z, alpha, 1.0f};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) if (!isfinite(temp[i])) return;          // imageblock.h:148-152
+    const int W = P.sc.width, H = P.sc.height;
+    const float posx = px - 0.5f, posy = py - 0.5f, r = P.fradius;
+    const int minx = max((int) ceilf(posx - r), 0), miny = max((int) ceilf(posy - r), 0),
+              maxx = min((int) floorf(posx + r), W - 1), maxy = min((int) floorf(posy + r), H - 1);
+    for (int y = miny; y <= maxy; ++y) {
+        const float wy = P.fvalues[min((int) fabsf(((float) y - posy) * P.fscale), 31)];   // rfilter.h:76-77
+        for (int x = minx; x <= maxx; ++x) {
+            const float wx = P.fvalues[min((int) fabsf(((float) x - posx) * P.fscale), 31)];
+            const float weight = wx * wy;
+            float *dest = P.film + ((size_t) y * W + x) * 5;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) atomicAdd(dest + k, weight * temp[k]);
+        }
+    }
+}
+
+}  // namespace mer

@@ -1,0 +1,466 @@
+// mer_kernels.hpp -- gfx950 kernels: the render megakernel (K_trace + K_film), leaf kernels for the
+// parity entry points, grid re-layout, B-spline prefilter, synthetic fields.
+#pragma once
+#include "mer_walk.hpp"
+
+namespace mer {
+
+#define MER_BLOCK 256
+#define MER_TILE 32
+
+// ---------------------------------------------------------------------------------------------------
+// Work decode: w -> (pixel, sample).  Sample-major; inside a pass pixels go by 32x32 image tiles (the
+// reference's block size, src/mitsuba/mitsuba.cpp:80-81) and by 8x8 sub-tiles so that the 64 lanes of a
+// fresh wavefront start on one 8x8 pixel patch (coherent camera rays, distinct film pixels per lane).
+__device__ __forceinline__ bool decode_work(const Params &P, uint64_t w, int &x, int &y, uint32_t &sample) {
+    const uint32_t npix = (uint32_t) P.ntiles_mine * (MER_TILE * MER_TILE);
+    const uint32_t s_local = (uint32_t) (w / npix);
+    const uint32_t r = (uint32_t) (w - (uint64_t) s_local * npix);
+    const uint32_t tile_local = r >> 10, q = r & 1023u, sub = q >> 6, lane = q & 63u;
+    const uint32_t tile = (uint32_t) P.tile_rank + tile_local * (uint32_t) P.tile_count;
+    const uint32_t tx = tile % (uint32_t) P.tiles_x, ty = tile / (uint32_t) P.tiles_x;
+    x = (int) (tx * MER_TILE + (sub & 3u) * 8u + (lane & 7u));
+    y = (int) (ty * MER_TILE + (sub >> 2) * 8u + (lane >> 3));
+    sample = (uint32_t) P.spp_begin + s_local * (uint32_t) P.spp_stride;
+    return x < P.sc.width && y < P.sc.height;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K_trace: VolumetricPathTracer::Li (src/integrators/path/volpath.cpp:84-343) restricted to one convex
+// index-matched shape + interior medium + constant environment emitter, with the refractive hooks of
+// src/libbidir/edge.cpp:45-60,91-93 and src/libbidir/vertex.cpp:251-255, as a lane-persistent state machine.
+template <bool CURVED, int RIF, int STEPPER, int SIGMA>
+__global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
+    typedef Walk<CURVED, RIF, STEPPER, SIGMA> WalkT;
+    const mer_scene_desc &S = P.sc;
+    const f3 env(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
+    const bool hasEnv = !is_zero(env);
+    const bool hasEmission = S.emission[0] != 0 || S.emission[1] != 0 || S.emission[2] != 0;
+    const int maxDepth = S.max_depth;
+    const int nwalks = (SIGMA == MER_SIGMA_GRID && S.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
+
+    Rng rng; rng.state = 0; rng.inc = 1;
+    LaneCounters C; C.clear();
+    WalkT W;
+    W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = false; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1;
+    W.dist = 0; W.opt = 0; W.sdens = 0; W.Tr = 1; W.trsum = 0; W.walk = 0; W.p = f3(0, 0, 0); W.v = f3(0, 0, 1);
+    int st = ST_NEW;
+    int px_i = 0, py_i = 0; float px = 0, py = 0;
+    f3 L(0, 0, 0), T(1, 1, 1);
+    int depth = 1; bool scattered = false, emitted = true;
+    f3 ps(0, 0, 0), dsave(0, 0, 1), dd(0, 0, 1), wi(0, 0, 1);
+    f3 trv(1, 1, 1);                   // transmittance of the walk that just finished
+    float phasePdf = 0, itsT = 0; bool itsValid = false;
+    uint32_t wave_iters = 0;
+
+    for (;;) {
+        int ev = EV_NONE;
+        float sigma = 0.0f;
+        // ------------------------------------------------------------------ regeneration (integrator.cpp:162-187)
+        if (st == ST_NEW) {
+            const uint64_t w = atomicAdd(P.work_counter, 1ULL);
+            if (w >= P.total_work) st = ST_DONE;
+            else {
+                uint32_t sample;
+                if (!decode_work(P, w, px_i, py_i, sample)) { /* pixel of a partial edge tile */ }
+                else {
+                    rng.seed(P.seed, (uint32_t) (py_i * S.width + px_i), sample);
+                    const float sx = rng.next1D(), sy = rng.next1D();
+                    px = (float) px_i + sx; py = (float) py_i + sy;
+                    f3 o, d; float mint, maxt;
+                    sample_ray(P, px, py, o, d, mint, maxt);
+                    L = f3(0, 0, 0); T = f3(1, 1, 1); depth = 1; scattered = false; emitted = true;
+                    C.paths++;
+                    itsT = intersect_shape(S, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
+                    if (itsT < 0) {
+                        if (!S.hide_emitters) L = L + T * env;                         // volpath.cpp:194-201
+                        ev = EV_PATH_DONE;
+                    } else if (depth >= maxDepth && maxDepth != -1) ev = EV_PATH_DONE;
+                    else {
+                        (void) rng.next1D(); (void) rng.next1D();                      // null bsdf->sample(..., nextSample2D())
+                        const f3 ro = o + d * itsT;
+                        bool medium = true;
+                        if (CURVED) { itsT = 0; itsValid = true; }
+                        else { itsT = intersect_shape(S, ro, d, MER_EPSILON, MER_INF); itsValid = itsT >= 0; if (!itsValid) medium = false; }
+                        depth++;
+                        if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
+                        else if (!medium) { if (!S.hide_emitters) L = L + T * env; ev = EV_PATH_DONE; }
+                        else { C.segments++; ps = ro; dsave = d; ev = W.begin(P, rng, C, K_FREE, ro, d, itsT); st = ST_MARCH; }
+                    }
+                }
+            }
+        } else if (st == ST_MARCH) {
+            ev = W.advance(P, rng, C);
+        }
+        wave_iters++;
+        if (st == ST_DONE) break;
+
+        // ------------------------------------------------------------------ events
+        while (ev != EV_NONE) {
+            if (ev == EV_ARRIVED) {
+                ev = W.on_arrived(P, rng, C, sigma);
+            } else if (ev == EV_EXITED) {
+                ev = (W.kind == K_FREE) ? EV_FAIL : EV_WALK_END;
+            } else if (ev == EV_GATE_FAIL) {
+                if (W.kind == K_FREE) ev = EV_PATH_DONE;          // transmittance 0 => nothing further contributes
+                else { trv = f3(0, 0, 0); ev = EV_TR_DONE; }
+            } else if (ev == EV_WALK_END) {
+                W.trsum += W.Tr; W.walk++;
+                if (W.walk < nwalks) ev = W.begin(P, rng, C, W.kind, ps, W.kind == K_NEE ? dd : dsave, itsT, false);
+                else {
+                    if (SIGMA == MER_SIGMA_GRID) { const float tv = W.trsum / (float) nwalks; trv = f3(tv, tv, tv); }
+                    else trv = homogeneous_transmittance(P, -W.dist);                    // heterogeneousrefractive.cpp:393-400
+                    ev = EV_TR_DONE;
+                }
+            } else if (ev == EV_REAL) {
+                // ---- medium interaction: volpath.cpp:104-118
+                MRec m;
+                finish_free_flight(P, C, W, true, sigma, m);
+                bool success = true;
+                if (SIGMA == MER_SIGMA_HOMOGENEOUS) {
+                    const f3 o0 = ps;
+                    if (m.p.x == o0.x && m.p.y == o0.y && m.p.z == o0.z) success = false;   // no forward progress
+                }
+                if (!success) { ev = EV_FAIL; continue; }
+                C.real++;
+                if (depth >= maxDepth && maxDepth != -1) { ev = EV_PATH_DONE; continue; }
+                if (hasEmission && SIGMA == MER_SIGMA_GRID)
+                    L = L + T * f3(S.emission[0], S.emission[1], S.emission[2]) * m.refRatioSq;
+                T = T * (m.sigmaS * m.transmittance / m.pdfSuccess);
+                if (CURVED) T = T * m.refRatioSq;                                         // edge.cpp:91-93
+                wi = CURVED ? normalize(-m.d) : -W.v;                                     // vertex.cpp:251-255
+                ps = m.p;
+                if (hasEnv) {
+                    // ---- luminaire sampling: scene.cpp:854-874, constant.cpp:179-214
+                    C.nee++;
+                    const int interactions = maxDepth - depth - 1;
+                    const float s2x = rng.next1D(), s2y = rng.next1D();
+                    dd = square_to_uniform_sphere(s2x, s2y);
+                    W.kind = K_NEE;
+                    if (interactions != 0) {                                              // scene.cpp:619-678: one null crossing
+                        float tExit = 0.0f;
+                        if (!CURVED) tExit = intersect_shape(S, ps, dd, 0.0f, MER_INF);
+                        if (tExit >= 0) {
+                            itsT = tExit;
+                            ev = W.begin(P, rng, C, K_NEE, ps, dd, tExit);
+                            if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - tExit);
+                        } else { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
+                    } else { trv = f3(0, 0, 0); ev = EV_TR_DONE; }
+                } else ev = EV_PHASE;
+            } else if (ev == EV_TR_DONE) {
+                const f3 tr = trv;
+                if (W.kind == K_NEE) {
+                    const float dpdf = MER_INV_FOURPI;
+                    f3 value = env / dpdf;
+                    value = value * tr;
+                    if (!is_zero(value)) {
+                        const float phaseVal = phase_eval(S.phase, S.g, wi, dd);
+                        if (phaseVal != 0) {
+                            const float weight = mi_weight(dpdf, phaseVal);              // env emitter is "on surface": constant.cpp:47
+                            L = L + T * value * phaseVal * weight;
+                        }
+                    }
+                    ev = EV_PHASE;
+                } else {
+                    // emitter look-up along the phase-sampled direction: volpath.cpp:162-173,370-428
+                    const int maxInteractions = maxDepth - depth - 1;
+                    const bool blocked = (maxInteractions == 0) && (CURVED || itsValid);
+                    if (!blocked && !is_zero(tr)) {
+                        const f3 value = tr * env;
+                        L = L + T * value * mi_weight(phasePdf, MER_INV_FOURPI);
+                    }
+                    ev = EV_AFTER_LOOKUP;
+                }
+            } else if (ev == EV_PHASE) {
+                // ---- phase function sampling: volpath.cpp:149-160
+                const float p2x = rng.next1D(), p2y = rng.next1D();
+                f3 wo;
+                phase_sample(S.phase, S.g, wi, p2x, p2y, wo, phasePdf);
+                dsave = wo;
+                if (CURVED) { itsT = 0; itsValid = true; }
+                else { itsT = intersect_shape(S, ps, wo, 0.0f, MER_INF); itsValid = itsT >= 0; }
+                if (hasEnv) {
+                    W.kind = K_LOOKUP;
+                    if (!CURVED && !itsValid) { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
+                    else {
+                        ev = W.begin(P, rng, C, K_LOOKUP, ps, wo, itsT);
+                        if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - itsT);
+                    }
+                } else ev = EV_AFTER_LOOKUP;
+            } else if (ev == EV_AFTER_LOOKUP) {
+                emitted = false;                                                          // ERadianceNoEmission
+                ev = EV_NONE;
+                if (depth++ >= S.rr_depth) {                                              // volpath.cpp:326-336
+                    const float q = fminf(max3(T) * 1.0f * 1.0f, 0.95f);
+                    if (rng.next1D() >= q) ev = EV_PATH_DONE;
+                    else T = T / q;
+                }
+                if (ev == EV_NONE) {
+                    scattered = true;
+                    if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
+                    else { C.segments++; ev = W.begin(P, rng, C, K_FREE, ps, dsave, itsT); }
+                }
+            } else if (ev == EV_FAIL) {
+                // ---- no medium interaction: volpath.cpp:183-201,289-301
+                MRec m;
+                finish_free_flight(P, C, W, false, 0.0f, m);
+                T = T * (m.transmittance / m.pdfFailure);
+                if (CURVED) { T = T * m.refRatioSq; itsValid = true; }                    // edge.cpp:45-60
+                ev = EV_PATH_DONE;
+                if (!itsValid) {
+                    if (emitted && (!S.hide_emitters || scattered)) L = L + T * env;
+                } else if (!(depth >= maxDepth && maxDepth != -1)) {
+                    (void) rng.next1D(); (void) rng.next1D();                             // null BSDF sample
+                    emitted = !scattered;
+                    depth++;
+                    if (depth <= maxDepth || maxDepth < 0)
+                        if (emitted && (!S.hide_emitters || scattered)) L = L + T * env;
+                }
+            } else {  // EV_PATH_DONE: ImageBlock::put (imageblock.h:124-205)
+                if (P.path_out) {
+                    float *q = P.path_out + ((size_t) py_i * S.width + px_i) * 3;
+                    q[0] = L.x; q[1] = L.y; q[2] = L.z;
+                } else film_put(P, px, py, L, 1.0f);
+                st = ST_NEW;
+                ev = EV_NONE;
+            }
+        }
+    }
+    // ---- counters (StatsCounter analogue; inputs of the roofline formula)
+    const uint32_t sums[8] = {wave_sum(C.paths), wave_sum(C.steps), wave_sum(C.rif_evals), wave_sum(C.tentative),
+                              wave_sum(C.real), wave_sum(C.segments), wave_sum(C.nee), wave_sum(C.marched)};
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; i++) if (sums[i]) atomicAdd(P.counters + i, (unsigned long long) sums[i]);
+        atomicAdd(P.counters + MER_C_LOOP_ITERS, (unsigned long long) wave_iters * 64ULL);
+        atomicAdd(P.counters + MER_C_ACTIVE_LANES, (unsigned long long) sums[7]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Leaf kernels (parity entry points).  One thread per item; divergence is irrelevant here.
+__global__ void lookup_trilinear_kernel(DGrid g, const float *pts, int64_t n, float *out_val, int32_t *out_idx) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int idx[4];
+    out_val[i] = lookup_float(g, f3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), idx);
+    if (out_idx) { out_idx[4 * i] = idx[0]; out_idx[4 * i + 1] = idx[1]; out_idx[4 * i + 2] = idx[2]; out_idx[4 * i + 3] = idx[3]; }
+}
+__global__ void lookup_rgb_kernel(DGrid g, const float *pts, int64_t n, float *out) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 v = lookup_spectrum(g, f3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    out[3 * i] = v.x; out[3 * i + 1] = v.y; out[3 * i + 2] = v.z;
+}
+__global__ void rif_value_grad_kernel(DGrid g, int interp, const float *pts, int64_t n, float *val, float *grad) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v; f3 gr;
+    const f3 p(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    if (interp == MER_RIF_TRILINEAR) trilinear_value_grad(g, p, v, gr); else bspline_value_grad(g, p, v, gr);
+    val[i] = v; grad[3 * i] = gr.x; grad[3 * i + 1] = gr.y; grad[3 * i + 2] = gr.z;
+}
+
+template <int RIF, int STEPPER>
+__global__ void er_trace_kernel(const Params P, const float *p0, const float *d0, const float *dist, int64_t n,
+                                float *out_p, float *out_v, float *out_ds, float *out_opt, int32_t *out_ok) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Walk<true, RIF, STEPPER, MER_SIGMA_HOMOGENEOUS> W;
+    LaneCounters C; C.clear();
+    W.kind = K_FREE; W.trsum = 0; W.walk = 0; W.Tr = 1; W.dist = 0; W.opt = 0; W.sdens = 0; W.t = 0; W.tmin = 0; W.tmax = 0;
+    W.p = f3(p0[3 * i], p0[3 * i + 1], p0[3 * i + 2]);
+    const f3 d(d0[3 * i], d0[3 * i + 1], d0[3 * i + 2]);
+    float n0; f3 g;
+    rif_value_grad<RIF>(P.rif, W.p, n0, g);
+    W.n0 = n0; W.v = d * n0;
+    if (isfinite(dist[i])) W.set_segment(P, dist[i]);
+    else { W.seg_inf = true; W.steps_left = 100000; W.rem = 0.0f; }
+    Rng rng; rng.state = 0; rng.inc = 1;
+    int ev = EV_NONE;
+    while (ev == EV_NONE) ev = W.advance(P, rng, C);
+    out_p[3 * i] = W.p.x; out_p[3 * i + 1] = W.p.y; out_p[3 * i + 2] = W.p.z;
+    out_v[3 * i] = W.v.x; out_v[3 * i + 1] = W.v.y; out_v[3 * i + 2] = W.v.z;
+    out_ds[i] = W.dist; out_opt[i] = W.opt; out_ok[i] = (ev == EV_ARRIVED) ? 1 : 0;
+}
+
+// Medium::sampleDistance for item i with RNG stream (seed, pixel=i, sample=0); rec stride 20
+template <bool CURVED, int RIF, int STEPPER, int SIGMA>
+__global__ void sample_distance_kernel(const Params P, const float *o, const float *d, const float *maxt, int64_t n, float *rec) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Walk<CURVED, RIF, STEPPER, SIGMA> W;
+    LaneCounters C; C.clear();
+    Rng rng; rng.seed(P.seed, (uint32_t) i, 0);
+    const f3 oo(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.rem = 0; W.steps_left = 0; W.seg_inf = false; W.sdens = 0;
+    int ev = W.begin(P, rng, C, K_FREE, oo, dd, maxt[i]);
+    float sigma = 0.0f;
+    for (;;) {
+        if (ev == EV_NONE) ev = W.advance(P, rng, C);
+        else if (ev == EV_ARRIVED) ev = W.on_arrived(P, rng, C, sigma);
+        else if (ev == EV_EXITED) ev = EV_FAIL;
+        else break;
+    }
+    float *r = rec + 20 * i;
+    MRec m;
+    bool success = ev == EV_REAL;
+    if (ev == EV_GATE_FAIL) {
+        m.p = oo; m.d = dd; m.t = 0; m.sigmaS = f3(0, 0, 0); m.transmittance = f3(0, 0, 0);
+        m.pdfSuccess = 1; m.pdfFailure = 1; m.refRatioSq = 1; success = false;
+        if (SIGMA == MER_SIGMA_GRID) m.transmittance = f3(0, 0, 0);
+    } else {
+        finish_free_flight(P, C, W, success, sigma, m);
+        if (SIGMA == MER_SIGMA_HOMOGENEOUS && success && m.p.x == oo.x && m.p.y == oo.y && m.p.z == oo.z) success = false;
+    }
+    r[0] = success ? 1.0f : 0.0f; r[1] = m.t; r[2] = m.p.x; r[3] = m.p.y; r[4] = m.p.z;
+    r[5] = success ? m.sigmaS.x : 0.0f; r[6] = success ? m.sigmaS.y : 0.0f; r[7] = success ? m.sigmaS.z : 0.0f;
+    r[8] = m.transmittance.x; r[9] = m.transmittance.y; r[10] = m.transmittance.z;
+    r[11] = m.pdfSuccess; r[12] = m.pdfFailure; r[13] = m.refRatioSq; r[14] = m.d.x; r[15] = m.d.y; r[16] = m.d.z;
+    r[17] = r[18] = r[19] = 0.0f;
+}
+
+// Medium::evalTransmittance over [0,maxt] (straight) or to the boundary (curved)
+template <bool CURVED, int RIF, int STEPPER, int SIGMA>
+__global__ void eval_transmittance_kernel(const Params P, const float *o, const float *d, const float *maxt, int64_t n, float *out) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Walk<CURVED, RIF, STEPPER, SIGMA> W;
+    LaneCounters C; C.clear();
+    Rng rng; rng.seed(P.seed, (uint32_t) i, 0);
+    const f3 oo(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    const int nwalks = (SIGMA == MER_SIGMA_GRID && P.sc.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
+    W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.rem = 0; W.steps_left = 0; W.seg_inf = false; W.sdens = 0;
+    int ev = W.begin(P, rng, C, K_NEE, oo, dd, maxt[i]);
+    float sigma = 0.0f; f3 tr(1, 1, 1);
+    bool gate = false, closed = (ev == EV_TR_DONE);
+    for (;;) {
+        if (ev == EV_NONE) ev = W.advance(P, rng, C);
+        else if (ev == EV_ARRIVED) ev = W.on_arrived(P, rng, C, sigma);
+        else if (ev == EV_EXITED) ev = EV_WALK_END;
+        else if (ev == EV_GATE_FAIL) { gate = true; break; }
+        else if (ev == EV_WALK_END) {
+            W.trsum += W.Tr; W.walk++;
+            if (W.walk < nwalks) ev = W.begin(P, rng, C, K_NEE, oo, dd, maxt[i], false); else break;
+        } else break;
+    }
+    if (gate) tr = f3(0, 0, 0);
+    else if (SIGMA == MER_SIGMA_GRID) { const float v = closed ? 1.0f : W.trsum / (float) nwalks; tr = f3(v, v, v); }
+    else if (CURVED) tr = homogeneous_transmittance(P, -W.dist);
+    else tr = homogeneous_transmittance(P, 0.0f - maxt[i]);
+    out[3 * i] = tr.x; out[3 * i + 1] = tr.y; out[3 * i + 2] = tr.z;
+}
+
+__global__ void phase_sample_kernel(int kind, float g, const float *wi, const float *u2, int64_t n, float *wo, float *pdf) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 o; float p;
+    phase_sample(kind, g, f3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), u2[2 * i], u2[2 * i + 1], o, p);
+    wo[3 * i] = o.x; wo[3 * i + 1] = o.y; wo[3 * i + 2] = o.z; pdf[i] = p;
+}
+__global__ void phase_eval_kernel(int kind, float g, const float *wi, const float *wo, int64_t n, float *val) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    val[i] = phase_eval(kind, g, f3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), f3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]));
+}
+__global__ void camera_rays_kernel(const Params P, const float *pos2, int64_t n, float *o, float *d) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 oo, dd; float a, b;
+    sample_ray(P, pos2[2 * i], pos2[2 * i + 1], oo, dd, a, b);
+    o[3 * i] = oo.x; o[3 * i + 1] = oo.y; o[3 * i + 2] = oo.z; d[3 * i] = dd.x; d[3 * i + 1] = dd.y; d[3 * i + 2] = dd.z;
+}
+__global__ void rng_kernel(uint64_t seed, uint32_t pixel, uint32_t sample, int n, float *out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    Rng r; r.seed(seed, pixel, sample);
+    for (int i = 0; i < n; i++) out[i] = r.next1D();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Grid re-layout DENSE -> CELL8: the 8 corners of every cell stored contiguously (32 B, one sector):
+// a trilinear fetch becomes two 16-B loads from one cache line instead of eight 4-B loads from four.
+// The integer index contract stays (x,y,z); the cell address is a pure function of it.
+__global__ void relayout_cell8_kernel(const float *dense, float *cell8, int rx, int ry, int rz) {
+    const int64_t ncell = (int64_t) (rx - 1) * (ry - 1) * (rz - 1);
+    for (int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; c < ncell; c += (int64_t) gridDim.x * blockDim.x) {
+        const int x = (int) (c % (rx - 1)), y = (int) ((c / (rx - 1)) % (ry - 1)), z = (int) (c / ((int64_t) (rx - 1) * (ry - 1)));
+        const int64_t base = ((int64_t) z * ry + y) * rx + x, sy = rx, sz = (int64_t) rx * ry;
+        float4 a, b;
+        a.x = dense[base]; a.y = dense[base + 1]; a.z = dense[base + sy]; a.w = dense[base + sy + 1];
+        b.x = dense[base + sz]; b.y = dense[base + sz + 1]; b.z = dense[base + sz + sy]; b.w = dense[base + sz + sy + 1];
+        float4 *dst = (float4 *) (cell8 + c * 8);
+        dst[0] = a; dst[1] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K_prefilter: cubic-B-spline coefficients, Spline<3>::build1d / build3d
+// (include/mitsuba/core/basisspline.h:812-890): per line a causal + anti-causal 1-pole IIR with pole
+// z1 = sqrt(3)-2 and the full mirror-sum initialisation, applied along y, then x, then z.  One thread per line.
+__global__ void bspline_pass_kernel(const float *src, float *dst, int nlines_a, int nlines_b, int64_t stride_a, int64_t stride_b,
+                                    int64_t stride_line, int size) {
+    const int64_t id = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t) nlines_a * nlines_b) return;
+    const int64_t a = id % nlines_a, b = id / nlines_a;
+    const int64_t offset = a * stride_a + b * stride_b;
+    const float z1 = -2.0f + sqrtf(3.0f);
+    // cp[0]: the reference evaluates pow(z1, i) in double (float,int overload promotes) and sums in float
+    float cp0 = 0.0f;
+    double zp = 1.0;
+    for (int i = 0; i < size; i++) { cp0 += (float) ((double) src[offset + i * stride_line] * zp); zp *= (double) z1; }
+    for (int i = size - 2; i > 0; i--) cp0 += (float) ((double) src[offset + i * stride_line] * pow((double) z1, (double) (2 * size - 2 - i)));
+    cp0 = (float) ((double) cp0 / (1.0 - pow((double) z1, (double) (2 * size - 2))));
+    // causal pass written into dst, then the anti-causal pass in place
+    float prev = cp0;
+    dst[offset] = cp0;
+    float cp_last2 = cp0;
+    for (int i = 1; i < size; i++) {
+        const float cur = src[offset + i * stride_line] + z1 * prev;
+        cp_last2 = prev; prev = cur;
+        dst[offset + i * stride_line] = cur;
+    }
+    float cn = z1 / (z1 * z1 - 1) * (prev + z1 * cp_last2);
+    float cpi = prev;
+    dst[offset + (int64_t) (size - 1) * stride_line] = 6 * cn;
+    for (int i = size - 2; i >= 0; i--) {
+        cpi = dst[offset + i * stride_line];
+        cn = z1 * (cn - cpi);
+        dst[offset + i * stride_line] = 6 * cn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Synthetic fields of BASELINE.json's configs, generated in HBM
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x;
+}
+__global__ void synth_field_kernel(int kind, int N, float *out) {
+    const int64_t total = (int64_t) N * N * N;
+    for (int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; c < total; c += (int64_t) gridDim.x * blockDim.x) {
+        const int i = (int) (c % N), j = (int) ((c / N) % N), k = (int) (c / ((int64_t) N * N));
+        const double x = -1.0 + 2.0 * i / (N - 1), y = -1.0 + 2.0 * j / (N - 1), z = -1.0 + 2.0 * k / (N - 1);
+        float v;
+        if (kind == 0) {
+            const uint32_t lin = ((uint32_t) i + (uint32_t) N * ((uint32_t) j + (uint32_t) N * (uint32_t) k)) ^ 0x5EEDu;
+            const double h = (double) lowbias32(lin) / 4294967296.0;
+            const double pi = 3.14159265358979323846;
+            double r = 0.5 + 0.35 * (sin(3.0 * pi * x) * sin(3.0 * pi * y) * sin(3.0 * pi * z)) + 0.15 * (h - 0.5);
+            r = r < 0.0 ? 0.0 : (r > 1.0 ? 1.0 : r);
+            v = (float) r;
+        } else if (kind == 1) {
+            v = (float) (1.3 + (1.6 - 1.3) / (N - 1) * j);          // mfiles/createLinearRIFWithBox.m:6-20
+        } else {
+            const double R2 = 3.0;                                    // half diagonal of [-1,1]^3, squared
+            v = (float) (2.0 - (x * x + y * y + z * z) / R2);         // mfiles/createRadialRIFWithBox.m:15-23
+        }
+        out[c] = v;
+    }
+}
+
+}  // namespace mer

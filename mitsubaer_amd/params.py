@@ -1,0 +1,81 @@
+"""Flat scene parameters for the hot path (what the C-ABI descs carry).
+
+Vocabulary follows the reference's plugins: a `heterogeneous` /
+`homogeneous` / `heterogeneousrefractive` medium with `density` / `albedo` / `rif` volumes,
+an `hg` / `isotropic` phase function, a `perspective` sensor with an `hdrfilm`, a
+`volpath` integrator and a `constant` environment emitter.
+"""
+import numpy as np
+
+# enums shared with include/mer.h
+VOL_F32, VOL_U8 = 1, 3
+SIGMA_HOMOGENEOUS, SIGMA_GRID = 0, 1
+RIF_CONST, RIF_TRILINEAR, RIF_BSPLINE3 = 0, 1, 2
+STEP_VERLET, STEP_RK4 = 0, 1
+BOUNDARY_AABB, BOUNDARY_SPHERE = 0, 1
+PHASE_ISOTROPIC, PHASE_HG = 0, 1
+TR_WOODCOCK2, TR_RATIO = 0, 1
+STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL = 0, 1, 2
+FILTER_BOX, FILTER_GAUSSIAN = 0, 1
+ALBEDO_CONST, ALBEDO_GRID = 0, 1
+
+
+def look_at(origin, target, up):
+    """Transform::lookAt (reference src/libcore/transform.cpp:191-214), float32, left-handed.
+    Returns the row-major 3x4 camera-to-world matrix with columns (left, newUp, dir, origin)."""
+    f = np.float32
+    p = np.asarray(origin, f); t = np.asarray(target, f); u = np.asarray(up, f)
+    d = (t - p).astype(f)
+    d = (d / f(np.sqrt(f(np.dot(d, d))))).astype(f)
+    left = np.cross(u, d).astype(f)
+    left = (left / f(np.sqrt(f(np.dot(left, left))))).astype(f)
+    new_up = np.cross(d, left).astype(f)
+    m = np.zeros((3, 4), f)
+    m[:, 0] = left; m[:, 1] = new_up; m[:, 2] = d; m[:, 3] = p
+    return m
+
+
+class SceneParams:
+    """Attribute bag; defaults follow the reference plugin defaults."""
+
+    def __init__(self, **kw):
+        # sensor perspective + film hdrfilm (scenes/volumetric/BoundedScatteringVolume_directionalsource.xml:27-49)
+        self.width = 512; self.height = 512
+        self.fov_x_deg = 95.8402; self.near_clip = 1e-2; self.far_clip = 1e4
+        self.cam_to_world = look_at([-3, 0, 0], [-2, 0, 0], [0, 1, 0])
+        self.rfilter = FILTER_GAUSSIAN; self.rfilter_param = 0.5
+        # integrator volpath (src/librender/integrator.cpp:190-225)
+        self.max_depth = -1; self.rr_depth = 5; self.hide_emitters = False
+        # shape: cube [-1,1]^3 (scenes/volumetric/bounds.obj), null BSDF
+        self.boundary = BOUNDARY_AABB
+        self.bmin = [-1.0, -1.0, -1.0]; self.bmax = [1.0, 1.0, 1.0]
+        self.sph_center = [0.0, 0.0, 0.0]; self.sph_radius = 1.0
+        # medium
+        self.sigma_mode = SIGMA_GRID
+        self.sigma_a = [0.05, 0.05, 0.05]; self.sigma_s = [0.5, 3.5, 7.5]
+        self.strategy = STRATEGY_BALANCE; self.channel = -1; self.sampling_density = 0.0
+        self.medium_sampling_weight = -1.0
+        self.density = None; self.density_aabb = ([-1, -1, -1], [1, 1, 1]); self.density_scale = 4.0
+        self.albedo_mode = ALBEDO_CONST; self.albedo = [0.9, 0.9, 0.9]
+        self.albedo_grid = None; self.albedo_aabb = ([-1, -1, -1], [1, 1, 1])
+        self.rif_mode = RIF_CONST; self.rif_const = 1.0
+        self.rif = None; self.rif_aabb = ([-1, -1, -1], [1, 1, 1])
+        self.stepper = STEP_RK4; self.stepsize = 1e-3
+        self.rif_double = 0
+        self.phase = PHASE_HG; self.g = 0.8
+        self.tr_estimator = TR_RATIO
+        self.env_radiance = [1.0, 1.0, 1.0]
+        self.emission = [0.0, 0.0, 0.0]
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError("unknown scene parameter '%s'" % k)
+            setattr(self, k, v)
+
+    def copy(self, **kw):
+        q = SceneParams()
+        q.__dict__.update(self.__dict__)
+        for k, v in kw.items():
+            if not hasattr(q, k):
+                raise AttributeError("unknown scene parameter '%s'" % k)
+            setattr(q, k, v)
+        return q

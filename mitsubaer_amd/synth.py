@@ -1,0 +1,53 @@
+"""Deterministic synthetic fields of BASELINE.json's configs.
+
+No RNG-library dependence: the noise term is the lowbias32 integer hash.  Arrays are [z][y][x].
+"""
+import numpy as np
+
+
+def lowbias32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16); x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15); x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def density_field(N):
+    """rho = clamp(0.5 + 0.35 sin(3 pi x) sin(3 pi y) sin(3 pi z) + 0.15 (hash32((i+N(j+Nk)) ^ 0x5EED)/2^32 - 0.5), 0, 1)
+    at node centres x = -1 + 2 i/(N-1)."""
+    ax = (-1.0 + 2.0 * np.arange(N, dtype=np.float64) / (N - 1))
+    s = np.sin(3.0 * np.pi * ax)
+    out = np.empty((N, N, N), np.float32)
+    ii = np.arange(N, dtype=np.uint32)[None, :]
+    jj = np.arange(N, dtype=np.uint32)[:, None]
+    with np.errstate(over="ignore"):
+        for k in range(N):
+            lin = (ii + np.uint32(N) * (jj + np.uint32(N) * np.uint32(k))) ^ np.uint32(0x5EED)
+            h = lowbias32(lin).astype(np.float64) / 4294967296.0
+            v = 0.5 + 0.35 * (s[None, :] * s[:, None] * s[k]) + 0.15 * (h - 0.5)
+            out[k] = np.clip(v, 0.0, 1.0).astype(np.float32)
+    return out
+
+
+def linear_rif(N, nmin=1.3, nmax=1.6, shape=None):
+    """mfiles/createLinearRIFWithBox.m:6-20: n = nmin + (nmax-nmin)/(Ny-1)*j along y."""
+    nz, ny, nx = shape if shape else (N, N, N)
+    col = (nmin + (nmax - nmin) / (ny - 1) * np.arange(ny, dtype=np.float64)).astype(np.float32)
+    return np.ascontiguousarray(np.broadcast_to(col[None, :, None], (nz, ny, nx)))
+
+
+def radial_rif(N, aabb_min=(-1, -1, -1), aabb_max=(1, 1, 1), shape=None):
+    """mfiles/createRadialRIFWithBox.m:15-23: n = 2 - (r/R)^2, R = half diagonal of the box."""
+    nz, ny, nx = shape if shape else (N, N, N)
+    mn = np.asarray(aabb_min, np.float64); mx = np.asarray(aabb_max, np.float64)
+    c = (mx + mn) / 2
+    R = max(np.linalg.norm(mx - c), np.linalg.norm(mn - c))
+    x = mn[0] + (mx[0] - mn[0]) * np.arange(nx) / (nx - 1) - c[0]
+    y = mn[1] + (mx[1] - mn[1]) * np.arange(ny) / (ny - 1) - c[1]
+    z = mn[2] + (mx[2] - mn[2]) * np.arange(nz) / (nz - 1) - c[2]
+    out = np.empty((nz, ny, nx), np.float32)
+    xy = x[None, :] ** 2 + y[:, None] ** 2
+    for k in range(nz):
+        out[k] = (2.0 - (xy + z[k] ** 2) / (R * R)).astype(np.float32)
+    return out

@@ -1,0 +1,1280 @@
+/*
+ * mer_oracle.cpp -- CPU ORACLE: restatement of the reference's refractive volumetric
+ * path-tracing hot path (cmu-ci-lab/MitsubaER, mounted at /root/reference at authoring time).
+ *
+ * TEST INFRASTRUCTURE ONLY (see mer_oracle.h).  Never linked into or called by the product.
+ *
+ * Every function cites the reference file:line it follows.  Type conventions of the
+ * reference build (-DSINGLE_PRECISION -DSPECTRUM_SAMPLES=3): Float = float, Spectrum = 3 floats,
+ * FLOAT = float (config_custom_release) or double (-DFLOATDEBUG) for the RIF path.
+ * Compile with -ffp-contract=off: fused operations appear only where written as fmaf().
+ *
+ * Deliberate, documented departures (no reference analogue exists):
+ *   - Sampler: counter-based PCG32 stream per (pixel, sample) instead of SFMT (src/samplers are OOS);
+ *     float conversion follows src/libcore/random.cpp:630-639.
+ *   - Composed estimator "delta tracking along a curved ray" (SURVEY D3, section 9.2).
+ *   - Trilinear RIF value + analytic gradient, RK4 stepper.
+ *   - Ratio-tracking transmittance (north star) next to the reference's 2-sample Woodcock.
+ *   - Medium boundary taken as data (AABB / sphere) instead of the hard-coded sphere.
+ */
+#include "mer_oracle.h"
+#include <cmath>
+#include <cstring>
+#include <cstdio>
+#include <limits>
+#include <algorithm>
+#include <vector>
+#include <thread>
+#include <atomic>
+#include <string>
+
+namespace {
+
+typedef float Float;
+static const Float Epsilon = 1e-4f;            /* include/mitsuba/core/constants.h:25-31 */
+static const Float M_PI_F  = 3.14159265358979323846f;
+static const Float INV_FOURPI_F = 0.07957747154594766788f;
+
+thread_local std::string g_err;
+
+/* ------------------------------------------------------------------ small vector types */
+template <typename T> struct V3 {
+    T x, y, z;
+    V3() {}
+    V3(T a, T b, T c) : x(a), y(b), z(c) {}
+    template <typename U> explicit V3(const V3<U> &o) : x((T) o.x), y((T) o.y), z((T) o.z) {}
+    V3 operator+(const V3 &o) const { return V3(x + o.x, y + o.y, z + o.z); }
+    V3 operator-(const V3 &o) const { return V3(x - o.x, y - o.y, z - o.z); }
+    V3 operator*(T s) const { return V3(x * s, y * s, z * s); }
+    V3 operator/(T s) const { T recip = (T) 1 / s; return V3(x * recip, y * recip, z * recip); }   /* vector.h:548-557 */
+    V3 operator-() const { return V3(-x, -y, -z); }
+    V3 &operator+=(const V3 &o) { x += o.x; y += o.y; z += o.z; return *this; }
+    V3 &operator*=(T s) { x *= s; y *= s; z *= s; return *this; }
+};
+template <typename T> inline V3<T> operator*(T s, const V3<T> &v) { return V3<T>(s * v.x, s * v.y, s * v.z); }
+template <typename T> inline T dot(const V3<T> &a, const V3<T> &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> inline V3<T> cross(const V3<T> &a, const V3<T> &b) {
+    return V3<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <typename T> inline V3<T> normalize(const V3<T> &a) { return a / std::sqrt(dot(a, a)); }
+typedef V3<Float> Vec;
+
+struct Spec {
+    Float c[3];
+    Spec() {}
+    explicit Spec(Float v) { c[0] = c[1] = c[2] = v; }
+    Spec(Float r, Float g, Float b) { c[0] = r; c[1] = g; c[2] = b; }
+    Float &operator[](int i) { return c[i]; }
+    Float operator[](int i) const { return c[i]; }
+    Spec operator*(const Spec &o) const { return Spec(c[0] * o.c[0], c[1] * o.c[1], c[2] * o.c[2]); }
+    Spec operator*(Float s) const { return Spec(c[0] * s, c[1] * s, c[2] * s); }
+    Spec operator/(Float s) const { Float recip = 1.0f / s; return Spec(c[0] * recip, c[1] * recip, c[2] * recip); }  /* spectrum.h:415-425 */
+    Spec operator+(const Spec &o) const { return Spec(c[0] + o.c[0], c[1] + o.c[1], c[2] + o.c[2]); }
+    Spec operator-(const Spec &o) const { return Spec(c[0] - o.c[0], c[1] - o.c[1], c[2] - o.c[2]); }
+    Spec &operator*=(const Spec &o) { c[0] *= o.c[0]; c[1] *= o.c[1]; c[2] *= o.c[2]; return *this; }
+    Spec &operator*=(Float s) { c[0] *= s; c[1] *= s; c[2] *= s; return *this; }
+    Spec &operator/=(Float s) { Float recip = 1.0f / s; c[0] *= recip; c[1] *= recip; c[2] *= recip; return *this; }
+    Spec &operator+=(const Spec &o) { c[0] += o.c[0]; c[1] += o.c[1]; c[2] += o.c[2]; return *this; }
+    bool isZero() const { return c[0] == 0 && c[1] == 0 && c[2] == 0; }
+    Float max() const { return std::max(c[0], std::max(c[1], c[2])); }
+};
+
+/* ------------------------------------------------------------------ sampler (departure: PCG32) */
+struct Pcg32 {
+    uint64_t state, inc;
+    static uint64_t splitmix64(uint64_t x) {
+        x += 0x9E3779B97F4A7C15ULL;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+        return x ^ (x >> 31);
+    }
+    void seed(uint64_t seedv, uint32_t pixel, uint32_t sample) {
+        uint64_t initseq = ((uint64_t) sample << 32) | (uint64_t) pixel;
+        state = 0; inc = (initseq << 1) | 1ULL;
+        next();
+        state += splitmix64(seedv);
+        next();
+    }
+    uint32_t next() {
+        uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        uint32_t xorshifted = (uint32_t) (((old >> 18u) ^ old) >> 27u);
+        uint32_t rot = (uint32_t) (old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
+    }
+    /* src/libcore/random.cpp:630-639: 23 mantissa bits in [1,2) minus 1 */
+    Float next1D() {
+        union { uint32_t u; float f; } x;
+        x.u = (next() >> 9) | 0x3f800000u;
+        return x.f - 1.0f;
+    }
+};
+
+/* ------------------------------------------------------------------ A1/A2 grid volume */
+struct Grid {
+    int res[3], channels, dtype;
+    const void *data;
+    Float bmin[3], bmax[3];
+    Float m[3][4];          /* worldToGrid, gridvolume.cpp:188-195 */
+    Float stepSize;         /* gridvolume.cpp:196-198 */
+    Float densityMap[256];  /* gridvolume.cpp:204-214 */
+    bool valid;
+
+    Grid() : data(NULL), valid(false) {}
+    void configure(const orc_grid &g) {
+        valid = g.data != NULL;
+        for (int i = 0; i < 3; ++i) { res[i] = g.res[i]; bmin[i] = g.aabb_min[i]; bmax[i] = g.aabb_max[i]; }
+        channels = g.channels; dtype = g.dtype; data = g.data;
+        std::memset(m, 0, sizeof(m));
+        stepSize = std::numeric_limits<Float>::infinity();
+        for (int i = 0; i < 3; ++i) {
+            Float extent = bmax[i] - bmin[i];
+            Float s = (Float) (res[i] - 1) / extent;       /* Transform::scale((res-1)/extents) */
+            m[i][i] = s;
+            m[i][3] = s * (-bmin[i]);                       /* * Transform::translate(-min); toWorld = identity */
+            stepSize = std::min(stepSize, 0.5f * extent / (Float) (res[i] - 1));
+        }
+        for (int i = 0; i < 255; ++i) densityMap[i] = i / 255.0f;
+        densityMap[255] = 1.0f;
+    }
+    /* include/mitsuba/core/transform.h:147-155 transformAffine, operation order kept */
+    inline Vec toGrid(const Vec &p) const {
+        Float x = m[0][0] * p.x + m[0][1] * p.y + m[0][2] * p.z + m[0][3];
+        Float y = m[1][0] * p.x + m[1][1] * p.y + m[1][2] * p.z + m[1][3];
+        Float z = m[2][0] * p.x + m[2][1] * p.y + m[2][2] * p.z + m[2][3];
+        return Vec(x, y, z);
+    }
+    inline Float fetch(int idx) const {
+        return dtype == ORC_VOL_F32 ? ((const float *) data)[idx] : densityMap[((const uint8_t *) data)[idx]];
+    }
+    /* gridvolume.cpp:337-388 lookupFloat.  idx4 (optional) = x1,y1,z1,linear index / -1 */
+    inline Float lookupFloat(const Vec &_p, int *idx4 = NULL) const {
+        const Vec p = toGrid(_p);
+        const int x1 = (int) std::floor(p.x), y1 = (int) std::floor(p.y), z1 = (int) std::floor(p.z),
+                  x2 = x1 + 1, y2 = y1 + 1, z2 = z1 + 1;
+        if (idx4) { idx4[0] = x1; idx4[1] = y1; idx4[2] = z1; idx4[3] = -1; }
+        if (x1 < 0 || y1 < 0 || z1 < 0 || x2 >= res[0] || y2 >= res[1] || z2 >= res[2])
+            return 0;
+        const Float fx = p.x - x1, fy = p.y - y1, fz = p.z - z1,
+                    _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
+        if (idx4) idx4[3] = (z1 * res[1] + y1) * res[0] + x1;
+        const Float d000 = fetch((z1 * res[1] + y1) * res[0] + x1), d001 = fetch((z1 * res[1] + y1) * res[0] + x2),
+                    d010 = fetch((z1 * res[1] + y2) * res[0] + x1), d011 = fetch((z1 * res[1] + y2) * res[0] + x2),
+                    d100 = fetch((z2 * res[1] + y1) * res[0] + x1), d101 = fetch((z2 * res[1] + y1) * res[0] + x2),
+                    d110 = fetch((z2 * res[1] + y2) * res[0] + x1), d111 = fetch((z2 * res[1] + y2) * res[0] + x2);
+        return ((d000 * _fx + d001 * fx) * _fy + (d010 * _fx + d011 * fx) * fy) * _fz +
+               ((d100 * _fx + d101 * fx) * _fy + (d110 * _fx + d111 * fx) * fy) * fz;
+    }
+    /* gridvolume.cpp:390-421 lookupSpectrum (float32, 3 channels) */
+    inline Spec lookupSpectrum(const Vec &_p) const {
+        const Vec p = toGrid(_p);
+        const int x1 = (int) std::floor(p.x), y1 = (int) std::floor(p.y), z1 = (int) std::floor(p.z),
+                  x2 = x1 + 1, y2 = y1 + 1, z2 = z1 + 1;
+        if (x1 < 0 || y1 < 0 || z1 < 0 || x2 >= res[0] || y2 >= res[1] || z2 >= res[2])
+            return Spec(0.0f);
+        const Float fx = p.x - x1, fy = p.y - y1, fz = p.z - z1,
+                    _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
+        Spec out;
+        for (int c = 0; c < 3; ++c) {
+            auto F = [&](int z, int y, int x) -> Float {
+                int idx = ((z * res[1] + y) * res[0] + x) * 3 + c;
+                return dtype == ORC_VOL_F32 ? ((const float *) data)[idx] : densityMap[((const uint8_t *) data)[idx]];
+            };
+            out[c] = ((F(z1, y1, x1) * _fx + F(z1, y1, x2) * fx) * _fy + (F(z1, y2, x1) * _fx + F(z1, y2, x2) * fx) * fy) * _fz +
+                     ((F(z2, y1, x1) * _fx + F(z2, y1, x2) * fx) * _fy + (F(z2, y2, x1) * _fx + F(z2, y2, x2) * fx) * fy) * fz;
+        }
+        return out;
+    }
+    /* include/mitsuba/core/aabb.h:308-339 */
+    inline bool rayIntersect(const Vec &o, const Vec &d, Float &nearT, Float &farT) const {
+        return aabbIntersect(bmin, bmax, o, d, nearT, farT);
+    }
+    static inline bool aabbIntersect(const Float mn[3], const Float mx[3], const Vec &o, const Vec &d, Float &nearT, Float &farT) {
+        nearT = -std::numeric_limits<Float>::infinity();
+        farT = std::numeric_limits<Float>::infinity();
+        const Float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+        for (int i = 0; i < 3; i++) {
+            const Float origin = oo[i], minVal = mn[i], maxVal = mx[i];
+            if (dd[i] == 0) {
+                if (origin < minVal || origin > maxVal) return false;
+            } else {
+                const Float dRcp = 1.0f / dd[i];          /* ray.dRcp, include/mitsuba/core/ray.h */
+                Float t1 = (minVal - origin) * dRcp, t2 = (maxVal - origin) * dRcp;
+                if (t1 > t2) std::swap(t1, t2);
+                nearT = std::max(t1, nearT);
+                farT = std::min(t2, farT);
+                if (!(nearT <= farT)) return false;
+            }
+        }
+        return true;
+    }
+};
+
+/* trilinear value + analytic gradient of the interpolant, cell clamped to the grid (new: SURVEY D2).
+   value keeps the blend order of gridvolume.cpp:364-367. */
+template <typename FLOAT>
+inline void trilinearValueGrad(const Grid &g, const V3<FLOAT> &pw, FLOAT &val, V3<FLOAT> &grad) {
+    const FLOAT px = (FLOAT) g.m[0][0] * pw.x + (FLOAT) g.m[0][3];
+    const FLOAT py = (FLOAT) g.m[1][1] * pw.y + (FLOAT) g.m[1][3];
+    const FLOAT pz = (FLOAT) g.m[2][2] * pw.z + (FLOAT) g.m[2][3];
+    int x1 = (int) std::floor(px), y1 = (int) std::floor(py), z1 = (int) std::floor(pz);
+    x1 = std::min(std::max(x1, 0), g.res[0] - 2);
+    y1 = std::min(std::max(y1, 0), g.res[1] - 2);
+    z1 = std::min(std::max(z1, 0), g.res[2] - 2);
+    const FLOAT fx = px - x1, fy = py - y1, fz = pz - z1, _fx = 1 - fx, _fy = 1 - fy, _fz = 1 - fz;
+    const float *D = (const float *) g.data;
+    const int base = (z1 * g.res[1] + y1) * g.res[0] + x1, sy = g.res[0], sz = g.res[0] * g.res[1];
+    const FLOAT d000 = D[base], d001 = D[base + 1], d010 = D[base + sy], d011 = D[base + sy + 1],
+                d100 = D[base + sz], d101 = D[base + sz + 1], d110 = D[base + sz + sy], d111 = D[base + sz + sy + 1];
+    const FLOAT c00 = d000 * _fx + d001 * fx, c01 = d010 * _fx + d011 * fx,
+                c10 = d100 * _fx + d101 * fx, c11 = d110 * _fx + d111 * fx;
+    const FLOAT c0 = c00 * _fy + c01 * fy, c1 = c10 * _fy + c11 * fy;
+    val = c0 * _fz + c1 * fz;
+    const FLOAT gx = ((d001 - d000) * _fy + (d011 - d010) * fy) * _fz + ((d101 - d100) * _fy + (d111 - d110) * fy) * fz;
+    const FLOAT gy = (c01 - c00) * _fz + (c11 - c10) * fz;
+    const FLOAT gz = c1 - c0;
+    grad = V3<FLOAT>(gx * (FLOAT) g.m[0][0], gy * (FLOAT) g.m[1][1], gz * (FLOAT) g.m[2][2]);
+}
+
+/* ------------------------------------------------------------------ A5 cubic B-spline (basisspline.h) */
+template <typename FLOAT> struct SplineConst;
+template <> struct SplineConst<float> {   /* constants.h:93-101 non-FLOATDEBUG: *_FLT literals */
+    static float half() { return 0.5f; } static float sixth() { return 0.16666666667f; } static float twothird() { return 0.66666666667f; }
+};
+template <> struct SplineConst<double> {  /* FLOATDEBUG: 1.0/2.0, 1.0/6.0, 2.0/3.0 */
+    static double half() { return 1.0 / 2.0; } static double sixth() { return 1.0 / 6.0; } static double twothird() { return 2.0 / 3.0; }
+};
+template <typename T> inline int sgn(T val) { return (T(0) < val) - (val < T(0)); }
+
+/* basisspline.h:40-46 */
+template <typename FLOAT> inline FLOAT kernel0(FLOAT x) {
+    x = std::abs(x);
+    if (x > 2) return (FLOAT) 0.0;
+    if (x > 1) return (SplineConst<FLOAT>::sixth() * (2 - x) * (2 - x) * (2 - x));
+    return (SplineConst<FLOAT>::twothird() - x * x + SplineConst<FLOAT>::half() * x * x * x);
+}
+/* basisspline.h:65-72 (note the double literal 1.5, as in the reference) */
+template <typename FLOAT> inline FLOAT kernel1(FLOAT x) {
+    int s = sgn(x);
+    x = std::abs(x);
+    if (x > 2) return (FLOAT) 0.0;
+    if (x > 1) return s * (-SplineConst<FLOAT>::half() * (2 - x) * (2 - x));
+    return (FLOAT) (s * ((1.5 * x - 2) * x));
+}
+/* basisspline.h:91-97 */
+template <typename FLOAT> inline FLOAT kernel2(FLOAT x) {
+    x = std::abs(x);
+    if (x > 2) return (FLOAT) 0.0;
+    if (x > 1) return 2 - x;
+    return 3 * x - 2;
+}
+
+template <typename FLOAT> struct Spline3 {
+    FLOAT xmin[3], xmax[3], xres[3], dxres[3], dxres2[3];
+    std::vector<FLOAT> own;
+    const FLOAT *coeff;
+    int N[3];
+    FLOAT z1;
+    Spline3() : coeff(NULL) {}
+    /* basisspline.h:124-138 */
+    void initialize(const FLOAT mn[3], const FLOAT mx[3], const int n[3]) {
+        for (int i = 0; i < 3; i++) {
+            xmin[i] = mn[i]; xmax[i] = mx[i]; N[i] = n[i];
+            xres[i] = (N[i] - 1) / (xmax[i] - xmin[i]);
+            dxres[i] = xres[i];
+            dxres2[i] = dxres[i] * dxres[i];
+        }
+        z1 = -2 + std::sqrt((FLOAT) 3);
+    }
+    FLOAT getStride(int d) const { return (FLOAT) (1.0 / xres[d]); }   /* basisspline.h:622-624 */
+    /* basisspline.h:812-840 */
+    void build1d(const FLOAT *data, int offset, int stride, int size, FLOAT *out) const {
+        std::vector<FLOAT> cp(size), cn(size);
+        cp[0] = 0;
+        for (int i = 0; i < size; i++) cp[0] += data[offset + i * stride] * std::pow(z1, i);
+        for (int i = size - 2; i > 0; i--) cp[0] += data[offset + i * stride] * std::pow(z1, 2 * size - 2 - i);
+        cp[0] /= (1 - std::pow(z1, 2 * size - 2));
+        for (int i = 1; i < size; i++) cp[i] = data[offset + i * stride] + z1 * cp[i - 1];
+        cn[size - 1] = z1 / (z1 * z1 - 1) * (cp[size - 1] + z1 * cp[size - 2]);
+        for (int i = size - 2; i >= 0; i--) cn[i] = z1 * (cn[i + 1] - cp[i]);
+        for (int i = 0; i < size; i++) out[i] = 6 * cn[i];
+    }
+    /* basisspline.h:865-890: along y, then x, then z */
+    void build3d(const FLOAT *data, FLOAT *c) const {
+        std::vector<FLOAT> temp(std::max(std::max(N[0], N[1]), N[2]));
+        for (int k = 0; k < N[2]; k++)
+            for (int i = 0; i < N[0]; i++) {
+                build1d(data, k * N[0] * N[1] + i, N[0], N[1], temp.data());
+                for (int t = 0; t < N[1]; t++) c[i + t * N[0] + k * N[0] * N[1]] = temp[t];
+            }
+        for (int k = 0; k < N[2]; k++)
+            for (int j = 0; j < N[1]; j++) {
+                build1d(c, k * N[0] * N[1] + j * N[0], 1, N[0], temp.data());
+                for (int t = 0; t < N[0]; t++) c[t + j * N[0] + k * N[0] * N[1]] = temp[t];
+            }
+        for (int i = 0; i < N[0]; i++)
+            for (int j = 0; j < N[1]; j++) {
+                build1d(c, j * N[0] + i, N[0] * N[1], N[2], temp.data());
+                for (int t = 0; t < N[2]; t++) c[i + j * N[0] + t * N[0] * N[1]] = temp[t];
+            }
+    }
+    void buildFromFloat(const float *data) {   /* splinevolume.cpp:285-289: f32 file data -> FLOAT */
+        size_t n = (size_t) N[0] * N[1] * N[2];
+        std::vector<FLOAT> tmp(n);
+        for (size_t i = 0; i < n; i++) tmp[i] = (FLOAT) data[i];
+        own.resize(n);
+        build3d(tmp.data(), own.data());
+        coeff = own.data();
+    }
+    inline void convertToX(FLOAT x[3]) const { for (int i = 0; i < 3; i++) x[i] = (x[i] - xmin[i]) * xres[i]; } /* :655-658 */
+    /* basisspline.h:302-315 */
+    inline FLOAT value(const FLOAT x1[3]) const {
+        FLOAT x[3] = {x1[0], x1[1], x1[2]};
+        convertToX(x);
+        FLOAT v = 0;
+        for (int i1 = (int) std::ceil(x[0] - 2); i1 <= std::floor(x[0] + 2); i1++)
+            for (int i2 = (int) std::ceil(x[1] - 2); i2 <= std::floor(x[1] + 2); i2++)
+                for (int i3 = (int) std::ceil(x[2] - 2); i3 <= std::floor(x[2] + 2); i3++)
+                    v += coeff[i1 + i2 * N[0] + i3 * N[0] * N[1]] * kernel0<FLOAT>(x[0] - i1) * kernel0<FLOAT>(x[1] - i2) * kernel0<FLOAT>(x[2] - i3);
+        return v;
+    }
+    /* basisspline.h:318-364 */
+    inline V3<FLOAT> gradient(const FLOAT x1[3]) const {
+        FLOAT x[3] = {x1[0], x1[1], x1[2]};
+        convertToX(x);
+        V3<FLOAT> v(0, 0, 0);
+        for (int i1 = (int) std::ceil(x[0] - 2); i1 <= std::floor(x[0] + 2); i1++)
+            for (int i2 = (int) std::ceil(x[1] - 2); i2 <= std::floor(x[1] + 2); i2++)
+                for (int i3 = (int) std::ceil(x[2] - 2); i3 <= std::floor(x[2] + 2); i3++) {
+                    FLOAT c = coeff[i1 + i2 * N[0] + i3 * N[0] * N[1]];
+                    FLOAT k0x = kernel0<FLOAT>(x[0] - i1), k0y = kernel0<FLOAT>(x[1] - i2), k0z = kernel0<FLOAT>(x[2] - i3);
+                    v.x += c * kernel1<FLOAT>(x[0] - i1) * k0y * k0z;
+                    v.y += c * k0x * kernel1<FLOAT>(x[1] - i2) * k0z;
+                    v.z += c * k0x * k0y * kernel1<FLOAT>(x[2] - i3);
+                }
+        v.x *= dxres[0]; v.y *= dxres[1]; v.z *= dxres[2];
+        return v;
+    }
+    /* basisspline.h:438-471 */
+    inline void valueAndGradient(const FLOAT x1[3], FLOAT &f, V3<FLOAT> &v) const {
+        FLOAT x[3] = {x1[0], x1[1], x1[2]};
+        v.x = v.y = v.z = 0; f = 0;
+        convertToX(x);
+        for (int i1 = (int) std::ceil(x[0] - 2); i1 <= std::floor(x[0] + 2); i1++)
+            for (int i2 = (int) std::ceil(x[1] - 2); i2 <= std::floor(x[1] + 2); i2++)
+                for (int i3 = (int) std::ceil(x[2] - 2); i3 <= std::floor(x[2] + 2); i3++) {
+                    FLOAT c = coeff[i1 + i2 * N[0] + i3 * N[0] * N[1]];
+                    FLOAT k0x = kernel0<FLOAT>(x[0] - i1), k0y = kernel0<FLOAT>(x[1] - i2), k0z = kernel0<FLOAT>(x[2] - i3);
+                    f += c * k0x * k0y * k0z;
+                    v.x += c * kernel1<FLOAT>(x[0] - i1) * k0y * k0z;
+                    v.y += c * k0x * kernel1<FLOAT>(x[1] - i2) * k0z;
+                    v.z += c * k0x * k0y * kernel1<FLOAT>(x[2] - i3);
+                }
+        v.x *= dxres[0]; v.y *= dxres[1]; v.z *= dxres[2];
+    }
+    /* basisspline.h:539-606 valueGradientAndHessian; H row-major (Hxx,Hxy,Hzx; Hxy,Hyy,Hyz; Hzx,Hyz,Hzz) */
+    inline void valueGradientAndHessian(const FLOAT x1[3], FLOAT &f, V3<FLOAT> &v, FLOAT H[9]) const {
+        FLOAT x[3] = {x1[0], x1[1], x1[2]};
+        v.x = v.y = v.z = 0; f = 0;
+        FLOAT Hxx = 0, Hyy = 0, Hzz = 0, Hxy = 0, Hyz = 0, Hzx = 0;
+        convertToX(x);
+        for (int i1 = (int) std::ceil(x[0] - 2); i1 <= std::floor(x[0] + 2); i1++)
+            for (int i2 = (int) std::ceil(x[1] - 2); i2 <= std::floor(x[1] + 2); i2++)
+                for (int i3 = (int) std::ceil(x[2] - 2); i3 <= std::floor(x[2] + 2); i3++) {
+                    FLOAT c = coeff[i1 + i2 * N[0] + i3 * N[0] * N[1]];
+                    FLOAT k0x = kernel0<FLOAT>(x[0] - i1), k0y = kernel0<FLOAT>(x[1] - i2), k0z = kernel0<FLOAT>(x[2] - i3);
+                    FLOAT k1x = kernel1<FLOAT>(x[0] - i1), k1y = kernel1<FLOAT>(x[1] - i2), k1z = kernel1<FLOAT>(x[2] - i3);
+                    f += c * k0x * k0y * k0z;
+                    v.x += c * k1x * k0y * k0z;
+                    v.y += c * k0x * k1y * k0z;
+                    v.z += c * k0x * k0y * k1z;
+                    Hxx += c * kernel2<FLOAT>(x[0] - i1) * k0y * k0z;
+                    Hyy += c * k0x * kernel2<FLOAT>(x[1] - i2) * k0z;
+                    Hzz += c * k0x * k0y * kernel2<FLOAT>(x[2] - i3);
+                    Hxy += c * k1x * k1y * k0z;
+                    Hyz += c * k0x * k1y * k1z;
+                    Hzx += c * k1x * k0y * k1z;
+                }
+        v.x *= dxres[0]; v.y *= dxres[1]; v.z *= dxres[2];
+        Hxx *= dxres2[0]; Hyy *= dxres2[1]; Hzz *= dxres2[2];
+        Hxy *= dxres[0] * dxres[1]; Hyz *= dxres[1] * dxres[2]; Hzx *= dxres[2] * dxres[0];
+        H[0] = Hxx; H[1] = Hxy; H[2] = Hzx; H[3] = Hxy; H[4] = Hyy; H[5] = Hyz; H[6] = Hzx; H[7] = Hyz; H[8] = Hzz;
+    }
+};
+
+/* ------------------------------------------------------------------ counters */
+struct Counters {
+    uint64_t c[ORC_C_COUNT];
+    Counters() { std::memset(c, 0, sizeof(c)); }
+};
+
+/* ------------------------------------------------------------------ scene */
+struct MediumRec {   /* include/mitsuba/render/medium.h:40-98 (fields used on this path) */
+    Float t; Vec p; Vec d; Spec sigmaA, sigmaS, transmittance;
+    Float pdfSuccess, pdfFailure, refRatioSq, opticalLength;
+};
+
+template <typename FLOAT> struct Rif {
+    int mode; FLOAT cst;
+    Grid grid;
+    Spline3<FLOAT> spline;
+    FLOAT limMin[3], limMax[3];   /* splinevolume.cpp:280-281 interpolatable limits */
+    void configure(const orc_scene &s) {
+        mode = s.rif_mode; cst = (FLOAT) s.rif_const;
+        if (mode != ORC_RIF_CONST) {
+            grid.configure(s.rif);
+            if (mode == ORC_RIF_BSPLINE3) {
+                FLOAT mn[3], mx[3];
+                for (int i = 0; i < 3; i++) { mn[i] = s.rif.aabb_min[i]; mx[i] = s.rif.aabb_max[i]; }
+                spline.initialize(mn, mx, s.rif.res);
+                spline.buildFromFloat((const float *) s.rif.data);
+                for (int i = 0; i < 3; i++) {
+                    limMin[i] = mn[i] + ((FLOAT) 2.0 * spline.getStride(i) + (FLOAT) Epsilon);
+                    limMax[i] = mx[i] + ((FLOAT) -2.0 * spline.getStride(i) - (FLOAT) Epsilon);
+                }
+            }
+        }
+    }
+    /* splinevolume.cpp:319-324 */
+    inline bool insideVolumeLimits(const V3<FLOAT> &p) const {
+        if (mode != ORC_RIF_BSPLINE3) return true;
+        return p.x > limMin[0] && p.x < limMax[0] && p.y > limMin[1] && p.y < limMax[1] && p.z > limMin[2] && p.z < limMax[2];
+    }
+    inline FLOAT value(const V3<FLOAT> &p, Counters &C) const {
+        C.c[ORC_C_RIF_EVALS]++;
+        if (mode == ORC_RIF_CONST) return cst;
+        if (mode == ORC_RIF_TRILINEAR) { FLOAT v; V3<FLOAT> g; trilinearValueGrad<FLOAT>(grid, p, v, g); return v; }
+        FLOAT x[3] = {p.x, p.y, p.z};
+        return spline.value(x);              /* splinevolume.cpp:330-337 */
+    }
+    inline void valueAndGradient(const V3<FLOAT> &p, FLOAT &n, V3<FLOAT> &g, Counters &C) const {
+        C.c[ORC_C_RIF_EVALS]++;
+        if (mode == ORC_RIF_CONST) { n = cst; g = V3<FLOAT>(0, 0, 0); return; }
+        if (mode == ORC_RIF_TRILINEAR) { trilinearValueGrad<FLOAT>(grid, p, n, g); return; }
+        FLOAT x[3] = {p.x, p.y, p.z};
+        spline.valueAndGradient(x, n, g);    /* splinevolume.cpp:354-360 (rotation = identity) */
+    }
+    inline V3<FLOAT> gradient(const V3<FLOAT> &p, Counters &C) const {
+        C.c[ORC_C_RIF_EVALS]++;
+        if (mode == ORC_RIF_CONST) return V3<FLOAT>(0, 0, 0);
+        if (mode == ORC_RIF_TRILINEAR) { FLOAT v; V3<FLOAT> g; trilinearValueGrad<FLOAT>(grid, p, v, g); return g; }
+        FLOAT x[3] = {p.x, p.y, p.z};
+        return spline.gradient(x);           /* splinevolume.cpp:338-344 */
+    }
+};
+
+struct Scene {
+    orc_scene s;
+    Grid density, albedoGrid;
+    Rif<float> rifF; Rif<double> rifD;
+    /* camera */
+    Float camM[3][4], aspect, cotHalfFov, invResX, invResY;
+    /* filter table, src/libcore/rfilter.cpp:40-55 */
+    Float fvalues[33], fradius, fscale;
+    /* medium derived */
+    Spec sigmaA, sigmaS, sigmaT;
+    Float mediumSamplingWeight, samplingDensity;
+    Float maxDensity, invMaxDensity;
+    bool curved;
+
+    bool configure(const orc_scene &in) {
+        s = in;
+        if (s.sigma_mode == ORC_SIGMA_GRID) {
+            if (!s.density.data) { g_err = "No density specified!"; return false; }   /* heterogeneous.cpp:229-230 */
+            density.configure(s.density);
+            /* heterogeneous.cpp:239-242 with gridvolume.cpp:583-585 (maximum hard-coded to 1) */
+            maxDensity = s.density_scale * 1.0f;
+            invMaxDensity = 1.0f / maxDensity;
+        }
+        if (s.albedo_mode == ORC_ALBEDO_GRID) albedoGrid.configure(s.albedo_grid);
+        curved = s.rif_mode != ORC_RIF_CONST;
+        if (s.rif_double) rifD.configure(s); else rifF.configure(s);
+        if (!s.rif_double && s.rif_mode == ORC_RIF_CONST) rifF.cst = s.rif_const;
+        /* homogeneous coefficients: src/librender/medium.cpp:26-36 */
+        for (int i = 0; i < 3; i++) { sigmaA[i] = s.sigma_a[i]; sigmaS[i] = s.sigma_s[i]; sigmaT[i] = s.sigma_a[i] + s.sigma_s[i]; }
+        /* homogeneous.cpp:172-190 == heterogeneousrefractive.cpp:239-255 */
+        mediumSamplingWeight = s.medium_sampling_weight;
+        if (mediumSamplingWeight == -1) {
+            for (int i = 0; i < 3; ++i) {
+                Float albedo = sigmaS[i] / sigmaT[i];
+                if (albedo > mediumSamplingWeight && sigmaT[i] != 0) mediumSamplingWeight = albedo;
+            }
+            if (mediumSamplingWeight > 0) mediumSamplingWeight = std::max(mediumSamplingWeight, (Float) 0.5f);
+        }
+        samplingDensity = 0;
+        if (s.strategy == ORC_STRATEGY_SINGLE) {       /* heterogeneousrefractive.cpp:259-275 */
+            int channel = 0; Float smallest = std::numeric_limits<Float>::infinity();
+            for (int i = 0; i < 3; ++i) if (sigmaT[i] < smallest) { smallest = sigmaT[i]; channel = i; }
+            if (s.channel >= 0) channel = s.channel;
+            samplingDensity = sigmaT[channel];
+        } else if (s.strategy == ORC_STRATEGY_MANUAL) {
+            samplingDensity = s.sampling_density;
+        }
+        /* camera: src/sensors/perspective.cpp:130-158, analytic inverse of cameraToSample at z'=0 */
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) camM[i][j] = s.cam_to_world[i * 4 + j];
+        aspect = (Float) s.width / (Float) s.height;
+        cotHalfFov = 1.0f / std::tan((s.fov_x_deg / 2.0f) * (M_PI_F / 180.0f));  /* transform.cpp:99-123 */
+        invResX = 1.0f / s.width; invResY = 1.0f / s.height;
+        filterTable(s.rfilter, s.rfilter_param, fvalues, fradius, fscale);
+        return true;
+    }
+    static Float filterEval(int kind, Float param, Float radius, Float x) {
+        if (kind == ORC_FILTER_BOX) return std::abs(x) <= radius ? 1.0f : 0.0f;     /* src/rfilters/box.cpp */
+        Float alpha = -1.0f / (2.0f * param * param);                                /* src/rfilters/gaussian.cpp:50-55 */
+        return std::max((Float) 0.0f, std::exp(alpha * x * x) - std::exp(alpha * radius * radius));
+    }
+    static void filterTable(int kind, Float param, Float *values, Float &radius, Float &scale) {
+        const int RES = 31;                                  /* MTS_FILTER_RESOLUTION, rfilter.h:28 */
+        radius = kind == ORC_FILTER_BOX ? param + 1e-5f : 4 * param;
+        Float sum = 0.0f;
+        for (int i = 0; i < RES; ++i) { Float v = filterEval(kind, param, radius, (radius * i) / RES); values[i] = v; sum += v; }
+        values[RES] = 0.0f; values[RES + 1] = 0.0f;
+        scale = RES / radius;
+        sum *= 2 * radius / RES;
+        Float normalization = 1.0f / sum;
+        for (int i = 0; i < RES; ++i) values[i] *= normalization;
+    }
+    inline Float evalDiscretized(Float x) const {            /* rfilter.h:76-77 */
+        return fvalues[std::min((int) std::abs(x * fscale), 31)];
+    }
+    /* perspective.cpp:247-269 */
+    inline void sampleRay(Float px, Float py, Vec &o, Vec &d, Float &mint, Float &maxt) const {
+        Float sx = px * invResX, sy = py * invResY;
+        Vec nearP((1.0f - 2.0f * sx) * s.near_clip / cotHalfFov,
+                  (1.0f - 2.0f * sy) / aspect * s.near_clip / cotHalfFov, s.near_clip);
+        Vec dl = normalize(nearP);
+        Float invZ = 1.0f / dl.z;
+        mint = s.near_clip * invZ; maxt = s.far_clip * invZ;
+        o = Vec(camM[0][3], camM[1][3], camM[2][3]);
+        d = Vec(camM[0][0] * dl.x + camM[0][1] * dl.y + camM[0][2] * dl.z,
+                camM[1][0] * dl.x + camM[1][1] * dl.y + camM[1][2] * dl.z,
+                camM[2][0] * dl.x + camM[2][1] * dl.y + camM[2][2] * dl.z);
+    }
+    /* medium boundary shape: heterogeneousrefractive.cpp:707-726 generalised to data */
+    template <typename FLOAT> inline bool insideShape(const V3<FLOAT> &p) const {
+        if (s.boundary == ORC_BOUNDARY_SPHERE) {
+            V3<FLOAT> q(p.x - (FLOAT) s.sph_center[0], p.y - (FLOAT) s.sph_center[1], p.z - (FLOAT) s.sph_center[2]);
+            return dot(q, q) < (FLOAT) s.sph_radius * (FLOAT) s.sph_radius;
+        }
+        return p.x >= s.bmin[0] && p.x <= s.bmax[0] && p.y >= s.bmin[1] && p.y <= s.bmax[1] && p.z >= s.bmin[2] && p.z <= s.bmax[2];
+    }
+    /* ray / boundary-shape intersection in [mint, maxt]; returns t or -1 */
+    inline Float intersectShape(const Vec &o, const Vec &d, Float mint, Float maxt) const {
+        Float nearT, farT;
+        if (s.boundary == ORC_BOUNDARY_SPHERE) {
+            /* src/shapes/sphere.cpp rayIntersect: double-precision quadratic */
+            double ox = (double) o.x - s.sph_center[0], oy = (double) o.y - s.sph_center[1], oz = (double) o.z - s.sph_center[2];
+            double dx = d.x, dy = d.y, dz = d.z;
+            double A = dx * dx + dy * dy + dz * dz, B = 2 * (dx * ox + dy * oy + dz * oz),
+                   C = ox * ox + oy * oy + oz * oz - (double) s.sph_radius * s.sph_radius;
+            double disc = B * B - 4 * A * C;
+            if (disc < 0) return -1;
+            double root = std::sqrt(disc);
+            double q = B < 0 ? -0.5 * (B - root) : -0.5 * (B + root);
+            double t0 = q / A, t1 = C / q;
+            if (t0 > t1) std::swap(t0, t1);
+            nearT = (Float) t0; farT = (Float) t1;
+        } else {
+            if (!Grid::aabbIntersect(s.bmin, s.bmax, o, d, nearT, farT)) return -1;
+        }
+        if (!(nearT <= maxt && farT >= mint)) return -1;
+        if (nearT >= mint) return nearT;
+        if (farT <= maxt) return farT;
+        return -1;
+    }
+    inline Spec albedoAt(const Vec &p) const {
+        if (s.albedo_mode == ORC_ALBEDO_GRID) return albedoGrid.lookupSpectrum(p);
+        return Spec(s.albedo[0], s.albedo[1], s.albedo[2]);       /* constvolume.cpp:57-64 */
+    }
+    template <typename FLOAT> const Rif<FLOAT> &rif() const;
+};
+template <> const Rif<float> &Scene::rif<float>() const { return rifF; }
+template <> const Rif<double> &Scene::rif<double>() const { return rifD; }
+
+/* ------------------------------------------------------------------ A6 er_step, A7 trace */
+template <typename FLOAT> struct Tracer {
+    const Scene &S; const Rif<FLOAT> &R; Counters &C;
+    Tracer(const Scene &s, Counters &c) : S(s), R(s.rif<FLOAT>()), C(c) {}
+
+    /* heterogeneousrefractive.cpp:653-661 (velocity-Verlet), or classic RK4 on (p,v,opt) (new) */
+    inline void er_step(V3<FLOAT> &p, V3<FLOAT> &v, FLOAT h, FLOAT &opt) const {
+        C.c[ORC_C_STEPS]++;
+        if (S.s.stepper == ORC_STEP_VERLET) {
+            FLOAT n; V3<FLOAT> G;
+            R.valueAndGradient(p, n, G, C);
+            v += SplineConst<FLOAT>::half() * h * G;
+            p += h * v / n;
+            v += SplineConst<FLOAT>::half() * h * R.gradient(p, C);
+            opt += h * n;
+        } else {
+            FLOAT n1, n2, n3, n4; V3<FLOAT> g1, g2, g3, g4;
+            const FLOAT hh = (FLOAT) 0.5 * h;
+            R.valueAndGradient(p, n1, g1, C);
+            V3<FLOAT> kp1 = v / n1;
+            V3<FLOAT> v2 = v + hh * g1;
+            R.valueAndGradient(p + hh * kp1, n2, g2, C);
+            V3<FLOAT> kp2 = v2 / n2;
+            V3<FLOAT> v3 = v + hh * g2;
+            R.valueAndGradient(p + hh * kp2, n3, g3, C);
+            V3<FLOAT> kp3 = v3 / n3;
+            V3<FLOAT> v4 = v + h * g3;
+            R.valueAndGradient(p + h * kp3, n4, g4, C);
+            V3<FLOAT> kp4 = v4 / n4;
+            const FLOAT h6 = h / (FLOAT) 6;
+            p += h6 * (kp1 + (FLOAT) 2 * kp2 + (FLOAT) 2 * kp3 + kp4);
+            v += h6 * (g1 + (FLOAT) 2 * g2 + (FLOAT) 2 * g3 + g4);
+            opt += h6 * (n1 + (FLOAT) 2 * n2 + (FLOAT) 2 * n3 + n4);
+        }
+    }
+    /* heterogeneousrefractive.cpp:671-691 */
+    inline bool trace(V3<FLOAT> &p, V3<FLOAT> &v, FLOAT sampledDistance, FLOAT &distSurf, FLOAT &opt) const {
+        const FLOAT h = (FLOAT) S.s.stepsize;
+        FLOAT distance = sampledDistance;
+        distSurf = 0;
+        int steps = (int) (distance / h);
+        distance = distance - steps * h;
+        for (int i = 0; i < steps; i++) {
+            er_step(p, v, h, opt);
+            if (!S.insideShape(p)) { er_step(p, v, -h, opt); return false; }
+            distSurf += h;
+        }
+        er_step(p, v, distance, opt);
+        if (!S.insideShape(p)) { er_step(p, v, -distance, opt); return false; }
+        distSurf += distance;
+        return true;
+    }
+    /* heterogeneousrefractive.cpp:742-776 */
+    inline void traceTillBoundary(V3<FLOAT> &p, V3<FLOAT> &v, FLOAT &distSurf, FLOAT &opt) const {
+        distSurf = 0;
+        const long maxsteps = 100000;
+        const FLOAT h = (FLOAT) S.s.stepsize;
+        for (long i = 0; i < maxsteps; i++) {
+            er_step(p, v, h, opt);
+            if (S.insideShape(p)) distSurf += h;
+            else { er_step(p, v, -h, opt); distSurf -= h; return; }
+        }
+    }
+};
+
+/* ------------------------------------------------------------------ A9 phase functions */
+/* src/libcore/util.cpp:606-615 */
+inline void coordinateSystem(const Vec &a, Vec &b, Vec &c) {
+    if (std::abs(a.x) > std::abs(a.y)) {
+        Float invLen = 1.0f / std::sqrt(a.x * a.x + a.z * a.z);
+        c = Vec(a.z * invLen, 0.0f, -a.x * invLen);
+    } else {
+        Float invLen = 1.0f / std::sqrt(a.y * a.y + a.z * a.z);
+        c = Vec(0.0f, a.z * invLen, -a.y * invLen);
+    }
+    b = cross(c, a);
+}
+inline Float safe_sqrt(Float v) { return std::sqrt(std::max((Float) 0.0f, v)); }   /* math.h:260-267 */
+/* src/libcore/warp.cpp:25-31 */
+inline Vec squareToUniformSphere(Float sx, Float sy) {
+    Float z = 1.0f - 2.0f * sy;
+    Float r = safe_sqrt(1.0f - z * z);
+    Float phi = 2.0f * M_PI_F * sx;
+    return Vec(r * std::cos(phi), r * std::sin(phi), z);
+}
+/* src/phase/hg.cpp:107-110, src/phase/isotropic.cpp:76-78.  wi points away from the vertex (phase.h:40-48) */
+inline Float phaseEval(int kind, Float g, const Vec &wi, const Vec &wo) {
+    if (kind == ORC_PHASE_ISOTROPIC) return INV_FOURPI_F;
+    Float temp = 1.0f + g * g + 2.0f * g * dot(wi, wo);
+    return INV_FOURPI_F * (1 - g * g) / (temp * std::sqrt(temp));
+}
+/* src/phase/hg.cpp:74-103, src/phase/isotropic.cpp:62-74 */
+inline Float phaseSample(int kind, Float g, const Vec &wi, Float sx, Float sy, Vec &wo, Float &pdf) {
+    if (kind == ORC_PHASE_ISOTROPIC) { wo = squareToUniformSphere(sx, sy); pdf = INV_FOURPI_F; return 1.0f; }
+    Float cosTheta;
+    if (std::abs(g) < Epsilon) cosTheta = 1 - 2 * sx;
+    else {
+        Float sqrTerm = (1 - g * g) / (1 - g + 2 * g * sx);
+        cosTheta = (1 + g * g - sqrTerm * sqrTerm) / (2 * g);
+    }
+    Float sinTheta = safe_sqrt(1.0f - cosTheta * cosTheta);
+    Float phi = 2 * M_PI_F * sy, sinPhi = std::sin(phi), cosPhi = std::cos(phi);
+    Vec n = -wi, s, t;
+    coordinateSystem(n, s, t);            /* Frame(n): include/mitsuba/core/frame.h:55-57 */
+    Vec l(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
+    wo = s * l.x + t * l.y + n * l.z;     /* frame.h:83-85 toWorld */
+    pdf = phaseEval(kind, g, wi, wo);
+    return 1.0f;
+}
+
+/* ------------------------------------------------------------------ media */
+struct Walker {
+    const Scene &S; Pcg32 &rng; Counters &C;
+    Walker(const Scene &s, Pcg32 &r, Counters &c) : S(s), rng(r), C(c) {}
+
+    inline Float sigmaTAt(const Vec &p) const {     /* heterogeneous.cpp:707-717 (isotropic medium) * m_scale */
+        C.c[ORC_C_TENTATIVE]++;
+        return S.density.lookupFloat(p) * S.s.density_scale;
+    }
+
+    /* (a) heterogeneous.cpp:589-663, Woodcock branch */
+    bool sampleDistanceWoodcock(const Vec &o, const Vec &d, Float rayMaxt, MediumRec &mRec) {
+        mRec.pdfFailure = 1.0f; mRec.pdfSuccess = 1.0f; mRec.transmittance = Spec(1.0f); mRec.refRatioSq = 1.0f;
+        Float mint, maxt;
+        if (!S.density.rayIntersect(o, d, mint, maxt)) return false;
+        mint = std::max(mint, (Float) 0.0f);
+        maxt = std::min(maxt, rayMaxt);
+        Float t = mint, densityAtT = 0;
+        bool success = false;
+        while (true) {
+            t -= std::log(1 - rng.next1D()) * S.invMaxDensity;
+            if (t >= maxt) break;
+            Vec p = o + d * t;
+            densityAtT = sigmaTAt(p);
+            if (densityAtT * S.invMaxDensity > rng.next1D()) {
+                mRec.t = t; mRec.p = p;
+                Spec albedo = S.albedoAt(p);
+                mRec.sigmaS = albedo * densityAtT;
+                mRec.sigmaA = Spec(densityAtT) - mRec.sigmaS;
+                mRec.transmittance = Spec(densityAtT != 0.0f ? 1.0f / densityAtT : 0);
+                if (!std::isfinite(mRec.transmittance[0])) mRec.transmittance = Spec(0.0f);
+                success = true;
+                C.c[ORC_C_REAL]++;
+                break;
+            }
+        }
+        return success && mRec.pdfSuccess > 0;
+    }
+    /* heterogeneous.cpp:546-587 (nSamples = 2 binary estimator) + ratio tracking (departure) */
+    Spec evalTransmittanceHet(const Vec &o, const Vec &d, Float rayMaxt) {
+        Float mint, maxt;
+        if (!S.density.rayIntersect(o, d, mint, maxt)) return Spec(1.0f);
+        mint = std::max(mint, (Float) 0.0f);
+        maxt = std::min(maxt, rayMaxt);
+        if (S.s.tr_estimator == ORC_TR_RATIO) {
+            Float T = 1.0f, t = mint;
+            while (true) {
+                t -= std::log(1 - rng.next1D()) * S.invMaxDensity;
+                if (t >= maxt) break;
+                Float density = sigmaTAt(o + d * t);
+                T *= 1.0f - density * S.invMaxDensity;
+                if (T == 0.0f) break;
+            }
+            return Spec(T);
+        }
+        int nSamples = 2; Float result = 0;
+        for (int i = 0; i < nSamples; ++i) {
+            Float t = mint;
+            while (true) {
+                t -= std::log(1 - rng.next1D()) * S.invMaxDensity;
+                if (t >= maxt) { result += 1; break; }
+                Float density = sigmaTAt(o + d * t);
+                if (density * S.invMaxDensity > rng.next1D()) break;
+            }
+        }
+        return Spec(result / nSamples);
+    }
+
+    /* strategy pdfs: homogeneous.cpp:317-343 == heterogeneousrefractive.cpp:533-558 */
+    inline void strategyPdfs(Float sampledDistance, Float samplingDensity, MediumRec &mRec) const {
+        switch (S.s.strategy) {
+        case ORC_STRATEGY_BALANCE:
+            mRec.pdfFailure = 0; mRec.pdfSuccess = 0;
+            for (int i = 0; i < 3; ++i) {
+                Float tmp = std::exp(-S.sigmaT[i] * sampledDistance);
+                mRec.pdfFailure += tmp; mRec.pdfSuccess += S.sigmaT[i] * tmp;
+            }
+            mRec.pdfFailure /= 3; mRec.pdfSuccess /= 3;
+            break;
+        default:
+            mRec.pdfFailure = std::exp(-samplingDensity * sampledDistance);
+            mRec.pdfSuccess = samplingDensity * mRec.pdfFailure;
+        }
+        for (int i = 0; i < 3; ++i) mRec.transmittance[i] = std::exp(S.sigmaT[i] * (-sampledDistance));
+        mRec.pdfSuccess = mRec.pdfSuccess * S.mediumSamplingWeight;
+        mRec.pdfFailure = S.mediumSamplingWeight * mRec.pdfFailure + (1 - S.mediumSamplingWeight);
+        if (mRec.transmittance.max() < 1e-20f) mRec.transmittance = Spec(0.0f);
+    }
+    inline Float sampleExpDistance(Float &samplingDensity) {   /* homogeneous.cpp:277-296 */
+        Float rand = rng.next1D(), sampledDistance;
+        samplingDensity = S.samplingDensity;
+        if (rand < S.mediumSamplingWeight) {
+            rand /= S.mediumSamplingWeight;
+            if (S.s.strategy == ORC_STRATEGY_BALANCE) {
+                int channel = std::min((int) (rng.next1D() * 3), 2);
+                samplingDensity = S.sigmaT[channel];
+            }
+            sampledDistance = -std::log(1 - rand) / samplingDensity;
+        } else sampledDistance = std::numeric_limits<Float>::infinity();
+        return sampledDistance;
+    }
+    /* (b) homogeneous.cpp:275-352 */
+    bool sampleDistanceHomogeneous(const Vec &o, const Vec &d, Float rayMaxt, MediumRec &mRec) {
+        Float samplingDensity;
+        Float sampledDistance = sampleExpDistance(samplingDensity);
+        Float distSurf = rayMaxt - 0.0f;
+        bool success = true;
+        mRec.refRatioSq = 1.0f;
+        if (sampledDistance < distSurf) {
+            mRec.t = sampledDistance; mRec.p = o + d * mRec.t;
+            mRec.sigmaA = S.sigmaA; mRec.sigmaS = S.sigmaS;
+            if (mRec.p.x == o.x && mRec.p.y == o.y && mRec.p.z == o.z) success = false;
+            else C.c[ORC_C_REAL]++;
+        } else { sampledDistance = distSurf; success = false; }
+        strategyPdfs(sampledDistance, samplingDensity, mRec);
+        return success;
+    }
+    /* (c) heterogeneousrefractive.cpp:402-568 (homogeneous sigma along a curved ray) */
+    template <typename FLOAT> bool sampleDistanceRefractive(const Vec &o, const Vec &d, MediumRec &mRec) {
+        Float samplingDensity;
+        FLOAT sampledDistance = sampleExpDistance(samplingDensity);
+        Tracer<FLOAT> T(S, C);
+        bool success = true;
+        FLOAT distSurf = 0, opticalDistance = 0;
+        V3<FLOAT> tempP(o), tempV(d);
+        if (!T.R.insideVolumeLimits(tempP)) {               /* :461-466 */
+            mRec.transmittance = Spec(0.0f); mRec.pdfSuccess = 1.0f; mRec.pdfFailure = 1.0f; mRec.refRatioSq = 1.0f;
+            mRec.p = o; mRec.d = d;
+            return false;
+        }
+        FLOAT refStart = T.R.value(tempP, C);
+        FLOAT refRatioSq = (FLOAT) 1.0 / (refStart * refStart);
+        tempV *= refStart;
+        if (std::isfinite(sampledDistance)) success = T.trace(tempP, tempV, sampledDistance, distSurf, opticalDistance);
+        else { T.traceTillBoundary(tempP, tempV, distSurf, opticalDistance); success = false; }
+        Float refEnd = (Float) T.R.value(tempP, C);
+        refRatioSq *= refEnd * refEnd;
+        mRec.opticalLength = (Float) opticalDistance; mRec.p = Vec(tempP); mRec.d = Vec(tempV); mRec.refRatioSq = (Float) refRatioSq;
+        if (success) {
+            mRec.t = (Float) sampledDistance; mRec.sigmaA = S.sigmaA; mRec.sigmaS = S.sigmaS;
+            if (mRec.p.x == o.x && mRec.p.y == o.y && mRec.p.z == o.z) success = false;
+            else C.c[ORC_C_REAL]++;
+        } else { sampledDistance = distSurf; mRec.t = (Float) sampledDistance; }
+        strategyPdfs((Float) sampledDistance, samplingDensity, mRec);
+        return success;
+    }
+    /* (d) composed estimator, SURVEY section 9.2: delta tracking (heterogeneous.cpp:613-659) whose free
+       paths are walked with trace() (heterogeneousrefractive.cpp:671-691) */
+    template <typename FLOAT> bool sampleDistanceComposed(const Vec &o, const Vec &d, MediumRec &mRec) {
+        mRec.pdfFailure = 1.0f; mRec.pdfSuccess = 1.0f; mRec.transmittance = Spec(1.0f); mRec.refRatioSq = 1.0f;
+        Tracer<FLOAT> T(S, C);
+        V3<FLOAT> tempP(o), tempV(d);
+        mRec.p = o; mRec.d = d;
+        if (!T.R.insideVolumeLimits(tempP)) { mRec.transmittance = Spec(0.0f); return false; }
+        FLOAT refStart = T.R.value(tempP, C);
+        tempV *= refStart;
+        FLOAT total = 0, opt = 0, distSurf = 0;
+        bool success = false;
+        while (true) {
+            FLOAT s = (FLOAT) (-std::log(1 - rng.next1D()) * S.invMaxDensity);
+            bool inside = T.trace(tempP, tempV, s, distSurf, opt);
+            total += distSurf;
+            if (!inside) break;
+            Vec p(tempP);
+            Float densityAtT = sigmaTAt(p);
+            if (densityAtT * S.invMaxDensity > rng.next1D()) {
+                Spec albedo = S.albedoAt(p);
+                mRec.sigmaS = albedo * densityAtT;
+                mRec.sigmaA = Spec(densityAtT) - mRec.sigmaS;
+                mRec.transmittance = Spec(densityAtT != 0.0f ? 1.0f / densityAtT : 0);
+                if (!std::isfinite(mRec.transmittance[0])) mRec.transmittance = Spec(0.0f);
+                success = true;
+                C.c[ORC_C_REAL]++;
+                break;
+            }
+        }
+        Float refEnd = (Float) T.R.value(tempP, C);
+        mRec.refRatioSq = (Float) ((FLOAT) 1.0 / (refStart * refStart)) * refEnd * refEnd;
+        mRec.t = (Float) total; mRec.opticalLength = (Float) opt; mRec.p = Vec(tempP); mRec.d = Vec(tempV);
+        return success;
+    }
+    /* transmittance from (o,d) along the curved ray to the boundary (no reference analogue for volpath) */
+    template <typename FLOAT> Spec evalTransmittanceCurved(const Vec &o, const Vec &d) {
+        Tracer<FLOAT> T(S, C);
+        if (!T.R.insideVolumeLimits(V3<FLOAT>(o))) return Spec(0.0f);
+        if (S.s.sigma_mode == ORC_SIGMA_HOMOGENEOUS) {
+            V3<FLOAT> p(o), v(d);
+            v *= T.R.value(p, C);
+            FLOAT distSurf = 0, opt = 0;
+            T.traceTillBoundary(p, v, distSurf, opt);
+            Spec tr;                                           /* heterogeneousrefractive.cpp:393-400 */
+            for (int i = 0; i < 3; ++i) tr[i] = S.sigmaT[i] != 0 ? std::exp(S.sigmaT[i] * (Float) (-distSurf)) : 1.0f;
+            return tr;
+        }
+        const int nWalks = S.s.tr_estimator == ORC_TR_RATIO ? 1 : 2;
+        Float result = 0;
+        for (int w = 0; w < nWalks; ++w) {
+            V3<FLOAT> p(o), v(d);
+            v *= T.R.value(p, C);
+            FLOAT distSurf = 0, opt = 0;
+            Float Tr = 1.0f;
+            while (true) {
+                FLOAT s = (FLOAT) (-std::log(1 - rng.next1D()) * S.invMaxDensity);
+                if (!T.trace(p, v, s, distSurf, opt)) break;
+                Float density = sigmaTAt(Vec(p));
+                if (S.s.tr_estimator == ORC_TR_RATIO) { Tr *= 1.0f - density * S.invMaxDensity; if (Tr == 0.0f) break; }
+                else if (density * S.invMaxDensity > rng.next1D()) { Tr = 0.0f; break; }
+            }
+            result += Tr;
+        }
+        return Spec(result / nWalks);
+    }
+
+    bool sampleDistance(const Vec &o, const Vec &d, Float maxt, MediumRec &mRec) {
+        C.c[ORC_C_SEGMENTS]++;
+        if (!S.curved) {
+            mRec.d = d;
+            return S.s.sigma_mode == ORC_SIGMA_GRID ? sampleDistanceWoodcock(o, d, maxt, mRec)
+                                                    : sampleDistanceHomogeneous(o, d, maxt, mRec);
+        }
+        if (S.s.sigma_mode == ORC_SIGMA_GRID)
+            return S.s.rif_double ? sampleDistanceComposed<double>(o, d, mRec) : sampleDistanceComposed<float>(o, d, mRec);
+        return S.s.rif_double ? sampleDistanceRefractive<double>(o, d, mRec) : sampleDistanceRefractive<float>(o, d, mRec);
+    }
+    /* Medium::evalTransmittance over [0,maxt] (straight) or to the boundary (curved) */
+    Spec evalTransmittance(const Vec &o, const Vec &d, Float maxt) {
+        if (!S.curved) {
+            if (S.s.sigma_mode == ORC_SIGMA_GRID) return evalTransmittanceHet(o, d, maxt);
+            Spec tr;                                           /* homogeneous.cpp:264-273 */
+            Float negLength = 0.0f - maxt;
+            for (int i = 0; i < 3; ++i) tr[i] = S.sigmaT[i] != 0 ? std::exp(S.sigmaT[i] * negLength) : 1.0f;
+            return tr;
+        }
+        return S.s.rif_double ? evalTransmittanceCurved<double>(o, d) : evalTransmittanceCurved<float>(o, d);
+    }
+
+    static inline Float miWeight(Float pdfA, Float pdfB) { pdfA *= pdfA; pdfB *= pdfB; return pdfA / (pdfA + pdfB); } /* volpath.cpp:430-433 */
+
+    /* A10: VolumetricPathTracer::Li (src/integrators/path/volpath.cpp:84-343) restricted to the scene
+       {one index-matched (null BSDF) convex shape with an interior medium, constant environment emitter};
+       refractive deltas from src/libbidir/edge.cpp:45-60,91-93 and src/libbidir/vertex.cpp:251-255. */
+    Spec Li(Vec ro, Vec rd, Float rmint, Float rmaxt) {
+        const orc_scene &P = S.s;
+        const Spec env(P.env_radiance[0], P.env_radiance[1], P.env_radiance[2]);
+        const bool hasEnv = !env.isZero();
+        const bool hasEmission = P.emission[0] != 0 || P.emission[1] != 0 || P.emission[2] != 0;
+        Spec Li(0.0f), throughput(1.0f);
+        Float eta = 1.0f;
+        bool scattered = false, medium = false, emitted = true;   /* rRec.type & EEmittedRadiance */
+        int depth = 1;
+        MediumRec mRec;
+        Float itsT = S.intersectShape(ro, rd, rmint, rmaxt);       /* rRec.rayIntersect(ray) */
+        bool itsValid = itsT >= 0;
+        const int maxDepth = P.max_depth;
+
+        while (depth <= maxDepth || maxDepth < 0) {
+            if (medium && sampleDistance(ro, rd, itsT, mRec)) {
+                if (depth >= maxDepth && maxDepth != -1) break;
+                if (hasEmission && P.sigma_mode == ORC_SIGMA_GRID) {
+                    /* collision estimator for volumetric emission (new, config 5): eps(p)/sigma_t(p),
+                       eps = emission * density(p) * scale ; sigma_t = density(p)*scale  => ratio = emission */
+                    Li += throughput * Spec(P.emission[0], P.emission[1], P.emission[2]) * mRec.refRatioSq;
+                }
+                throughput *= mRec.sigmaS * mRec.transmittance / mRec.pdfSuccess;       /* volpath.cpp:113 */
+                if (S.curved) throughput *= mRec.refRatioSq;                              /* edge.cpp:91-93 */
+                const Vec wi = S.curved ? normalize(-mRec.d) : -rd;                       /* vertex.cpp:251-255 */
+
+                /* ---- luminaire sampling: scene.cpp:854-874 + constant.cpp:179-214 */
+                if (hasEnv) {
+                    C.c[ORC_C_NEE]++;
+                    int interactions = maxDepth - depth - 1;
+                    Float s2x = rng.next1D(), s2y = rng.next1D();
+                    Vec dd = squareToUniformSphere(s2x, s2y);
+                    Float dpdf = INV_FOURPI_F;
+                    Spec value = env / dpdf;
+                    Spec tr(0.0f);
+                    if (interactions != 0) {                 /* scene.cpp:619-678: one null crossing is needed */
+                        Float tExit = 0;
+                        if (!S.curved) {
+                            tExit = S.intersectShape(mRec.p, dd, 0.0f, std::numeric_limits<Float>::infinity());
+                            tr = tExit >= 0 ? evalTransmittance(mRec.p, dd, tExit) : Spec(1.0f);
+                        } else tr = evalTransmittance(mRec.p, dd, 0);
+                    }
+                    value *= tr;
+                    if (!value.isZero()) {
+                        Float phaseVal = phaseEval(P.phase, P.g, wi, dd);
+                        if (phaseVal != 0) {
+                            Float phasePdf = phaseVal;       /* env emitter isOnSurface: constant.cpp:47 */
+                            Float weight = miWeight(dpdf, phasePdf);
+                            Li += throughput * value * phaseVal * weight;
+                        }
+                    }
+                }
+                /* ---- phase function sampling: volpath.cpp:149-158 */
+                Float phasePdf; Vec wo;
+                Float p2x = rng.next1D(), p2y = rng.next1D();
+                Float phaseVal = phaseSample(P.phase, P.g, wi, p2x, p2y, wo, phasePdf);
+                if (phaseVal == 0) break;
+                throughput *= phaseVal;
+                ro = mRec.p; rd = wo;
+                /* rayIntersectAndLookForEmitter: volpath.cpp:370-428 */
+                if (S.curved) { itsT = 0; itsValid = true; }
+                else { itsT = S.intersectShape(ro, rd, 0.0f, std::numeric_limits<Float>::infinity()); itsValid = itsT >= 0; }
+                if (hasEnv) {
+                    Spec tr(1.0f);
+                    int maxInteractions = maxDepth - depth - 1;
+                    bool blocked = false;
+                    if (!S.curved) {
+                        if (itsValid) { tr = evalTransmittance(ro, rd, itsT); if (maxInteractions == 0) blocked = true; }
+                    } else {
+                        tr = evalTransmittance(ro, rd, 0);
+                        if (maxInteractions == 0) blocked = true;
+                    }
+                    if (!blocked && !tr.isZero()) {
+                        Spec value = tr * env;
+                        Float emitterPdf = INV_FOURPI_F;
+                        Li += throughput * value * miWeight(phasePdf, emitterPdf);
+                    }
+                }
+                emitted = false;                              /* ERadianceNoEmission */
+            } else {
+                if (medium) {
+                    throughput *= mRec.transmittance / mRec.pdfFailure;                  /* volpath.cpp:188-189 */
+                    if (S.curved) {
+                        throughput *= mRec.refRatioSq;
+                        /* edge.cpp:45-60: boundary re-hit at mRec.p along mRec.d */
+                        ro = mRec.p; rd = normalize(mRec.d); itsValid = true; itsT = 0;
+                    }
+                }
+                if (!itsValid) {
+                    if (emitted && (!P.hide_emitters || scattered)) Li += throughput * env;   /* volpath.cpp:194-201 */
+                    break;
+                }
+                if (depth >= maxDepth && maxDepth != -1) break;
+                /* null BSDF (shape.cpp:48-70): no NEE (not smooth), pass-through sample */
+                (void) rng.next1D(); (void) rng.next1D();     /* bsdf->sample(bRec, pdf, rRec.nextSample2D()) */
+                ro = ro + rd * itsT;
+                medium = !medium;
+                emitted = !scattered;                         /* volpath.cpp:293-301 */
+                if (medium) {
+                    itsT = S.curved ? 0 : S.intersectShape(ro, rd, Epsilon, std::numeric_limits<Float>::infinity());
+                    itsValid = S.curved ? true : itsT >= 0;
+                    if (!itsValid) { medium = false; }        /* grazing hit: no exit found */
+                } else { itsValid = false; itsT = -1; }
+                depth++;
+                continue;
+            }
+            if (depth++ >= P.rr_depth) {                      /* volpath.cpp:326-336 */
+                Float q = std::min(throughput.max() * eta * eta, (Float) 0.95f);
+                if (rng.next1D() >= q) break;
+                throughput /= q;
+            }
+            scattered = true;
+        }
+        return Li;
+    }
+};
+
+/* ------------------------------------------------------------------ A11 pixel loop + film */
+/* include/mitsuba/render/imageblock.h:124-205 with block = whole image (borders cropped) */
+inline bool filmPut(const Scene &S, float *film, Float px, Float py, const Spec &spec, Float alpha) {
+    Float temp[5] = {spec[0], spec[1], spec[2], alpha, 1.0f};
+    for (int i = 0; i < 5; ++i) if (!std::isfinite(temp[i])) return false;
+    const int W = S.s.width, H = S.s.height;
+    const Float posx = px - 0.5f, posy = py - 0.5f, r = S.fradius;
+    const int minx = std::max((int) std::ceil(posx - r), 0), miny = std::max((int) std::ceil(posy - r), 0),
+              maxx = std::min((int) std::floor(posx + r), W - 1), maxy = std::min((int) std::floor(posy + r), H - 1);
+    Float wx[16], wy[16];
+    for (int x = minx, idx = 0; x <= maxx; ++x) wx[idx++] = S.evalDiscretized(x - posx);
+    for (int y = miny, idx = 0; y <= maxy; ++y) wy[idx++] = S.evalDiscretized(y - posy);
+    for (int y = miny, yr = 0; y <= maxy; ++y, ++yr) {
+        const Float weightY = wy[yr];
+        float *dest = film + ((size_t) y * W + minx) * 5;
+        for (int x = minx, xr = 0; x <= maxx; ++x, ++xr) {
+            const Float weight = wx[xr] * weightY;
+            for (int k = 0; k < 5; ++k) *dest++ += weight * temp[k];
+        }
+    }
+    return true;
+}
+
+struct SceneHolder { Scene S; bool ok; SceneHolder(const orc_scene *s) { ok = S.configure(*s); } };
+
+}  // namespace
+
+template <typename FLOAT> static void bsplineBuild(const float *data, const int32_t N[3], FLOAT *coeff) {
+    Spline3<FLOAT> sp; FLOAT mn[3] = {0, 0, 0}, mx[3] = {1, 1, 1}; int n[3] = {N[0], N[1], N[2]};
+    sp.initialize(mn, mx, n);
+    size_t tot = (size_t) N[0] * N[1] * N[2];
+    std::vector<FLOAT> tmp(tot);
+    for (size_t i = 0; i < tot; i++) tmp[i] = (FLOAT) data[i];
+    sp.build3d(tmp.data(), coeff);
+}
+template <typename FLOAT> static void bsplineEval(const FLOAT *coeff, const int32_t N[3], const float xmin[3], const float xmax[3],
+                                                   const FLOAT *pts, int64_t n, FLOAT *val, FLOAT *grad, FLOAT *hess) {
+    Spline3<FLOAT> sp; FLOAT mn[3], mx[3]; int nn[3];
+    for (int i = 0; i < 3; i++) { mn[i] = xmin[i]; mx[i] = xmax[i]; nn[i] = N[i]; }
+    sp.initialize(mn, mx, nn); sp.coeff = coeff;
+    for (int64_t i = 0; i < n; i++) {
+        FLOAT x[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, f; V3<FLOAT> g;
+        if (hess) sp.valueGradientAndHessian(x, f, g, hess + 9 * i); else sp.valueAndGradient(x, f, g);
+        val[i] = f; grad[3 * i] = g.x; grad[3 * i + 1] = g.y; grad[3 * i + 2] = g.z;
+    }
+}
+/* =========================================================================== C exports */
+extern "C" {
+
+const char *orc_last_error(void) { return g_err.c_str(); }
+
+void orc_lookup_trilinear(const orc_grid *g, const float *pts, int64_t n, float *out_val, int32_t *out_idx) {
+    Grid G; G.configure(*g);
+    for (int64_t i = 0; i < n; i++) {
+        int idx[4];
+        out_val[i] = G.lookupFloat(Vec(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), idx);
+        if (out_idx) for (int k = 0; k < 4; k++) out_idx[4 * i + k] = idx[k];
+    }
+}
+void orc_lookup_trilinear_rgb(const orc_grid *g, const float *pts, int64_t n, float *out_rgb) {
+    Grid G; G.configure(*g);
+    for (int64_t i = 0; i < n; i++) {
+        Spec s = G.lookupSpectrum(Vec(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+        for (int k = 0; k < 3; k++) out_rgb[3 * i + k] = s[k];
+    }
+}
+void orc_trilinear_value_grad(const orc_grid *g, const float *pts, int64_t n, float *out_val, float *out_grad) {
+    Grid G; G.configure(*g);
+    for (int64_t i = 0; i < n; i++) {
+        float v; V3<float> gr;
+        trilinearValueGrad<float>(G, V3<float>(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), v, gr);
+        out_val[i] = v; out_grad[3 * i] = gr.x; out_grad[3 * i + 1] = gr.y; out_grad[3 * i + 2] = gr.z;
+    }
+}
+void orc_bspline_build_f32(const float *data, const int32_t N[3], float *coeff) { bsplineBuild<float>(data, N, coeff); }
+void orc_bspline_build_f64(const float *data, const int32_t N[3], double *coeff) { bsplineBuild<double>(data, N, coeff); }
+void orc_bspline_eval_f32(const float *coeff, const int32_t N[3], const float xmin[3], const float xmax[3],
+                          const float *pts, int64_t n, float *val, float *grad, float *hess) {
+    bsplineEval<float>(coeff, N, xmin, xmax, pts, n, val, grad, hess);
+}
+void orc_bspline_eval_f64(const double *coeff, const int32_t N[3], const float xmin[3], const float xmax[3],
+                          const double *pts, int64_t n, double *val, double *grad, double *hess) {
+    bsplineEval<double>(coeff, N, xmin, xmax, pts, n, val, grad, hess);
+}
+
+void orc_er_trace(const orc_scene *s, const float *p0, const float *d0, const float *dist, int64_t n,
+                  float *out_p, float *out_v, float *out_dist_surf, float *out_opt, int32_t *out_success) {
+    SceneHolder H(s); Counters C;
+    for (int64_t i = 0; i < n; i++) {
+        Vec o(p0[3 * i], p0[3 * i + 1], p0[3 * i + 2]), d(d0[3 * i], d0[3 * i + 1], d0[3 * i + 2]);
+        bool ok; Vec P, V; Float ds, op;
+        if (s->rif_double) {
+            Tracer<double> T(H.S, C); V3<double> p(o), v(d); v *= T.R.value(p, C); double a = 0, b = 0;
+            if (std::isfinite(dist[i])) ok = T.trace(p, v, dist[i], a, b); else { T.traceTillBoundary(p, v, a, b); ok = false; }
+            P = Vec(p); V = Vec(v); ds = (Float) a; op = (Float) b;
+        } else {
+            Tracer<float> T(H.S, C); V3<float> p(o), v(d); v *= T.R.value(p, C); float a = 0, b = 0;
+            if (std::isfinite(dist[i])) ok = T.trace(p, v, dist[i], a, b); else { T.traceTillBoundary(p, v, a, b); ok = false; }
+            P = p; V = v; ds = a; op = b;
+        }
+        out_p[3 * i] = P.x; out_p[3 * i + 1] = P.y; out_p[3 * i + 2] = P.z;
+        out_v[3 * i] = V.x; out_v[3 * i + 1] = V.y; out_v[3 * i + 2] = V.z;
+        out_dist_surf[i] = ds; out_opt[i] = op; out_success[i] = ok ? 1 : 0;
+    }
+}
+
+void orc_sample_distance(const orc_scene *s, const float *o, const float *d, const float *maxt, int64_t n,
+                         uint64_t seed, float *rec) {
+    SceneHolder H(s); Counters C;
+    for (int64_t i = 0; i < n; i++) {
+        Pcg32 rng; rng.seed(seed, (uint32_t) i, 0);
+        Walker W(H.S, rng, C);
+        MediumRec m; std::memset(&m, 0, sizeof(m));
+        bool ok = W.sampleDistance(Vec(o[3 * i], o[3 * i + 1], o[3 * i + 2]), Vec(d[3 * i], d[3 * i + 1], d[3 * i + 2]), maxt[i], m);
+        float *r = rec + 20 * i;
+        r[0] = ok ? 1.0f : 0.0f; r[1] = m.t; r[2] = m.p.x; r[3] = m.p.y; r[4] = m.p.z;
+        for (int k = 0; k < 3; k++) { r[5 + k] = ok ? m.sigmaS[k] : 0.0f; r[8 + k] = m.transmittance[k]; }
+        r[11] = m.pdfSuccess; r[12] = m.pdfFailure; r[13] = m.refRatioSq; r[14] = m.d.x; r[15] = m.d.y; r[16] = m.d.z;
+        r[17] = r[18] = r[19] = 0;
+    }
+}
+
+void orc_eval_transmittance(const orc_scene *s, const float *o, const float *d, const float *maxt, int64_t n,
+                            uint64_t seed, float *out_tr) {
+    SceneHolder H(s); Counters C;
+    for (int64_t i = 0; i < n; i++) {
+        Pcg32 rng; rng.seed(seed, (uint32_t) i, 0);
+        Walker W(H.S, rng, C);
+        Spec t = W.evalTransmittance(Vec(o[3 * i], o[3 * i + 1], o[3 * i + 2]), Vec(d[3 * i], d[3 * i + 1], d[3 * i + 2]), maxt[i]);
+        for (int k = 0; k < 3; k++) out_tr[3 * i + k] = t[k];
+    }
+}
+
+void orc_phase_sample(int32_t phase, float g, const float *wi, const float *u2, int64_t n, float *wo, float *pdf) {
+    for (int64_t i = 0; i < n; i++) {
+        Vec o; Float p;
+        phaseSample(phase, g, Vec(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), u2[2 * i], u2[2 * i + 1], o, p);
+        wo[3 * i] = o.x; wo[3 * i + 1] = o.y; wo[3 * i + 2] = o.z; pdf[i] = p;
+    }
+}
+void orc_phase_eval(int32_t phase, float g, const float *wi, const float *wo, int64_t n, float *val) {
+    for (int64_t i = 0; i < n; i++)
+        val[i] = phaseEval(phase, g, Vec(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]), Vec(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]));
+}
+void orc_camera_rays(const orc_scene *s, const float *pos2, int64_t n, float *o, float *d) {
+    SceneHolder H(s);
+    for (int64_t i = 0; i < n; i++) {
+        Vec oo, dd; Float a, b;
+        H.S.sampleRay(pos2[2 * i], pos2[2 * i + 1], oo, dd, a, b);
+        o[3 * i] = oo.x; o[3 * i + 1] = oo.y; o[3 * i + 2] = oo.z; d[3 * i] = dd.x; d[3 * i + 1] = dd.y; d[3 * i + 2] = dd.z;
+    }
+}
+void orc_filter_table(int32_t rfilter, float param, float *values33, float *radius, float *scale) {
+    Scene::filterTable(rfilter, param, values33, *radius, *scale);
+}
+void orc_rng_floats(uint64_t seed, uint32_t pixel, uint32_t sample, int32_t n, float *out) {
+    Pcg32 r; r.seed(seed, pixel, sample);
+    for (int i = 0; i < n; i++) out[i] = r.next1D();
+}
+
+static void renderRows(const Scene &S, int spp_begin, int spp_count, uint64_t seed, std::atomic<int> &nextRow, int y0, int y1,
+                       float *film, Counters &C, float *pathOut) {
+    const int W = S.s.width;
+    while (true) {
+        int y = nextRow.fetch_add(1);
+        if (y >= y1) break;
+        if (y < y0) continue;
+        for (int x = 0; x < W; x++) {
+            for (int sidx = spp_begin; sidx < spp_begin + spp_count; sidx++) {
+                /* integrator.cpp:162-187 */
+                Pcg32 rng; rng.seed(seed, (uint32_t) (y * W + x), (uint32_t) sidx);
+                Walker Wk(S, rng, C);
+                Float sx = rng.next1D(), sy = rng.next1D();
+                Float px = (Float) x + sx, py = (Float) y + sy;
+                Vec o, d; Float mint, maxt;
+                S.sampleRay(px, py, o, d, mint, maxt);
+                Spec L = Wk.Li(o, d, mint, maxt);
+                C.c[ORC_C_PATHS]++;
+                if (pathOut) { float *q = pathOut + ((size_t) y * W + x) * 3; q[0] = L[0]; q[1] = L[1]; q[2] = L[2]; }
+                else filmPut(S, film, px, py, L, 1.0f);
+            }
+        }
+    }
+}
+
+static int renderImpl(const orc_scene *s, int spp_begin, int spp_count, uint64_t seed, int y0, int y1, int nthreads,
+                      float *film, uint64_t *counters, float *pathOut) {
+    SceneHolder H(s);
+    if (!H.ok) return 1;
+    const int W = s->width, Hh = s->height;
+    if (y1 > Hh) y1 = Hh;
+    if (nthreads < 1) nthreads = 1;
+    std::atomic<int> nextRow(y0);
+    std::vector<Counters> Cs(nthreads);
+    std::vector<std::vector<float>> films(nthreads);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; t++) {
+        if (!pathOut) films[t].assign((size_t) W * Hh * 5, 0.0f);
+        th.emplace_back([&, t]() { renderRows(H.S, spp_begin, spp_count, seed, nextRow, y0, y1, pathOut ? NULL : films[t].data(), Cs[t], pathOut); });
+    }
+    for (auto &t : th) t.join();
+    if (!pathOut)
+        for (int t = 0; t < nthreads; t++)
+            for (size_t i = 0; i < (size_t) W * Hh * 5; i++) film[i] += films[t][i];
+    if (counters) {
+        for (int k = 0; k < ORC_C_COUNT; k++) { counters[k] = 0; for (int t = 0; t < nthreads; t++) counters[k] += Cs[t].c[k]; }
+    }
+    return 0;
+}
+
+int orc_render(const orc_scene *s, int32_t spp_begin, int32_t spp_count, uint64_t seed, int32_t y0, int32_t y1,
+               int32_t nthreads, float *film, uint64_t *counters) {
+    return renderImpl(s, spp_begin, spp_count, seed, y0, y1, nthreads, film, counters, NULL);
+}
+int orc_render_paths(const orc_scene *s, int32_t sample_index, uint64_t seed, int32_t nthreads, float *out_rgb) {
+    return renderImpl(s, sample_index, 1, seed, 0, s->height, nthreads, NULL, NULL, out_rgb);
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+"""GPU parity of the leaf entry points (through the C-ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+from mitsubaer_amd import params as P, synth, capi
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rng_stream_bit_exact(ctx, orc):
+    for seed, pix, smp in [(0, 0, 0), (7, 12345, 3), (2 ** 40 + 5, 2 ** 20 - 1, 1023)]:
+        a = ctx.rng_floats(seed, pix, smp, 64)
+        b = orc.rng_floats(seed, pix, smp, 64)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert a.min() >= 0.0 and a.max() < 1.0
+
+
+@pytest.mark.parametrize("layout", [capi.LAYOUT_DENSE, capi.LAYOUT_CELL8])
+@pytest.mark.parametrize("shape", [(24, 24, 24), (23, 30, 20)])
+def test_trilinear_lookup_indices_and_values_bit_exact(ctx, orc, layout, shape):
+    rng = np.random.RandomState(0)
+    data = rng.rand(*shape).astype(np.float32)
+    mn, mx = [-1, -2, 0.5], [1, 2.5, 3]
+    pts = np.stack([rng.uniform(mn[i] - 0.2, mx[i] + 0.2, 200000) for i in range(3)], 1).astype(np.float32)
+    # exact nodes / faces too
+    pts[:8] = [[-1, -2, 0.5], [1, 2.5, 3], [0, 0, 1], [1, 0, 1], [-1, 0, 1], [0, 2.5, 1], [0, -2, 3], [0, 0, 0.5]]
+    vol = ctx.upload_volume(data, mn, mx, layout)
+    v, idx = ctx.lookup_trilinear(vol, pts)
+    vo, idxo = orc.lookup_trilinear(data, mn, mx, pts)
+    assert np.array_equal(idx, idxo)                      # integer grid-index arithmetic: bit-exact
+    assert np.array_equal(v.view(np.uint32), vo.view(np.uint32))   # same blend order, no contraction
+    vol.destroy()
+
+
+def test_trilinear_lookup_u8_and_rgb(ctx, orc):
+    rng = np.random.RandomState(1)
+    d8 = rng.randint(0, 256, size=(17, 19, 21)).astype(np.uint8)
+    pts = scenes.rand_points(50000, -1.1, 1.1)
+    vol = ctx.upload_volume(d8, [-1] * 3, [1] * 3)
+    v, idx = ctx.lookup_trilinear(vol, pts)
+    vo, idxo = orc.lookup_trilinear(d8, [-1] * 3, [1] * 3, pts)
+    assert np.array_equal(idx, idxo) and np.array_equal(v.view(np.uint32), vo.view(np.uint32))
+    rgb = rng.rand(12, 13, 14, 3).astype(np.float32)
+    vol3 = ctx.upload_volume(rgb, [-1] * 3, [1] * 3)
+    a = ctx.lookup_trilinear_rgb(vol3, pts)
+    b = orc.lookup_trilinear_rgb(rgb, [-1] * 3, [1] * 3, pts)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    with pytest.raises(capi.MerError):
+        ctx.lookup_trilinear(vol3, pts)      # lookupFloat on a 3-channel volume (gridvolume.cpp:570)
+
+
+@pytest.mark.parametrize("layout", [capi.LAYOUT_DENSE, capi.LAYOUT_CELL8])
+def test_trilinear_value_grad_bit_exact(ctx, orc, layout):
+    data = synth.radial_rif(20)
+    pts = scenes.rand_points(100000, -1.02, 1.02)
+    vol = ctx.upload_volume(data, [-1] * 3, [1] * 3, layout)
+    v, g = ctx.rif_value_grad(vol, P.RIF_TRILINEAR, pts)
+    vo, go = orc.trilinear_value_grad(data, [-1] * 3, [1] * 3, pts)
+    assert np.array_equal(v.view(np.uint32), vo.view(np.uint32))
+    assert np.array_equal(g.view(np.uint32), go.view(np.uint32))
+
+
+def test_bspline_prefilter_and_eval(ctx, orc):
+    rng = np.random.RandomState(3)
+    shape = (17, 20, 33)
+    data = (1.3 + 0.3 * rng.rand(*shape)).astype(np.float32)
+    mn, mx = [-1, -2, 0], [1, 2, 3]
+    vol = ctx.upload_volume(data, mn, mx).build_spline()
+    coeff = vol.download_spline()
+    co = orc.bspline_build(data)
+    # tolerance: fp32 recursion, reference build flags are not bit-reproducible
+    assert np.abs(coeff - co).max() < 5e-6
+    stride = np.array([(mx[i] - mn[i]) / (shape[2 - i] - 1) for i in range(3)])
+    lo = np.array(mn) + 2.01 * stride; hi = np.array(mx) - 2.01 * stride
+    pts = np.stack([rng.uniform(lo[i], hi[i], 50000) for i in range(3)], 1).astype(np.float32)
+    v, g = ctx.rif_value_grad(vol, P.RIF_BSPLINE3, pts)
+    vo, go = orc.bspline_eval(co, mn, mx, pts)
+    assert np.abs(v - vo).max() < 2e-5
+    assert np.abs(g - go).max() < 4e-4        # gradient of O(1) random data times dxres ~ 16
+    c64 = orc.bspline_build(data, double=True)
+    v64, g64 = orc.bspline_eval(c64, mn, mx, pts.astype(np.float64))
+    assert np.abs(v - v64).max() < 2e-5
+
+
+@pytest.mark.parametrize("g", [0.9, -0.3, 0.8, 0.0])
+def test_hg_sample_eval(ctx, orc, g):
+    kind = P.PHASE_HG
+    wi = scenes.rand_dirs(100000)
+    u2 = np.random.RandomState(5).rand(100000, 2).astype(np.float32)
+    wo, pdf = ctx.phase_sample(kind, g, wi, u2)
+    woo, pdfo = orc.phase_sample(kind, g, wi, u2)
+    assert np.abs(wo - woo).max() < 2e-5 and np.abs(pdf - pdfo).max() < 2e-4 * max(1.0, pdfo.max())
+    ev = ctx.phase_eval(kind, g, wi, wo)
+    assert np.allclose(ev, pdf, rtol=1e-5, atol=1e-7)
+    # mean cosine = g (HGPhaseFunction::getMeanCosine); wi points away, so the scattered direction is -wi-relative
+    cos = -(wi * wo).sum(1)
+    assert abs(cos.mean() - g) < 5e-3
+    wo_i, pdf_i = ctx.phase_sample(P.PHASE_ISOTROPIC, 0.0, wi, u2)
+    assert np.allclose(pdf_i, 1 / (4 * np.pi))
+    with pytest.raises(capi.MerError):
+        ctx.phase_sample(kind, 1.0, wi[:4], u2[:4])       # hg.cpp:52-53
+
+
+def test_camera_rays(ctx, orc):
+    p = scenes.straight_scene()
+    sc, vols = ctx.upload_scene(p)
+    pos = np.random.RandomState(4).uniform(0, 48, size=(4096, 2)).astype(np.float32)
+    o, d = ctx.camera_rays(sc, pos)
+    oo, do = orc.camera_rays(p, pos)
+    assert np.array_equal(o, oo)
+    assert np.abs(d - do).max() < 1e-6
+    # pixel centre of the image maps to the optical axis (+x)
+    o, d = ctx.camera_rays(sc, np.array([[24.0, 20.0]], np.float32))
+    assert np.allclose(d[0], [1, 0, 0], atol=1e-6)
+
+
+@pytest.mark.parametrize("stepper", [P.STEP_VERLET, P.STEP_RK4])
+@pytest.mark.parametrize("rifkind", ["trilinear", "bspline"])
+def test_er_trace(ctx, orc, stepper, rifkind):
+    p = scenes.curved_scene(N=24, stepper=stepper) if rifkind == "trilinear" else scenes.bspline_scene(N=24, stepper=stepper)
+    sc, vols = ctx.upload_scene(p)
+    n = 4096
+    p0 = scenes.rand_points(n, -0.9, 0.9)
+    d0 = scenes.rand_dirs(n)
+    dist = np.random.RandomState(9).uniform(0.0, 1.5, n).astype(np.float32)
+    dist[::7] = np.inf                                   # traceTillBoundary
+    op, ov, ds, oo, ok = ctx.er_trace(sc, p0, d0, dist)
+    rp, rv, rds, roo, rok = orc.er_trace(p, p0, d0, dist)
+    same = ok == rok
+    assert same.mean() > 0.999
+    tol = 1e-6 if rifkind == "trilinear" else 2e-4
+    assert np.abs(op - rp)[same].max() < max(tol, 2e-5)
+    assert np.abs(ov - rv)[same].max() < max(tol * 10, 2e-4)
+    assert np.abs(ds - rds)[same].max() < 1e-4
+    assert np.abs(oo - roo)[same].max() < 1e-3
+    # eikonal invariant: |v| = n(p) along the ray
+    nv, _ = ctx.rif_value_grad(vols[-1], P.RIF_TRILINEAR if rifkind == "trilinear" else P.RIF_BSPLINE3, op)
+    assert np.abs(np.linalg.norm(ov, axis=1) - nv).max() < 5e-3
+
+
+@pytest.mark.parametrize("mode", ["woodcock", "homogeneous", "refractive_homog", "composed_rk4", "composed_verlet"])
+def test_sample_distance(ctx, orc, mode):
+    if mode == "woodcock":
+        p = scenes.straight_scene(N=24)
+    elif mode == "homogeneous":
+        p = scenes.homogeneous_scene()
+    elif mode == "refractive_homog":
+        p = scenes.curved_scene(N=24, sigma_mode=P.SIGMA_HOMOGENEOUS, stepper=P.STEP_VERLET)
+    elif mode == "composed_rk4":
+        p = scenes.curved_scene(N=24, stepper=P.STEP_RK4)
+    else:
+        p = scenes.curved_scene(N=24, stepper=P.STEP_VERLET)
+    sc, vols = ctx.upload_scene(p)
+    n = 8192
+    o = scenes.rand_points(n, -0.95, 0.95)
+    d = scenes.rand_dirs(n)
+    maxt = np.random.RandomState(3).uniform(0.2, 2.0, n).astype(np.float32)
+    a = ctx.sample_distance(sc, o, d, maxt, 11)
+    b = orc.sample_distance(p, o, d, maxt, 11)
+    same = a[:, 0] == b[:, 0]
+    assert same.mean() > 0.995          # same RNG stream => same accept/reject decisions (up to libm ulps)
+    assert np.abs(a - b)[same].max() < 2e-3
+    assert np.median(np.abs(a - b)[same].max(1)) < 1e-5
+
+
+@pytest.mark.parametrize("est", [P.TR_WOODCOCK2, P.TR_RATIO])
+@pytest.mark.parametrize("curved", [False, True])
+def test_eval_transmittance(ctx, orc, est, curved):
+    p = scenes.curved_scene(N=24, tr_estimator=est) if curved else scenes.straight_scene(N=24, tr_estimator=est)
+    sc, vols = ctx.upload_scene(p)
+    n = 8192
+    o = scenes.rand_points(n, -0.9, 0.9)
+    d = scenes.rand_dirs(n)
+    maxt = np.random.RandomState(3).uniform(0.2, 1.5, n).astype(np.float32)
+    a = ctx.eval_transmittance(sc, o, d, maxt, 5)
+    b = orc.eval_transmittance(p, o, d, maxt, 5)
+    close = np.abs(a - b).max(1) < 1e-4
+    assert close.mean() > 0.995
+    # both estimators are unbiased for exp(-integral sigma_t): compare means (MC tolerance)
+    assert abs(a.mean() - b.mean()) < 5e-3
