@@ -3,6 +3,7 @@
 // every entry point that computes launches a kernel, and fails loudly when no device is present.
 #include "mer_kernels.hpp"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <string>
@@ -411,6 +412,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     P.ntiles_mine = (ntiles - shard->tile_rank + shard->tile_count - 1) / shard->tile_count;
     P.total_work = (uint64_t) P.ntiles_mine * MER_TILE * MER_TILE * (uint64_t) shard->spp_count;
     P.film = film_dev; P.path_out = path_out_dev;
+    { const char *e = getenv("MER_DEBUG_PIXEL"); P.dbg_pixel = e ? atoi(e) : -1; }
     HIP_CHECK(ctx, hipSetDevice(ctx->device));
     HIP_CHECK(ctx, hipMemsetAsync(P.work_counter, 0, sizeof(unsigned long long), ctx->stream));
     if (P.total_work == 0) return 0;

@@ -333,6 +333,7 @@ struct Params {
     float *path_out;                    // per-path radiance (mer_render_paths) or NULL
     unsigned long long *counters;       // MER_C_COUNT
     unsigned long long *work_counter;
+    int32_t dbg_pixel;
 };
 
 __device__ __forceinline__ bool inside_shape(const mer_scene_desc &s, f3 p) {   // heterogeneousrefractive.cpp:707-726 as data (D5)

@@ -48,15 +48,21 @@ __global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
     Rng rng; rng.state = 0; rng.inc = 1;
     LaneCounters C; C.clear();
     WalkT W;
-    W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = false; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1;
+    W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = 0; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1;
     W.dist = 0; W.opt = 0; W.sdens = 0; W.Tr = 1; W.trsum = 0; W.walk = 0; W.p = f3(0, 0, 0); W.v = f3(0, 0, 1);
     int st = ST_NEW;
     int px_i = 0, py_i = 0; float px = 0, py = 0;
     f3 L(0, 0, 0), T(1, 1, 1);
-    int depth = 1; bool scattered = false, emitted = true;
+    // path flags live in one VGPR word (lane-mask booleans spilled through SGPRs proved fragile here)
+    enum { F_SCATTERED = 1, F_EMITTED = 2, F_ITSVALID = 4 };
+    int depth = 1, flags = F_EMITTED;
+#define scattered ((flags & F_SCATTERED) != 0)
+#define emitted ((flags & F_EMITTED) != 0)
+#define itsValid ((flags & F_ITSVALID) != 0)
+#define SET_FLAG(f, v) flags = (v) ? (flags | (f)) : (flags & ~(f))
     f3 ps(0, 0, 0), dsave(0, 0, 1), dd(0, 0, 1), wi(0, 0, 1);
     f3 trv(1, 1, 1);                   // transmittance of the walk that just finished
-    float phasePdf = 0, itsT = 0; bool itsValid = false;
+    float phasePdf = 0, itsT = 0;
     uint32_t wave_iters = 0;
 
     for (;;) {
@@ -75,7 +81,7 @@ __global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
                     px = (float) px_i + sx; py = (float) py_i + sy;
                     f3 o, d; float mint, maxt;
                     sample_ray(P, px, py, o, d, mint, maxt);
-                    L = f3(0, 0, 0); T = f3(1, 1, 1); depth = 1; scattered = false; emitted = true;
+                    L = f3(0, 0, 0); T = f3(1, 1, 1); depth = 1; flags = F_EMITTED;
                     C.paths++;
                     itsT = intersect_shape(S, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
                     if (itsT < 0) {
@@ -86,8 +92,8 @@ __global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
                         (void) rng.next1D(); (void) rng.next1D();                      // null bsdf->sample(..., nextSample2D())
                         const f3 ro = o + d * itsT;
                         bool medium = true;
-                        if (CURVED) { itsT = 0; itsValid = true; }
-                        else { itsT = intersect_shape(S, ro, d, MER_EPSILON, MER_INF); itsValid = itsT >= 0; if (!itsValid) medium = false; }
+                        if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
+                        else { itsT = intersect_shape(S, ro, d, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); if (!itsValid) medium = false; }
                         depth++;
                         if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
                         else if (!medium) { if (!S.hide_emitters) L = L + T * env; ev = EV_PATH_DONE; }
@@ -103,6 +109,10 @@ __global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
 
         // ------------------------------------------------------------------ events
         while (ev != EV_NONE) {
+#ifdef MER_DEBUG
+            if (P.dbg_pixel == py_i * S.width + px_i && ev != EV_ARRIVED)
+                printf("gpu ev=%d kind=%d depth=%d T=%g L=%g Tr=%g trsum=%g walk=%d trv=%g t=%g tmax=%g rng=%llu\n", ev, W.kind, depth, T.x, L.x, W.Tr, W.trsum, W.walk, trv.x, W.t, W.tmax, (unsigned long long) rng.state);
+#endif
             if (ev == EV_ARRIVED) {
                 ev = W.on_arrived(P, rng, C, sigma);
             } else if (ev == EV_EXITED) {
@@ -183,8 +193,8 @@ __global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
                 f3 wo;
                 phase_sample(S.phase, S.g, wi, p2x, p2y, wo, phasePdf);
                 dsave = wo;
-                if (CURVED) { itsT = 0; itsValid = true; }
-                else { itsT = intersect_shape(S, ps, wo, 0.0f, MER_INF); itsValid = itsT >= 0; }
+                if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
+                else { itsT = intersect_shape(S, ps, wo, 0.0f, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
                 if (hasEnv) {
                     W.kind = K_LOOKUP;
                     if (!CURVED && !itsValid) { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
@@ -194,7 +204,7 @@ __global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
                     }
                 } else ev = EV_AFTER_LOOKUP;
             } else if (ev == EV_AFTER_LOOKUP) {
-                emitted = false;                                                          // ERadianceNoEmission
+                SET_FLAG(F_EMITTED, false);                                               // ERadianceNoEmission
                 ev = EV_NONE;
                 if (depth++ >= S.rr_depth) {                                              // volpath.cpp:326-336
                     const float q = fminf(max3(T) * 1.0f * 1.0f, 0.95f);
@@ -202,7 +212,7 @@ __global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
                     else T = T / q;
                 }
                 if (ev == EV_NONE) {
-                    scattered = true;
+                    SET_FLAG(F_SCATTERED, true);
                     if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
                     else { C.segments++; ev = W.begin(P, rng, C, K_FREE, ps, dsave, itsT); }
                 }
@@ -211,13 +221,13 @@ __global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
                 MRec m;
                 finish_free_flight(P, C, W, false, 0.0f, m);
                 T = T * (m.transmittance / m.pdfFailure);
-                if (CURVED) { T = T * m.refRatioSq; itsValid = true; }                    // edge.cpp:45-60
+                if (CURVED) { T = T * m.refRatioSq; SET_FLAG(F_ITSVALID, true); }         // edge.cpp:45-60
                 ev = EV_PATH_DONE;
                 if (!itsValid) {
                     if (emitted && (!S.hide_emitters || scattered)) L = L + T * env;
                 } else if (!(depth >= maxDepth && maxDepth != -1)) {
                     (void) rng.next1D(); (void) rng.next1D();                             // null BSDF sample
-                    emitted = !scattered;
+                    SET_FLAG(F_EMITTED, !scattered);
                     depth++;
                     if (depth <= maxDepth || maxDepth < 0)
                         if (emitted && (!S.hide_emitters || scattered)) L = L + T * env;
@@ -232,6 +242,10 @@ __global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
             }
         }
     }
+#undef scattered
+#undef emitted
+#undef itsValid
+#undef SET_FLAG
     // ---- counters (StatsCounter analogue; inputs of the roofline formula)
     const uint32_t sums[8] = {wave_sum(C.paths), wave_sum(C.steps), wave_sum(C.rif_evals), wave_sum(C.tentative),
                               wave_sum(C.real), wave_sum(C.segments), wave_sum(C.nee), wave_sum(C.marched)};
@@ -281,7 +295,7 @@ __global__ void er_trace_kernel(const Params P, const float *p0, const float *d0
     rif_value_grad<RIF>(P.rif, W.p, n0, g);
     W.n0 = n0; W.v = d * n0;
     if (isfinite(dist[i])) W.set_segment(P, dist[i]);
-    else { W.seg_inf = true; W.steps_left = 100000; W.rem = 0.0f; }
+    else { W.seg_inf = 1; W.steps_left = 100000; W.rem = 0.0f; }
     Rng rng; rng.state = 0; rng.inc = 1;
     int ev = EV_NONE;
     while (ev == EV_NONE) ev = W.advance(P, rng, C);
@@ -299,7 +313,7 @@ __global__ void sample_distance_kernel(const Params P, const float *o, const flo
     LaneCounters C; C.clear();
     Rng rng; rng.seed(P.seed, (uint32_t) i, 0);
     const f3 oo(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-    W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.rem = 0; W.steps_left = 0; W.seg_inf = false; W.sdens = 0;
+    W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.rem = 0; W.steps_left = 0; W.seg_inf = 0; W.sdens = 0;
     int ev = W.begin(P, rng, C, K_FREE, oo, dd, maxt[i]);
     float sigma = 0.0f;
     for (;;) {
@@ -336,7 +350,7 @@ __global__ void eval_transmittance_kernel(const Params P, const float *o, const 
     Rng rng; rng.seed(P.seed, (uint32_t) i, 0);
     const f3 oo(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     const int nwalks = (SIGMA == MER_SIGMA_GRID && P.sc.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
-    W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.rem = 0; W.steps_left = 0; W.seg_inf = false; W.sdens = 0;
+    W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.rem = 0; W.steps_left = 0; W.seg_inf = 0; W.sdens = 0;
     int ev = W.begin(P, rng, C, K_NEE, oo, dd, maxt[i]);
     float sigma = 0.0f; f3 tr(1, 1, 1);
     bool gate = false, closed = (ev == EV_TR_DONE);

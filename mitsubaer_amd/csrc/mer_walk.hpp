@@ -30,7 +30,7 @@ struct Walk {
     float n0;                    // refStart (heterogeneousrefractive.cpp:468)
     float rem;                   // remainder step of the current trace()
     int   steps_left;            // full steps left; -1 => remainder taken; INT_MAX/1e5 for traceTillBoundary
-    bool  seg_inf;               // traceTillBoundary
+    int   seg_inf;               // traceTillBoundary (int: see render_kernel flags note)
     float dist;                  // distSurf accumulated (curved) / sampled distance (homogeneous)
     float opt;                   // optical length
     float sdens;                 // sampling density chosen by the strategy (homogeneous)
@@ -60,7 +60,7 @@ struct Walk {
         const int steps = (int) (s / h);
         rem = s - steps * h;
         steps_left = steps;
-        seg_inf = false;
+        seg_inf = 0;
     }
     __device__ __forceinline__ void draw_segment(const Params &P, Rng &rng) {      // heterogeneous.cpp:634
         set_segment(P, -logf(1 - rng.next1D()) * P.inv_max_density);
@@ -83,7 +83,7 @@ struct Walk {
             else {
                 const float s = (k == K_FREE) ? sample_exp_distance(P, rng) : MER_INF;
                 if (isfinite(s)) { set_segment(P, s); dist = 0.0f; t = s; }
-                else { seg_inf = true; steps_left = 100000; rem = 0.0f; t = MER_INF; }   // traceTillBoundary :742-776
+                else { seg_inf = 1; steps_left = 100000; rem = 0.0f; t = MER_INF; }   // traceTillBoundary :742-776
             }
             return EV_NONE;
         } else {

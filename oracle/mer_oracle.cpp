@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <algorithm>
 #include <vector>
@@ -942,6 +943,7 @@ struct Walker {
     /* A10: VolumetricPathTracer::Li (src/integrators/path/volpath.cpp:84-343) restricted to the scene
        {one index-matched (null BSDF) convex shape with an interior medium, constant environment emitter};
        refractive deltas from src/libbidir/edge.cpp:45-60,91-93 and src/libbidir/vertex.cpp:251-255. */
+    bool dbg = false;
     Spec Li(Vec ro, Vec rd, Float rmint, Float rmaxt) {
         const orc_scene &P = S.s;
         const Spec env(P.env_radiance[0], P.env_radiance[1], P.env_radiance[2]);
@@ -985,6 +987,7 @@ struct Walker {
                         } else tr = evalTransmittance(mRec.p, dd, 0);
                     }
                     value *= tr;
+                    if (dbg) printf("orc NEE depth=%d T=%g L=%g tr=%g rng=%llu\n", depth, throughput[0], Li[0], tr[0], (unsigned long long) rng.state);
                     if (!value.isZero()) {
                         Float phaseVal = phaseEval(P.phase, P.g, wi, dd);
                         if (phaseVal != 0) {
@@ -1014,6 +1017,7 @@ struct Walker {
                         tr = evalTransmittance(ro, rd, 0);
                         if (maxInteractions == 0) blocked = true;
                     }
+                    if (dbg) printf("orc LOOKUP depth=%d T=%g L=%g tr=%g rng=%llu\n", depth, throughput[0], Li[0], tr[0], (unsigned long long) rng.state);
                     if (!blocked && !tr.isZero()) {
                         Spec value = tr * env;
                         Float emitterPdf = INV_FOURPI_F;
@@ -1231,6 +1235,7 @@ static void renderRows(const Scene &S, int spp_begin, int spp_count, uint64_t se
                 /* integrator.cpp:162-187 */
                 Pcg32 rng; rng.seed(seed, (uint32_t) (y * W + x), (uint32_t) sidx);
                 Walker Wk(S, rng, C);
+                { const char *e = getenv("ORC_DEBUG_PIXEL"); Wk.dbg = e && atoi(e) == y * W + x; }
                 Float sx = rng.next1D(), sy = rng.next1D();
                 Float px = (Float) x + sx, py = (Float) y + sy;
                 Vec o, d; Float mint, maxt;

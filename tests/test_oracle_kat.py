@@ -1,0 +1,277 @@
+"""Pins the CPU oracle on every fixture the reference offers for this path, plus the
+analytic known answers of SURVEY section 7.3.  CPU only."""
+import numpy as np
+import pytest
+from scipy import stats
+from mitsubaer_amd import params as P, synth
+from tests import scenes
+
+
+# ---------------------------------------------------------------------------------------------------
+# A5: the one numeric known answer recorded from the reference's own basisspline.h (SURVEY 8c probe):
+# 9x8x7 grid on [-1,1]x[-2,2]x[0,3], data 1.3+0.05i+0.01j^2-0.02k (float ops), query (0.13,-0.4,1.7)
+def _probe_data():
+    f = np.float32
+    k, j, i = np.meshgrid(np.arange(7), np.arange(8), np.arange(9), indexing="ij")
+    return ((f(1.3) + f(0.05) * i.astype(f)) + (f(0.01) * (j * j).astype(f))) - (f(0.02) * k.astype(f))
+
+
+def test_bspline_known_answer_fp64(orc):
+    c = orc.bspline_build(_probe_data().astype(np.float32), double=True)
+    v, g, h = orc.bspline_eval(c, [-1, -2, 0], [1, 2, 3], np.array([[0.13, -0.4, 1.7]]), hessian=True)
+    assert abs(v[0] - 1.53604451) < 2e-8
+    assert np.abs(g[0] - [0.199610477, 0.0975018531, -0.0408002379]).max() < 2e-8
+    assert abs(h[0][0] - 0.0257299574) < 2e-8
+
+
+def test_bspline_known_answer_fp32(orc):
+    c = orc.bspline_build(_probe_data().astype(np.float32))
+    v, g, h = orc.bspline_eval(c, [-1, -2, 0], [1, 2, 3], np.array([[0.13, -0.4, 1.7]], np.float32), hessian=True)
+    # fp32 results of the reference are compiler-flag dependent: a few ulp
+    assert abs(v[0] - 1.53604436) < 1e-6
+    assert np.abs(g[0] - [0.199609831, 0.0975019857, -0.0408001691]).max() < 2e-6
+    assert abs(h[0][0] - 0.0257304087) < 2e-6
+
+
+def test_bspline_interpolates_nodes_and_linear_fields(orc):
+    rng = np.random.RandomState(0)
+    shape = (11, 12, 13)
+    data = rng.rand(*shape).astype(np.float32)
+    mn, mx = [0, 0, 0], [1, 2, 3]
+    c = orc.bspline_build(data, double=True)
+    idx = np.array([[i, j, k] for k in range(2, shape[0] - 2) for j in range(2, shape[1] - 2) for i in range(2, shape[2] - 2)])
+    pts = np.stack([mn[a] + (mx[a] - mn[a]) * idx[:, a] / (shape[2 - a] - 1) for a in range(3)], 1)
+    v, _ = orc.bspline_eval(c, mn, mx, pts)
+    assert np.abs(v - data[idx[:, 2], idx[:, 1], idx[:, 0]]).max() < 1e-7      # value(node) == data
+    lin = synth.linear_rif(0, shape=(11, 41, 13))       # mirror boundary: the kink decays as (sqrt(3)-2)^k
+    c = orc.bspline_build(lin, double=True)
+    q = rng.uniform([0.3, 0.8, 0.8], [0.7, 1.2, 2.2], size=(100, 3))
+    v, g = orc.bspline_eval(c, mn, mx, q)
+    assert np.abs(v - (1.3 + 0.3 * q[:, 1] / 2)).max() < 1e-6
+    assert np.abs(g - [0, 0.15, 0]).max() < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# A9: the reference's own phase-function fixture: src/tests/test_chisquare.cpp:508-573 on
+# data/tests/test_phase.xml (isotropic; hg g=0.9; hg g=-0.3): 10x20 (theta,phi) bins, 20 incident
+# directions, 200000 samples each, significance 0.0025 with Sidak correction, cells pooled below 5.
+def _chi2_phase(sample_fn, pdf_fn, wi, rng):
+    tb, pb, n = 10, 20, 10 * 20 * 1000
+    u2 = rng.rand(n, 2).astype(np.float32)
+    wo, _ = sample_fn(np.repeat(wi[None], n, 0), u2)
+    theta = np.arccos(np.clip(wo[:, 2], -1, 1)); phi = np.arctan2(wo[:, 1], wo[:, 0]); phi[phi < 0] += 2 * np.pi
+    ti = np.clip(np.floor(theta * tb / np.pi).astype(int), 0, tb - 1)
+    pi_ = np.clip(np.floor(phi * pb / (2 * np.pi)).astype(int), 0, pb - 1)
+    table = np.bincount(ti * pb + pi_, minlength=tb * pb).astype(np.float64)
+    m = 24                                             # midpoint rule per cell (reference: adaptive NDIntegrator)
+    th = (np.arange(tb * m) + 0.5) * np.pi / (tb * m); ph = (np.arange(pb * m) + 0.5) * 2 * np.pi / (pb * m)
+    T, Ph = np.meshgrid(th, ph, indexing="ij")
+    d = np.stack([np.sin(T) * np.cos(Ph), np.sin(T) * np.sin(Ph), np.cos(T)], -1).reshape(-1, 3).astype(np.float32)
+    pdf = pdf_fn(np.repeat(wi[None], d.shape[0], 0), d).reshape(tb * m, pb * m) * np.sin(T)
+    ref = pdf.reshape(tb, m, pb, m).sum((1, 3)) * (np.pi / (tb * m)) * (2 * np.pi / (pb * m)) * n
+    order = np.argsort(ref.ravel())
+    chsq, df, pc, pr = 0.0, 0, 0.0, 0.0
+    pooled = 0
+    for i in order:
+        e, o = ref.ravel()[i], table[i]
+        if e == 0:
+            assert o <= n * 1e-4
+        elif e < 5 or (0 < pr < 5):
+            pc += o; pr += e; pooled += 1
+        else:
+            chsq += (o - e) ** 2 / e; df += 1
+    if pooled:
+        chsq += (pc - pr) ** 2 / pr; df += 1
+    df -= 1
+    pval = 1 - stats.chi2.cdf(chsq, df)
+    alpha = 1 - (1 - 0.0025) ** (1.0 / 20)
+    return pval, alpha
+
+
+@pytest.mark.parametrize("kind,g", [(P.PHASE_ISOTROPIC, 0.0), (P.PHASE_HG, 0.9), (P.PHASE_HG, -0.3)])
+def test_phase_chisquare_reference_fixture(orc, kind, g):
+    rng = np.random.RandomState(42)
+    wis = scenes.rand_dirs(20, seed=7)
+    for wi in wis[:6]:                                  # 6 of the reference's 20 directions keep the CPU suite fast
+        pval, alpha = _chi2_phase(lambda a, b: orc.phase_sample(kind, g, a, b), lambda a, b: orc.phase_eval(kind, g, a, b), wi, rng)
+        assert pval >= alpha, (pval, alpha)
+
+
+def test_hg_mean_cosine_and_pdf_normalisation(orc):
+    rng = np.random.RandomState(1)
+    for g in (0.9, -0.3, 0.8, 0.0):
+        wi = np.repeat(np.array([[0.3, -0.5, 0.81]], np.float32) / np.linalg.norm([0.3, -0.5, 0.81]), 200000, 0).astype(np.float32)
+        wo, pdf = orc.phase_sample(P.PHASE_HG, g, wi, rng.rand(200000, 2).astype(np.float32))
+        assert abs((-(wi * wo).sum(1)).mean() - g) < 4e-3          # getMeanCosine() == g
+        assert np.allclose(np.linalg.norm(wo, axis=1), 1, atol=1e-5)
+        assert np.allclose(orc.phase_eval(P.PHASE_HG, g, wi, wo), pdf, rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------
+# A1/A2: VOL v3 format (mfiles/Test.m recipe: 20x30x23 grid on [0,1]^3) and trilinear lookup
+def test_trilinear_lookup_contract(orc):
+    rng = np.random.RandomState(1)
+    data = rng.rand(23, 30, 20).astype(np.float32)          # [z][y][x]: the MATLAB array is 20x30x23 (x,y,z)
+    mn, mx = [0, 0, 0], [1, 1, 1]
+    idx = np.array([[3, 4, 5], [0, 0, 0], [18, 28, 21]])
+    pts = np.stack([idx[:, a] / (np.array([20, 30, 23])[a] - 1) for a in range(3)], 1).astype(np.float32)
+    v, ii = orc.lookup_trilinear(data, mn, mx, pts + 1e-4)
+    assert np.array_equal(ii[:, :3], idx)
+    assert np.array_equal(ii[:, 3], (idx[:, 2] * 30 + idx[:, 1]) * 20 + idx[:, 0])
+    assert np.abs(v - data[idx[:, 2], idx[:, 1], idx[:, 0]]).max() < 2e-2
+    # reject outside and on the max face (x2 >= res): gridvolume.cpp:344-346
+    v, ii = orc.lookup_trilinear(data, mn, mx, np.array([[1.0, 0.5, 0.5], [-0.01, 0.5, 0.5], [0.5, 0.5, 1.2]], np.float32))
+    assert np.all(v == 0) and np.all(ii[:, 3] == -1)
+    # u8 path: m_densityMap[i] = i/255 (gridvolume.cpp:204-214)
+    d8 = np.full((4, 4, 4), 255, np.uint8)
+    v, _ = orc.lookup_trilinear(d8, mn, mx, np.array([[0.5, 0.5, 0.5]], np.float32))
+    assert v[0] == 1.0
+
+
+def test_trilinear_gradient_is_analytic(orc):
+    data = synth.linear_rif(16)
+    pts = scenes.rand_points(1000, -0.99, 0.99)
+    v, g = orc.trilinear_value_grad(data, [-1] * 3, [1] * 3, pts)
+    assert np.abs(v - (1.45 + 0.15 * pts[:, 1])).max() < 1e-5
+    assert np.abs(g - [0, 0.15, 0]).max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------
+# A6/A7 analytic invariants
+@pytest.mark.parametrize("stepper,tol", [(P.STEP_VERLET, 2e-4), (P.STEP_RK4, 2e-5)])
+def test_linear_rif_translation_invariants(orc, stepper, tol):
+    p = scenes.curved_scene(N=32, stepper=stepper, stepsize=2e-3)
+    n = 256
+    p0 = scenes.rand_points(n, -0.3, 0.3); d0 = scenes.rand_dirs(n)
+    dist = np.full(n, 0.6, np.float32)
+    op, ov, ds, oo, ok = orc.er_trace(p, p0, d0, dist)
+    n0 = 1.45 + 0.15 * p0[:, 1]
+    assert ok.all()
+    assert np.abs(ov[:, 0] - n0 * d0[:, 0]).max() < tol       # n d_x conserved
+    assert np.abs(ov[:, 2] - n0 * d0[:, 2]).max() < tol       # n d_z conserved
+    n1 = 1.45 + 0.15 * op[:, 1]
+    assert np.abs(np.linalg.norm(ov, axis=1) - n1).max() < 5e-4   # |v| = n (eikonal)
+    assert np.allclose(ds, 0.6, atol=1e-5)
+    assert np.abs(oo - 0.6 * 0.5 * (n0 + n1)).max() < 2e-3    # optical length ~ mean index * arc length
+
+
+def test_radial_rif_bouguer_invariant(orc):
+    p = scenes.curved_scene(N=48, rif="radial", stepper=P.STEP_RK4, stepsize=2e-3)
+    n = 256
+    p0 = scenes.rand_points(n, -0.4, 0.4); d0 = scenes.rand_dirs(n)
+    op, ov, ds, oo, ok = orc.er_trace(p, p0, d0, np.full(n, 0.5, np.float32))
+    r0 = np.linalg.norm(p0, axis=1) ** 2
+    v0 = d0 * (2 - r0 / 3)[:, None]
+    L0 = np.cross(p0, v0); L1 = np.cross(op, ov)
+    assert np.abs(L1 - L0).max() < 3e-3                       # |r x n d| = const (trilinear grid error included)
+
+
+def test_trace_exit_steps_back_inside(orc):
+    p = scenes.curved_scene(N=24)
+    n = 512
+    p0 = scenes.rand_points(n, -0.9, 0.9); d0 = scenes.rand_dirs(n)
+    op, ov, ds, oo, ok = orc.er_trace(p, p0, d0, np.full(n, np.inf, np.float32))
+    assert not ok.any()
+    assert (np.abs(op) <= 1 + 1e-6).all()                     # last inside point
+    assert (np.abs(op).max(1) > 1 - 3 * p.stepsize).all()     # within ~a step of the boundary
+
+
+# ---------------------------------------------------------------------------------------------------
+# A3/A4/A8 known answers
+def test_homogeneous_free_flight_and_transmittance(orc):
+    p = scenes.homogeneous_scene(strategy=P.STRATEGY_SINGLE, channel=0, medium_sampling_weight=1.0,
+                                 sigma_a=[0.5, 0.5, 0.5], sigma_s=[1.5, 1.5, 1.5])
+    n = 200000
+    o = np.zeros((n, 3), np.float32); d = np.tile(np.array([[1, 0, 0]], np.float32), (n, 1))
+    rec = orc.sample_distance(p, o, d, np.full(n, 0.8, np.float32), 1)
+    succ = rec[:, 0] == 1
+    assert abs(succ.mean() - (1 - np.exp(-2 * 0.8))) < 4e-3       # free-flight CDF 1-exp(-sigma_t t)
+    assert abs(rec[succ, 1].mean() - (1 / 2 - 0.8 * np.exp(-1.6) / (1 - np.exp(-1.6)))) < 4e-3
+    # pdf identities homogeneous.cpp:317-343
+    assert np.allclose(rec[succ, 11], 2 * np.exp(-2 * rec[succ, 1]), rtol=1e-5)
+    assert np.allclose(rec[~succ, 12], np.exp(-1.6), rtol=1e-5)
+    tr = orc.eval_transmittance(p, o[:4], d[:4], np.full(4, 0.8, np.float32), 1)
+    assert np.allclose(tr, np.exp(-1.6), rtol=1e-6)
+
+
+@pytest.mark.parametrize("est", [P.TR_WOODCOCK2, P.TR_RATIO])
+def test_delta_tracking_transmittance_is_unbiased(orc, est):
+    """E[tau] = exp(-int sigma_t) on a linear ramp sigma_t(x) = 4 * (0.5 + 0.25 x): analytic integral."""
+    N = 33
+    ramp = np.broadcast_to((0.5 + 0.25 * np.linspace(-1, 1, N, dtype=np.float32))[None, None, :], (N, N, N)).copy()
+    p = scenes.straight_scene(N=8, tr_estimator=est)
+    p.density = ramp
+    n = 400000
+    o = np.tile(np.array([[-0.5, 0.1, -0.2]], np.float32), (n, 1)); d = np.tile(np.array([[1, 0, 0]], np.float32), (n, 1))
+    tr = orc.eval_transmittance(p, o, d, np.full(n, 1.0, np.float32), 3)[:, 0]
+    exact = np.exp(-4 * (0.5 * 1.0 + 0.25 * (0.5 ** 2 - 0.5 ** 2) / 2))      # int_{-0.5}^{0.5} = 0.5
+    assert abs(tr.mean() - exact) < 4 * tr.std() / np.sqrt(n) + 1e-4
+    if est == P.TR_WOODCOCK2:
+        assert set(np.unique(tr)).issubset({0.0, 0.5, 1.0})       # binary estimator, nSamples = 2
+
+
+def test_woodcock_collision_density(orc):
+    """collisions land with density sigma_t(x) T(x); on constant rho = 0.5, scale 4: exponential, rate 2."""
+    p = scenes.straight_scene(N=8)
+    p.density = np.full((8, 8, 8), 0.5, np.float32)
+    n = 200000
+    o = np.tile(np.array([[-0.9, 0, 0]], np.float32), (n, 1)); d = np.tile(np.array([[1, 0, 0]], np.float32), (n, 1))
+    rec = orc.sample_distance(p, o, d, np.full(n, 1.5, np.float32), 4)
+    succ = rec[:, 0] == 1
+    assert abs(succ.mean() - (1 - np.exp(-3.0))) < 4e-3
+    assert np.allclose(rec[succ, 5:8], 0.9 * 2.0, rtol=1e-5)     # sigmaS = albedo * sigma_t
+    assert np.allclose(rec[succ, 8], 0.5, rtol=1e-5)             # transmittance = 1/sigma_t (heterogeneous.cpp:649)
+
+
+def test_refractive_sample_distance_limits(orc):
+    """sigma = const through the composed estimator == heterogeneousrefractive::sampleDistance statistics;
+    refRatioSq = n_end^2 / n_start^2 (heterogeneousrefractive.cpp:469,501)."""
+    p = scenes.curved_scene(N=24, sigma_mode=P.SIGMA_HOMOGENEOUS, strategy=P.STRATEGY_SINGLE, channel=0,
+                            medium_sampling_weight=1.0, sigma_a=[0.2] * 3, sigma_s=[1.8] * 3, stepper=P.STEP_VERLET)
+    n = 20000
+    o = np.tile(np.array([[0, -0.2, 0]], np.float32), (n, 1)); d = np.tile(np.array([[0, 1, 0]], np.float32), (n, 1))
+    rec = orc.sample_distance(p, o, d, np.full(n, 9.0, np.float32), 2)
+    succ = rec[:, 0] == 1
+    # exit happens when the (straight, along y) ray has travelled 1.2: P(success) = 1 - exp(-2*1.2)
+    assert abs(succ.mean() - (1 - np.exp(-2.4))) < 1e-2
+    ny = 1.45 + 0.15 * rec[:, 3]
+    assert np.allclose(rec[:, 13], (ny / 1.42) ** 2, rtol=2e-3)
+    assert np.allclose(np.linalg.norm(rec[:, 14:17], axis=1), ny, rtol=2e-3)      # mRec.d = un-normalised momentum
+
+
+# ---------------------------------------------------------------------------------------------------
+# A10/A11 known answers
+def test_non_absorbing_medium_furnace_straight(orc):
+    """albedo 1, env 1, n = 1: every pixel receives exactly 1 (NEE + phase MIS weights sum to one)."""
+    p = scenes.straight_scene(N=16, w=24, h=24, albedo=[1, 1, 1], rfilter=P.FILTER_BOX, rfilter_param=0.5, rr_depth=1000)
+    film, c = orc.render(p, 0, 16, 1)
+    img = film[..., :3] / film[..., 4:5]
+    assert abs(img.mean() - 1.0) < 2e-2
+    assert c[orc.C_PATHS] == 24 * 24 * 16
+
+
+def test_emission_only_slab(orc):
+    """no env, emissive non-scattering medium (albedo 0): L = eps/sigma_t * (1 - T), collision estimator."""
+    p = scenes.straight_scene(N=8, w=16, h=16, albedo=[0, 0, 0], env_radiance=[0, 0, 0], emission=[1.0, 0.6, 0.3],
+                              rfilter=P.FILTER_BOX, rfilter_param=0.5, fov_x_deg=10.0)
+    p.density = np.full((8, 8, 8), 0.5, np.float32)
+    film, _ = orc.render(p, 0, 256, 2)
+    img = film[..., :3] / film[..., 4:5]
+    expect = np.array([1.0, 0.6, 0.3]) * (1 - np.exp(-2.0 * 2.0))      # sigma_t = 2, chord ~2 at fov 10 deg
+    assert np.abs(img.mean((0, 1)) - expect).max() < 2e-2
+
+
+def test_filter_table(orc):
+    v, r, s = orc.filter_table(P.FILTER_GAUSSIAN, 0.5)
+    assert r == 2.0 and abs(s - 15.5) < 1e-6 and v[31] == 0
+    assert abs(2 * r / 31 * v[:31].sum() - 1.0) < 1e-5                 # normalised (rfilter.cpp:50-54)
+    v, r, s = orc.filter_table(P.FILTER_BOX, 0.5)
+    assert abs(r - 0.50001) < 1e-7 and np.allclose(v[:31], v[0])
+
+
+def test_rng_stream_properties(orc):
+    a = orc.rng_floats(0, 0, 0, 100000)
+    assert a.min() >= 0 and a.max() < 1 and abs(a.mean() - 0.5) < 5e-3
+    assert np.all((a * 2 ** 23) == np.floor(a * 2 ** 23))               # 23-bit granularity (random.cpp:630-639)
+    assert not np.array_equal(a[:8], orc.rng_floats(0, 1, 0, 8))
+    assert not np.array_equal(a[:8], orc.rng_floats(0, 0, 1, 8))
