@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its headline config.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A step = one full render of the workload (default: config 3 = 256^3 sigma_t grid + 256^3 linear RIF,
+RK4 eikonal stepping on the trilinear field, HG g=0.8, 512^2 x 256 spp, half-voxel steps, ratio-tracking
+transmittance, box filter) with all inputs resident in HBM.  N > 1 (launched by torch.distributed.run) shards
+sample indices across ranks (weak scaling: every rank renders 512^2 x 256 spp of a 512^2 x (256 N) spp job)
+and sum-reduces the film with RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 measured by a float4 copy
+
+
+def build_workload(name, res, size, spp):
+    import numpy as np
+    from mitsubaer_amd import params as P, synth
+    common = dict(width=size, height=size, rfilter=P.FILTER_BOX, rfilter_param=0.5, tr_estimator=P.TR_RATIO,
+                  phase=P.PHASE_HG, g=0.8, density_scale=4.0, albedo=[0.9, 0.9, 0.9])
+    dens = synth.density_field(res)
+    if name == "cfg2":
+        p = P.SceneParams(density=dens, rif_mode=P.RIF_CONST, **common)
+        desc = "%d^3 sigma_t grid, constant RIF (straight rays), HG g=0.8, %d^2 x %d spp" % (res, size, spp)
+    elif name == "cfg3":
+        p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.linear_rif(res), stepper=P.STEP_RK4,
+                          stepsize=0.5 * 2.0 / (res - 1), **common)
+        desc = "%d^3 sigma_t grid + %d^3 linear-gradient RIF, RK4 eikonal curved rays, HG g=0.8, %d^2 x %d spp" % (res, res, size, spp)
+    elif name == "cfg4":
+        p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.radial_rif(res), stepper=P.STEP_RK4,
+                          stepsize=0.5 * 2.0 / (res - 1), **common)
+        desc = "%d^3 sigma_t grid + %d^3 radial RIF, RK4 eikonal curved rays, HG g=0.8, %d^2 x %d spp" % (res, res, size, spp)
+    else:
+        raise SystemExit("unknown workload %s" % name)
+    return p, desc
+
+
+def algorithmic_bytes(c, p):
+    """B_alg = 4*[T_rif*E*C_steps + 8*C_tent + 24*C_real*[albedo gridded]] + 40*C_paths."""
+    from mitsubaer_amd import capi, params as P
+    t_rif = 0 if p.rif_mode == P.RIF_CONST else (8 if p.rif_mode == P.RIF_TRILINEAR else 64)
+    e = 2 if p.stepper == P.STEP_VERLET else 4
+    alb = 24 if p.albedo_mode == P.ALBEDO_GRID else 0
+    return 4.0 * (t_rif * e * float(c[capi.C_STEPS]) + 8.0 * float(c[capi.C_TENTATIVE]) + alb * float(c[capi.C_REAL])) \
+        + 40.0 * float(c[capi.C_PATHS])
+
+
+def cpu_baseline(p, target_seconds=20.0):
+    """The CPU oracle (kind 'port': the restatement of the reference's routines) on a bounded sample of the same
+    workload: whole image, few spp, all host cores."""
+    from oracle import orc
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    orc.build()
+    t0 = time.time()
+    orc.render(p, 0, 1, 0, nthreads=cores, rows=(p.height // 2 - 8, p.height // 2 + 8))      # calibration: 16 rows
+    dt = max(time.time() - t0, 1e-3)
+    per_spp = dt * p.height / 16.0
+    spp = int(max(1, min(16, target_seconds / per_spp)))
+    t0 = time.time()
+    _, c = orc.render(p, 0, spp, 0, nthreads=cores)
+    dt = time.time() - t0
+    paths = p.width * p.height * spp
+    return {"value": paths / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d x %d spp of the same scene (%.1f s), oracle/libmer_oracle.so fp32, std::thread over rows" % (p.width, p.height, spp, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--layout", default="dense", choices=["dense", "cell8"])
+    ap.add_argument("--shard", default="samples", choices=["samples", "tiles"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from mitsubaer_amd import capi, dist as mdist
+    rank, world, local = mdist.init_process_group()
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    p, desc = build_workload(args.workload, args.res, args.size, args.spp)
+    ctx = capi.Context(local)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    layout = capi.LAYOUT_CELL8 if args.layout == "cell8" else capi.LAYOUT_DENSE
+    sc, vols = ctx.upload_scene(p, layout=layout)
+    film = torch.zeros((p.height, p.width, 5), dtype=torch.float32, device=dev)
+    # weak scaling: every rank renders args.spp samples per pixel of a (spp * world)-sample job
+    sh = mdist.shard_args(args.shard, rank, world, args.spp * world) if args.shard == "samples" else \
+        mdist.shard_args(args.shard, rank, world, args.spp * world)
+
+    def step(seed):
+        film.zero_()
+        ctx.render(sc, film.data_ptr(), sh["spp_begin"], sh["spp_count"], seed=seed, spp_stride=sh["spp_stride"],
+                   tile_rank=sh["tile_rank"], tile_count=sh["tile_count"])
+        mdist.reduce_film(film)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(1000 + i)
+    barrier()
+    ctx.counters_reset()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+        # HIP events recorded by libmer around the render kernel on the launch stream; reading them waits for
+        # this step's kernel only (steps are dependent through the film anyway)
+        kernel_ms.append(ctx.last_kernel_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    counters = ctx.counters().astype(np.float64)
+    paths_rank = float(counters[capi.C_PATHS])
+    ct = torch.tensor(counters, dtype=torch.float64, device=dev)
+    mdist.reduce_counters(ct)
+    total_paths = float(ct[capi.C_PATHS].item())
+
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        b_alg = algorithmic_bytes(counters, p) / max(args.steps, 1)      # per launch, this rank
+        achieved = b_alg / (k_ms * 1e-3) / 1e9
+        lane_eff = float(counters[capi.C_ACTIVE_LANES] / max(counters[capi.C_LOOP_ITERS], 1.0))
+        name, cus, hbm = ctx.device_info()
+        out = {
+            "metric": "Mpaths/sec (curved-ray heterogeneous volume); roofline = achieved algorithmic HBM GB/s vs peak",
+            "value": total_paths / elapsed / 1e6, "unit": "Mpaths/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: " + desc, "grid": args.res, "film": [p.width, p.height], "spp_per_gpu": args.spp,
+                       "stepper": "rk4", "rif_interp": "trilinear", "layout": args.layout, "shard": args.shard,
+                       "stepsize": p.stepsize, "estimator": "volpath + delta tracking on eikonal rays, ratio-tracking NEE",
+                       "device": name, "cus": cus},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "render_kernel<curved,trilinear,rk4,grid>", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": b_alg,
+                         "counters_per_launch": {"paths": paths_rank / args.steps, "steps": counters[capi.C_STEPS] / args.steps,
+                                                 "tentative": counters[capi.C_TENTATIVE] / args.steps, "real": counters[capi.C_REAL] / args.steps},
+                         "active_lane_fraction": lane_eff},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(p, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

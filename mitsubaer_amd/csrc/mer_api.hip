@@ -37,6 +37,10 @@ struct mer_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     hipDeviceProp_t prop;
+    // wavefront path-state slots
+    uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
+    uint32_t *queue = nullptr, *qcount = nullptr;
+    int last_passes = 0;
 };
 
 #define HIP_CHECK(ctx, call)                                                                              \
@@ -259,6 +263,11 @@ void mer_context_destroy(mer_context *ctx) {
         if (kv.second.coeff) (void) hipFree(kv.second.coeff);
     }
     if (ctx->counters) (void) hipFree(ctx->counters);
+    if (ctx->slots) (void) hipFree(ctx->slots);
+    if (ctx->live) (void) hipFree(ctx->live);
+    if (ctx->queue) (void) hipFree(ctx->queue);
+    if (ctx->qcount) (void) hipFree(ctx->qcount);
+    if (ctx->host_live) (void) hipHostFree(ctx->host_live);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -416,19 +425,72 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     HIP_CHECK(ctx, hipSetDevice(ctx->device));
     HIP_CHECK(ctx, hipMemsetAsync(P.work_counter, 0, sizeof(unsigned long long), ctx->stream));
     if (P.total_work == 0) return 0;
+    const char *mode = getenv("MER_MODE");
+    if (mode && std::strcmp(mode, "mega") == 0) {
+        return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
+            auto kern = render_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
+            int per_cu = 0;
+            HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, MER_BLOCK, 0));
+            if (per_cu < 1) per_cu = 1;
+            int64_t blocks = (int64_t) per_cu * ctx->prop.multiProcessorCount;
+            const int64_t need = (int64_t) ((P.total_work + MER_BLOCK - 1) / MER_BLOCK);
+            if (blocks > need) blocks = need;
+            HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+            hipLaunchKernelGGL(kern, dim3((unsigned) blocks), dim3(MER_BLOCK), 0, ctx->stream, P);
+            HIP_CHECK(ctx, hipGetLastError());
+            HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+            ctx->timed = true;
+            return 0;
+        });
+    }
+    // ---- wavefront: K_event / K_march passes over the path-state slots until no lane is alive
+    uint32_t want = (uint32_t) ctx->prop.multiProcessorCount * 2048u * 2u;          // 2 x the resident lanes of the chip
+    { const char *e = getenv("MER_NSLOTS"); if (e && atoi(e) > 0) want = (uint32_t) atoi(e); }
+    want = (want + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
+    if (ctx->nslots != want) {
+        if (ctx->slots) (void) hipFree(ctx->slots);
+        if (ctx->queue) (void) hipFree(ctx->queue);
+        ctx->slots = nullptr; ctx->queue = nullptr; ctx->nslots = 0;
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->slots, (size_t) want * SLOT_WORDS * sizeof(uint32_t)));
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->queue, (size_t) want * sizeof(uint32_t)));
+        ctx->nslots = want;
+    }
+    if (!ctx->live) {
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->live, MER_LIVE_SLOTS * sizeof(uint32_t)));
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->qcount, MER_LIVE_SLOTS * sizeof(uint32_t)));
+        HIP_CHECK(ctx, hipHostMalloc((void **) &ctx->host_live, sizeof(uint32_t)));
+    }
+    uint32_t nslots = ctx->nslots;
+    const uint64_t need_slots = (P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
+    if (need_slots < nslots) nslots = (uint32_t) need_slots;
+    P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.queue = ctx->queue; P.qcount = ctx->qcount;
+    P.ksteps = 32;
+    { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) P.ksteps = atoi(e); }
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->slots + (size_t) H_FLAGS * nslots, 0, (size_t) nslots * sizeof(uint32_t), ctx->stream));
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->qcount, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
     return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
-        auto kern = render_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
-        int per_cu = 0;
-        HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, MER_BLOCK, 0));
-        if (per_cu < 1) per_cu = 1;
-        int64_t blocks = (int64_t) per_cu * ctx->prop.multiProcessorCount;
-        const int64_t need = (int64_t) ((P.total_work + MER_BLOCK - 1) / MER_BLOCK);
-        if (blocks > need) blocks = need;
+        auto kev = event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
+        auto kma = march_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
+        const unsigned blocks = nslots / MER_BLOCK;
         HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        hipLaunchKernelGGL(kern, dim3((unsigned) blocks), dim3(MER_BLOCK), 0, ctx->stream, P);
-        HIP_CHECK(ctx, hipGetLastError());
+        const uint32_t check_every = 8;
+        uint32_t pass = 0;
+        for (;;) {
+            hipLaunchKernelGGL(kev, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
+            hipLaunchKernelGGL(kma, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
+            pass++;
+            if (pass % check_every == 0) {
+                HIP_CHECK(ctx, hipGetLastError());
+                HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_live, ctx->live, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+                if (*ctx->host_live >= nslots) break;
+                if (pass > (1u << 24)) return fail(ctx, "mer_render: pass limit exceeded");
+            }
+        }
         HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        ctx->timed = true;
+        ctx->timed = true; ctx->last_passes = (int) pass;
+        if (getenv("MER_VERBOSE")) { float ms = 0; (void) hipEventSynchronize(ctx->ev1); (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); fprintf(stderr, "[mer] wavefront: %u passes, K=%d, nslots=%u, %.3f ms\n", pass, P.ksteps, nslots, ms); }
         return 0;
     });
 }

@@ -148,33 +148,47 @@ __device__ __forceinline__ f3 lookup_spectrum(const DGrid &g, f3 p) {
     return f3(out[0], out[1], out[2]);
 }
 
-// Trilinear value + analytic gradient of the interpolant; cell clamped to the grid (new --
-// gridvolume has no value()/gradient(), src/librender/volume.cpp:57-80).  Value keeps lookupFloat's blend.
-__device__ __forceinline__ void trilinear_value_grad(const DGrid &g, f3 p, float &val, f3 &grad) {
-    const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
+// Trilinear RIF: value + analytic gradient of the interpolant; cell clamped to the grid (new --
+// gridvolume has no value()/gradient(), src/librender/volume.cpp:57-80).  Being new functionality, its
+// arithmetic is DEFINED here (and restated identically in the oracle) in fused form: lerp(a,b,f)=fma(f,b-a,a).
+// The 8 corner values of the last cell are kept in registers: the 4 RK4 stages of a half-voxel step land in
+// the same cell most of the time, so the gather is re-issued only when the cell index changes.
+struct CellCache {
+    int cell;                 // linear index of the cached cell's base corner, -1 = empty
+    float d000, d001, d010, d011, d100, d101, d110, d111;
+    __device__ __forceinline__ void reset() { cell = -1; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f; }
+};
+
+__device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &cc, f3 p, float &val, f3 &grad) {
+    const float px = __builtin_fmaf(g.s[0], p.x, g.t[0]), py = __builtin_fmaf(g.s[1], p.y, g.t[1]), pz = __builtin_fmaf(g.s[2], p.z, g.t[2]);
     int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
     x1 = min(max(x1, 0), g.res[0] - 2); y1 = min(max(y1, 0), g.res[1] - 2); z1 = min(max(z1, 0), g.res[2] - 2);
-    const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
-                _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
-    float d000, d001, d010, d011, d100, d101, d110, d111;
-    if (g.layout == MER_LAYOUT_CELL8) {
-        const int cell = (z1 * (g.res[1] - 1) + y1) * (g.res[0] - 1) + x1;
-        const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
-        const float4 a = c[0], b = c[1];
-        d000 = a.x; d001 = a.y; d010 = a.z; d011 = a.w; d100 = b.x; d101 = b.y; d110 = b.z; d111 = b.w;
-    } else {
-        const float *D = (const float *) g.data;
-        const int base = (z1 * g.res[1] + y1) * g.res[0] + x1, sy = g.res[0], sz = g.res[0] * g.res[1];
-        d000 = D[base]; d001 = D[base + 1]; d010 = D[base + sy]; d011 = D[base + sy + 1];
-        d100 = D[base + sz]; d101 = D[base + sz + 1]; d110 = D[base + sz + sy]; d111 = D[base + sz + sy + 1];
+    const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1;
+    const int base = (z1 * g.res[1] + y1) * g.res[0] + x1;
+    if (base != cc.cell) {
+        cc.cell = base;
+        if (g.layout == MER_LAYOUT_CELL8) {
+            const int cell = (z1 * (g.res[1] - 1) + y1) * (g.res[0] - 1) + x1;
+            const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
+            const float4 a = c[0], b = c[1];
+            cc.d000 = a.x; cc.d001 = a.y; cc.d010 = a.z; cc.d011 = a.w; cc.d100 = b.x; cc.d101 = b.y; cc.d110 = b.z; cc.d111 = b.w;
+        } else {
+            const float *D = (const float *) g.data;
+            const int sy = g.res[0], sz = g.res[0] * g.res[1];
+            cc.d000 = D[base]; cc.d001 = D[base + 1]; cc.d010 = D[base + sy]; cc.d011 = D[base + sy + 1];
+            cc.d100 = D[base + sz]; cc.d101 = D[base + sz + 1]; cc.d110 = D[base + sz + sy]; cc.d111 = D[base + sz + sy + 1];
+        }
     }
-    const float c00 = d000 * _fx + d001 * fx, c01 = d010 * _fx + d011 * fx,
-                c10 = d100 * _fx + d101 * fx, c11 = d110 * _fx + d111 * fx;
-    const float c0 = c00 * _fy + c01 * fy, c1 = c10 * _fy + c11 * fy;
-    val = c0 * _fz + c1 * fz;
-    const float gx = ((d001 - d000) * _fy + (d011 - d010) * fy) * _fz + ((d101 - d100) * _fy + (d111 - d110) * fy) * fz;
-    const float gy = (c01 - c00) * _fz + (c11 - c10) * fz;
+    const float dx00 = cc.d001 - cc.d000, dx01 = cc.d011 - cc.d010, dx10 = cc.d101 - cc.d100, dx11 = cc.d111 - cc.d110;
+    const float c00 = __builtin_fmaf(fx, dx00, cc.d000), c01 = __builtin_fmaf(fx, dx01, cc.d010),
+                c10 = __builtin_fmaf(fx, dx10, cc.d100), c11 = __builtin_fmaf(fx, dx11, cc.d110);
+    const float dy0 = c01 - c00, dy1 = c11 - c10;
+    const float c0 = __builtin_fmaf(fy, dy0, c00), c1 = __builtin_fmaf(fy, dy1, c10);
     const float gz = c1 - c0;
+    val = __builtin_fmaf(fz, gz, c0);
+    const float gy = __builtin_fmaf(fz, dy1 - dy0, dy0);
+    const float gxa = __builtin_fmaf(fy, dx01 - dx00, dx00), gxb = __builtin_fmaf(fy, dx11 - dx10, dx10);
+    const float gx = __builtin_fmaf(fz, gxb - gxa, gxa);
     grad = f3(gx * g.s[0], gy * g.s[1], gz * g.s[2]);
 }
 
@@ -231,42 +245,51 @@ __device__ __forceinline__ bool inside_volume_limits(const DGrid &g, f3 p) {   /
            p.z > g.lim_min[2] && p.z < g.lim_max[2];
 }
 
-template <int RIF> __device__ __forceinline__ void rif_value_grad(const DGrid &g, f3 p, float &n, f3 &gr) {
-    if (RIF == MER_RIF_TRILINEAR) trilinear_value_grad(g, p, n, gr);
+template <int RIF> __device__ __forceinline__ void rif_value_grad(const DGrid &g, CellCache &cc, f3 p, float &n, f3 &gr) {
+    if (RIF == MER_RIF_TRILINEAR) trilinear_value_grad(g, cc, p, n, gr);
     else bspline_value_grad(g, p, n, gr);
+}
+
+__device__ __forceinline__ f3 fma3(float s, f3 a, f3 b) {           // s*a + b, fused per component
+    return f3(__builtin_fmaf(s, a.x, b.x), __builtin_fmaf(s, a.y, b.y), __builtin_fmaf(s, a.z, b.z));
 }
 
 // ------------------------------------------------------------------------------------------------
 // er_step: velocity-Verlet (heterogeneousrefractive.cpp:653-661) or classic RK4 on
-// dp/ds = v/n, dv/ds = grad n, dopt/ds = n.  Returns the number of field evaluations.
+// dp/ds = v/n, dv/ds = grad n, dopt/ds = n.  The Verlet form keeps the reference's operation
+// order; the RK4 form is new and is defined with fused multiply-adds (restated identically in the oracle).
 template <int RIF, int STEPPER>
-__device__ __forceinline__ void er_step(const DGrid &g, f3 &p, f3 &v, float h, float &opt) {
+__device__ __forceinline__ void er_step(const DGrid &g, CellCache &cc, f3 &p, f3 &v, float h, float &opt) {
     if (STEPPER == MER_STEP_VERLET) {
         float n, n2; f3 G, G2;
-        rif_value_grad<RIF>(g, p, n, G);
+        rif_value_grad<RIF>(g, cc, p, n, G);
         v = v + 0.5f * h * G;
         p = p + h * v / n;
-        rif_value_grad<RIF>(g, p, n2, G2);
+        rif_value_grad<RIF>(g, cc, p, n2, G2);
         v = v + 0.5f * h * G2;
         opt += h * n;
     } else {
-        float n1, n2, n3, n4; f3 g1, g2, g3, g4;
+        float n; f3 gr;
         const float hh = 0.5f * h;
-        rif_value_grad<RIF>(g, p, n1, g1);
-        const f3 kp1 = v / n1;
-        const f3 v2 = v + hh * g1;
-        rif_value_grad<RIF>(g, p + hh * kp1, n2, g2);
-        const f3 kp2 = v2 / n2;
-        const f3 v3 = v + hh * g2;
-        rif_value_grad<RIF>(g, p + hh * kp2, n3, g3);
-        const f3 kp3 = v3 / n3;
-        const f3 v4 = v + h * g3;
-        rif_value_grad<RIF>(g, p + h * kp3, n4, g4);
-        const f3 kp4 = v4 / n4;
-        const float h6 = h / 6.0f;
-        p = p + h6 * (kp1 + 2.0f * kp2 + 2.0f * kp3 + kp4);
-        v = v + h6 * (g1 + 2.0f * g2 + 2.0f * g3 + g4);
-        opt += h6 * (n1 + 2.0f * n2 + 2.0f * n3 + n4);
+        rif_value_grad<RIF>(g, cc, p, n, gr);                       // k1
+        f3 kp = v * (1.0f / n);
+        f3 ps = kp, vs = gr; float ns = n;
+        f3 vv = fma3(hh, gr, v);
+        rif_value_grad<RIF>(g, cc, fma3(hh, kp, p), n, gr);          // k2
+        kp = vv * (1.0f / n);
+        ps = fma3(2.0f, kp, ps); vs = fma3(2.0f, gr, vs); ns = __builtin_fmaf(2.0f, n, ns);
+        vv = fma3(hh, gr, v);
+        rif_value_grad<RIF>(g, cc, fma3(hh, kp, p), n, gr);          // k3
+        kp = vv * (1.0f / n);
+        ps = fma3(2.0f, kp, ps); vs = fma3(2.0f, gr, vs); ns = __builtin_fmaf(2.0f, n, ns);
+        vv = fma3(h, gr, v);
+        rif_value_grad<RIF>(g, cc, fma3(h, kp, p), n, gr);           // k4
+        kp = vv * (1.0f / n);
+        ps = ps + kp; vs = vs + gr; ns = ns + n;
+        const float h6 = h * (1.0f / 6.0f);
+        p = fma3(h6, ps, p);
+        v = fma3(h6, vs, v);
+        opt = __builtin_fmaf(h6, ns, opt);
     }
 }
 template <int STEPPER> __device__ __forceinline__ constexpr int evals_per_step() { return STEPPER == MER_STEP_VERLET ? 2 : 4; }
@@ -334,7 +357,12 @@ struct Params {
     unsigned long long *counters;       // MER_C_COUNT
     unsigned long long *work_counter;
     int32_t dbg_pixel;
+    // wavefront path-state slots (struct of arrays, word k of slot i at slots[k*nslots + i])
+    uint32_t *slots; uint32_t nslots; int32_t ksteps;
+    uint32_t *live;                     // live[0]: number of finished slots
+    uint32_t *queue, *qcount;           // event queue (slot indices) and its length per pass (ring of MER_LIVE_SLOTS)
 };
+#define MER_LIVE_SLOTS 4096
 
 __device__ __forceinline__ bool inside_shape(const mer_scene_desc &s, f3 p) {   // heterogeneousrefractive.cpp:707-726 as data (D5)
     if (s.boundary == MER_BOUNDARY_SPHERE) {

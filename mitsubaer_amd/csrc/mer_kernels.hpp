@@ -31,7 +31,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+}  // namespace mer
+#include "mer_wavefront.hpp"
+namespace mer {
+
 // ---------------------------------------------------------------------------------------------------
+// Megakernel form of the same state machine (kept for A/B timing: MER_MODE=mega).
 // K_trace: VolumetricPathTracer::Li (src/integrators/path/volpath.cpp:84-343) restricted to one convex
 // index-matched shape + interior medium + constant environment emitter, with the refractive hooks of
 // src/libbidir/edge.cpp:45-60,91-93 and src/libbidir/vertex.cpp:251-255, as a lane-persistent state machine.
@@ -50,6 +55,7 @@ __global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
     WalkT W;
     W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = 0; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1;
     W.dist = 0; W.opt = 0; W.sdens = 0; W.Tr = 1; W.trsum = 0; W.walk = 0; W.p = f3(0, 0, 0); W.v = f3(0, 0, 1);
+    W.backstep = 0; W.hprev = 0; W.cc.reset();
     int st = ST_NEW;
     int px_i = 0, py_i = 0; float px = 0, py = 0;
     f3 L(0, 0, 0), T(1, 1, 1);
@@ -277,7 +283,8 @@ __global__ void rif_value_grad_kernel(DGrid g, int interp, const float *pts, int
     if (i >= n) return;
     float v; f3 gr;
     const f3 p(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    if (interp == MER_RIF_TRILINEAR) trilinear_value_grad(g, p, v, gr); else bspline_value_grad(g, p, v, gr);
+    CellCache cc; cc.reset();
+    if (interp == MER_RIF_TRILINEAR) trilinear_value_grad(g, cc, p, v, gr); else bspline_value_grad(g, p, v, gr);
     val[i] = v; grad[3 * i] = gr.x; grad[3 * i + 1] = gr.y; grad[3 * i + 2] = gr.z;
 }
 
@@ -289,10 +296,11 @@ __global__ void er_trace_kernel(const Params P, const float *p0, const float *d0
     Walk<true, RIF, STEPPER, MER_SIGMA_HOMOGENEOUS> W;
     LaneCounters C; C.clear();
     W.kind = K_FREE; W.trsum = 0; W.walk = 0; W.Tr = 1; W.dist = 0; W.opt = 0; W.sdens = 0; W.t = 0; W.tmin = 0; W.tmax = 0;
+    W.backstep = 0; W.hprev = 0; W.cc.reset();
     W.p = f3(p0[3 * i], p0[3 * i + 1], p0[3 * i + 2]);
     const f3 d(d0[3 * i], d0[3 * i + 1], d0[3 * i + 2]);
     float n0; f3 g;
-    rif_value_grad<RIF>(P.rif, W.p, n0, g);
+    rif_value_grad<RIF>(P.rif, W.cc, W.p, n0, g);
     W.n0 = n0; W.v = d * n0;
     if (isfinite(dist[i])) W.set_segment(P, dist[i]);
     else { W.seg_inf = 1; W.steps_left = 100000; W.rem = 0.0f; }
@@ -313,7 +321,7 @@ __global__ void sample_distance_kernel(const Params P, const float *o, const flo
     LaneCounters C; C.clear();
     Rng rng; rng.seed(P.seed, (uint32_t) i, 0);
     const f3 oo(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-    W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.rem = 0; W.steps_left = 0; W.seg_inf = 0; W.sdens = 0;
+    W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.rem = 0; W.steps_left = 0; W.seg_inf = 0; W.sdens = 0; W.backstep = 0; W.hprev = 0; W.cc.reset();
     int ev = W.begin(P, rng, C, K_FREE, oo, dd, maxt[i]);
     float sigma = 0.0f;
     for (;;) {
@@ -350,7 +358,7 @@ __global__ void eval_transmittance_kernel(const Params P, const float *o, const 
     Rng rng; rng.seed(P.seed, (uint32_t) i, 0);
     const f3 oo(o[3 * i], o[3 * i + 1], o[3 * i + 2]), dd(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     const int nwalks = (SIGMA == MER_SIGMA_GRID && P.sc.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
-    W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.rem = 0; W.steps_left = 0; W.seg_inf = 0; W.sdens = 0;
+    W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.rem = 0; W.steps_left = 0; W.seg_inf = 0; W.sdens = 0; W.backstep = 0; W.hprev = 0; W.cc.reset();
     int ev = W.begin(P, rng, C, K_NEE, oo, dd, maxt[i]);
     float sigma = 0.0f; f3 tr(1, 1, 1);
     bool gate = false, closed = (ev == EV_TR_DONE);

@@ -36,6 +36,9 @@ struct Walk {
     float sdens;                 // sampling density chosen by the strategy (homogeneous)
     float Tr, trsum; int walk;   // transmittance estimator
     int   kind;
+    int   backstep;              // 1 => the next step is the step back after leaving the shape (trace(): :678-681)
+    float hprev;
+    CellCache cc;                // RIF cell cache (trilinear)
 
     __device__ __forceinline__ f3 pos() const { return CURVED ? p : p + v * t; }
 
@@ -71,12 +74,12 @@ struct Walk {
     __device__ __forceinline__ int begin(const Params &P, Rng &rng, LaneCounters &C, int k, f3 o, f3 d, float rayMaxt, bool first_walk = true) {
         kind = k;
         if (first_walk) { trsum = 0.0f; walk = 0; }
-        Tr = 1.0f; dist = 0.0f; opt = 0.0f;
+        Tr = 1.0f; dist = 0.0f; opt = 0.0f; backstep = 0;
         if (CURVED) {
             p = o; v = d;
             if (RIF == MER_RIF_BSPLINE3 && !inside_volume_limits(P.rif, p)) return EV_GATE_FAIL;   // heterogeneousrefractive.cpp:461-466
             float n; f3 g;
-            rif_value_grad<RIF>(P.rif, p, n, g); C.rif_evals++;
+            rif_value_grad<RIF>(P.rif, cc, p, n, g); C.rif_evals++;
             n0 = n;
             v = d * n0;                                                       // :470-472
             if (SIGMA == MER_SIGMA_GRID) draw_segment(P, rng);
@@ -117,16 +120,17 @@ struct Walk {
     __device__ __forceinline__ int advance(const Params &P, Rng &rng, LaneCounters &C) {
         C.marched++;
         if (CURVED) {
+            // one er_step call site: the step back after an exit is one more trip through here with -h
             const bool full = steps_left > 0;
-            const float h = full ? P.sc.stepsize : rem;
-            er_step<RIF, STEPPER>(P.rif, p, v, h, opt);
+            const float h = backstep ? -hprev : (full ? P.sc.stepsize : rem);
+            er_step<RIF, STEPPER>(P.rif, cc, p, v, h, opt);
             C.steps++; C.rif_evals += evals_per_step<STEPPER>();
-            if (!inside_shape(P.sc, p)) {
-                er_step<RIF, STEPPER>(P.rif, p, v, -h, opt);                  // step back (:678-681)
-                C.steps++; C.rif_evals += evals_per_step<STEPPER>();
-                if (seg_inf) dist -= h;                                       // traceTillBoundary :757-759 (as shipped)
+            if (backstep) {
+                backstep = 0;
+                if (seg_inf) dist -= hprev;                                   // traceTillBoundary :757-759 (as shipped)
                 return EV_EXITED;
             }
+            if (!inside_shape(P.sc, p)) { backstep = 1; hprev = h; return EV_NONE; }   // (:678-681)
             dist += h;
             if (full) {
                 steps_left--;
@@ -208,7 +212,7 @@ __device__ __forceinline__ void finish_free_flight(const Params &P, LaneCounters
     m.p = W.pos(); m.d = W.v; m.t = CURVED ? W.dist : W.t;
     if (CURVED) {
         float refEnd; f3 g;
-        rif_value_grad<RIF>(P.rif, W.p, refEnd, g); C.rif_evals++;                      // :500-501
+        rif_value_grad<RIF>(P.rif, W.cc, W.p, refEnd, g); C.rif_evals++;                // :500-501
         m.refRatioSq = (1.0f / (W.n0 * W.n0)) * (refEnd * refEnd);
     }
     if (SIGMA == MER_SIGMA_GRID) {

@@ -1,0 +1,361 @@
+// mer_wavefront.hpp -- wavefront form of the hot path: K_march (hot, lean) + K_event (cold, fat).
+//
+// Why two kernels: the per-path state of volpath (throughput, radiance, scatter point, saved directions, MIS
+// pdfs, sampler, film position ...) is ~45 registers that the marching loop never touches.  Kept live in one
+// megakernel they cap the occupancy at 1-2 waves/SIMD, and the loop is latency-bound (4 dependent field
+// gathers per RK4 step).  Here path state lives in HBM as struct-of-arrays slots; K_march loads only the ray it
+// is marching (~20 words), takes up to `ksteps` eikonal steps / tentative-collision jumps -- null collisions are
+// resolved in place -- and parks the lane at the first real event.  K_event then runs the volpath state machine
+// (scatter, NEE, look-up, Russian roulette, exit, film splat, regeneration from the work counter) for the
+// lanes that have an event.  Slot traffic is ~160 B per lane per pass against ksteps x 128 B of field fetches.
+#pragma once
+#include "mer_walk.hpp"
+
+namespace mer {
+
+// hot words (K_march reads/writes these)
+enum { H_PX = 0, H_PY, H_PZ, H_VX, H_VY, H_VZ, H_OPT, H_DIST, H_REM, H_HPREV, H_TR, H_T, H_TMAX, H_STEPS, H_FLAGS,
+       H_RNG_LO, H_RNG_HI, H_PIXEL, H_SAMPLE, H_SIGMA, H_COUNT };
+// cold words (K_event only)
+enum { CO_PXF = H_COUNT, CO_PYF, CO_LX, CO_LY, CO_LZ, CO_TX, CO_TY, CO_TZ, CO_DEPTH, CO_PFLAGS, CO_PSX, CO_PSY, CO_PSZ,
+       CO_DSX, CO_DSY, CO_DSZ, CO_DDX, CO_DDY, CO_DDZ, CO_WIX, CO_WIY, CO_WIZ, CO_PHASEPDF, CO_ITST, CO_N0, CO_TRSUM,
+       CO_SDENS, CO_TMIN, SLOT_WORDS };
+
+// H_FLAGS: st[1:0] ev[5:2] kind[7:6] seg_inf[8] backstep[9] walk[11:10]
+__device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg_inf, int backstep, int walk) {
+    return (uint32_t) st | ((uint32_t) ev << 2) | ((uint32_t) kind << 6) | ((uint32_t) seg_inf << 8) | ((uint32_t) backstep << 9) |
+           ((uint32_t) walk << 10);
+}
+
+#define SLOT(k) P.slots[(size_t) (k) * P.nslots + i]
+#define SLOTF(k) __uint_as_float(SLOT(k))
+
+template <class WalkT>
+__device__ __forceinline__ void load_hot(const Params &P, uint32_t i, uint32_t fl, WalkT &W, Rng &rng, uint32_t &pixel, uint32_t &sample) {
+    W.p = f3(SLOTF(H_PX), SLOTF(H_PY), SLOTF(H_PZ));
+    W.v = f3(SLOTF(H_VX), SLOTF(H_VY), SLOTF(H_VZ));
+    W.opt = SLOTF(H_OPT); W.dist = SLOTF(H_DIST); W.rem = SLOTF(H_REM); W.hprev = SLOTF(H_HPREV); W.Tr = SLOTF(H_TR);
+    W.t = SLOTF(H_T); W.tmax = SLOTF(H_TMAX); W.steps_left = (int) SLOT(H_STEPS);
+    W.kind = (fl >> 6) & 3; W.seg_inf = (fl >> 8) & 1; W.backstep = (fl >> 9) & 1; W.walk = (fl >> 10) & 3;
+    pixel = SLOT(H_PIXEL); sample = SLOT(H_SAMPLE);
+    rng.state = (uint64_t) SLOT(H_RNG_LO) | ((uint64_t) SLOT(H_RNG_HI) << 32);
+    rng.inc = (((((uint64_t) sample) << 32) | (uint64_t) pixel) << 1) | 1ULL;
+}
+template <class WalkT>
+__device__ __forceinline__ void store_hot(const Params &P, uint32_t i, int st, int ev, const WalkT &W, const Rng &rng, float sigma) {
+    SLOT(H_PX) = __float_as_uint(W.p.x); SLOT(H_PY) = __float_as_uint(W.p.y); SLOT(H_PZ) = __float_as_uint(W.p.z);
+    SLOT(H_VX) = __float_as_uint(W.v.x); SLOT(H_VY) = __float_as_uint(W.v.y); SLOT(H_VZ) = __float_as_uint(W.v.z);
+    SLOT(H_OPT) = __float_as_uint(W.opt); SLOT(H_DIST) = __float_as_uint(W.dist); SLOT(H_REM) = __float_as_uint(W.rem);
+    SLOT(H_HPREV) = __float_as_uint(W.hprev); SLOT(H_TR) = __float_as_uint(W.Tr); SLOT(H_T) = __float_as_uint(W.t);
+    SLOT(H_TMAX) = __float_as_uint(W.tmax); SLOT(H_STEPS) = (uint32_t) W.steps_left;
+    SLOT(H_FLAGS) = pack_flags(st, ev, W.kind, W.seg_inf, W.backstep, W.walk);
+    SLOT(H_RNG_LO) = (uint32_t) rng.state; SLOT(H_RNG_HI) = (uint32_t) (rng.state >> 32);
+    SLOT(H_SIGMA) = __float_as_uint(sigma);
+}
+
+__device__ __forceinline__ void flush_counters(const Params &P, const LaneCounters &C, uint32_t lane_slots) {
+    const uint32_t sums[8] = {wave_sum(C.paths), wave_sum(C.steps), wave_sum(C.rif_evals), wave_sum(C.tentative),
+                              wave_sum(C.real), wave_sum(C.segments), wave_sum(C.nee), wave_sum(C.marched)};
+    const uint32_t slots = wave_sum(lane_slots);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; k++) if (sums[k]) atomicAdd(P.counters + k, (unsigned long long) sums[k]);
+        if (slots) atomicAdd(P.counters + MER_C_LOOP_ITERS, (unsigned long long) slots);
+        if (sums[7]) atomicAdd(P.counters + MER_C_ACTIVE_LANES, (unsigned long long) sums[7]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K_march: the hot loop.  trace() / traceTillBoundary (heterogeneousrefractive.cpp:671-691,742-776) and the
+// delta-tracking loop (heterogeneous.cpp:633-656, :562-585) for whichever ray the lane is on.
+template <bool CURVED, int RIF, int STEPPER, int SIGMA>
+__global__ void __launch_bounds__(MER_BLOCK) march_kernel(const Params P, uint32_t pass) {
+    const uint32_t i = blockIdx.x * MER_BLOCK + threadIdx.x;
+    if (i >= P.nslots) return;
+    const uint32_t fl = SLOT(H_FLAGS);
+    LaneCounters C; C.clear();
+    uint32_t iters = 0;
+    bool has_event = false;
+    if ((fl & 3u) == ST_MARCH && ((fl >> 2) & 15u) == EV_NONE) {
+        Walk<CURVED, RIF, STEPPER, SIGMA> W;
+        Rng rng; uint32_t pixel, sample;
+        load_hot(P, i, fl, W, rng, pixel, sample);
+        W.cc.reset(); W.n0 = 1.0f; W.tmin = 0.0f; W.trsum = 0.0f; W.sdens = 0.0f;
+        int ev = EV_NONE; float sigma = 0.0f;
+        const int K = P.ksteps;
+        for (int k = 0; k < K; ++k) {
+            ev = W.advance(P, rng, C);
+            if (ev == EV_ARRIVED) ev = W.on_arrived(P, rng, C, sigma);
+            iters++;
+            if (ev != EV_NONE) break;
+        }
+        store_hot(P, i, ST_MARCH, ev, W, rng, sigma);
+        has_event = ev != EV_NONE;
+    }
+    // compaction: lanes parked on an event append their slot to the queue K_event will sweep (wave-aggregated)
+    {
+        const unsigned long long mask = __ballot(has_event);
+        if (mask) {
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long) mask) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(P.qcount + ((pass + 1) & (MER_LIVE_SLOTS - 1)), (uint32_t) __popcll(mask));
+            base = (uint32_t) __shfl((int) base, leader, 64);
+            if (has_event) P.queue[base + (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL))] = i;
+        }
+    }
+    // lane-slot accounting: every lane of the wave is held for as many trips as its slowest lane
+    uint32_t wave_iters = iters;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wave_iters = max(wave_iters, (uint32_t) __shfl_xor((int) wave_iters, off, 64));
+    flush_counters(P, C, wave_iters);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K_event: VolumetricPathTracer::Li (src/integrators/path/volpath.cpp:84-343) restricted to one convex
+// index-matched shape + interior medium + constant environment emitter, with the refractive hooks of
+// src/libbidir/edge.cpp:45-60,91-93 and src/libbidir/vertex.cpp:251-255, plus pixel regeneration
+// (src/librender/integrator.cpp:162-187) and ImageBlock::put (include/mitsuba/render/imageblock.h:124-205).
+template <bool CURVED, int RIF, int STEPPER, int SIGMA>
+__global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32_t pass) {
+    typedef Walk<CURVED, RIF, STEPPER, SIGMA> WalkT;
+    const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
+    if (j >= P.nslots) return;
+    // pass 0: every slot is new; later passes: the compacted list of slots K_march parked on an event
+    const uint32_t count = pass == 0 ? P.nslots : P.qcount[pass & (MER_LIVE_SLOTS - 1)];
+    if (j == 0) P.qcount[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0;     // ring hygiene: K_march of pass+1 adds to this entry
+    LaneCounters C; C.clear();
+    if (j < count) {
+    const uint32_t i = pass == 0 ? j : P.queue[j];
+    const uint32_t fl = SLOT(H_FLAGS);
+    int st = fl & 3u, ev = (fl >> 2) & 15u;
+
+    const mer_scene_desc &S = P.sc;
+    const f3 env(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
+    const bool hasEnv = !is_zero(env);
+    const bool hasEmission = S.emission[0] != 0 || S.emission[1] != 0 || S.emission[2] != 0;
+    const int maxDepth = S.max_depth;
+    const int nwalks = (SIGMA == MER_SIGMA_GRID && S.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
+    enum { F_SCATTERED = 1, F_EMITTED = 2, F_ITSVALID = 4 };
+#define scattered ((flags & F_SCATTERED) != 0)
+#define emitted ((flags & F_EMITTED) != 0)
+#define itsValid ((flags & F_ITSVALID) != 0)
+#define SET_FLAG(f, v) flags = (v) ? (flags | (f)) : (flags & ~(f))
+
+    WalkT W; Rng rng; uint32_t pixel = 0, sample = 0;
+    W.cc.reset();
+    float px = 0, py = 0, sigma = 0, phasePdf = 0, itsT = 0;
+    f3 L(0, 0, 0), T(1, 1, 1), ps(0, 0, 0), dsave(0, 0, 1), dd(0, 0, 1), wi(0, 0, 1), trv(1, 1, 1);
+    int depth = 1, flags = F_EMITTED, px_i = 0, py_i = 0;
+    if (st == ST_MARCH) {
+        load_hot(P, i, fl, W, rng, pixel, sample);
+        sigma = SLOTF(H_SIGMA);
+        px = SLOTF(CO_PXF); py = SLOTF(CO_PYF);
+        L = f3(SLOTF(CO_LX), SLOTF(CO_LY), SLOTF(CO_LZ)); T = f3(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ));
+        depth = (int) SLOT(CO_DEPTH); flags = (int) SLOT(CO_PFLAGS);
+        ps = f3(SLOTF(CO_PSX), SLOTF(CO_PSY), SLOTF(CO_PSZ)); dsave = f3(SLOTF(CO_DSX), SLOTF(CO_DSY), SLOTF(CO_DSZ));
+        dd = f3(SLOTF(CO_DDX), SLOTF(CO_DDY), SLOTF(CO_DDZ)); wi = f3(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
+        phasePdf = SLOTF(CO_PHASEPDF); itsT = SLOTF(CO_ITST); W.n0 = SLOTF(CO_N0); W.trsum = SLOTF(CO_TRSUM);
+        W.sdens = SLOTF(CO_SDENS); W.tmin = SLOTF(CO_TMIN);
+        px_i = (int) (pixel % (uint32_t) S.width); py_i = (int) (pixel / (uint32_t) S.width);
+    } else {
+        W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = 0; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.dist = 0;
+        W.opt = 0; W.sdens = 0; W.Tr = 1; W.trsum = 0; W.walk = 0; W.p = f3(0, 0, 0); W.v = f3(0, 0, 1); W.backstep = 0; W.hprev = 0;
+        rng.state = 0; rng.inc = 1;
+    }
+
+    for (;;) {
+        // ---------------------------------------------------------------- regeneration (integrator.cpp:162-187)
+        if (st == ST_NEW) {
+            const uint64_t w = atomicAdd(P.work_counter, 1ULL);
+            if (w >= P.total_work) { st = ST_DONE; break; }
+            int x, y;
+            if (!decode_work(P, w, x, y, sample)) continue;      // pixel of a partial edge tile
+            px_i = x; py_i = y; pixel = (uint32_t) (y * S.width + x);
+            rng.seed(P.seed, pixel, sample);
+            const float sx = rng.next1D(), sy = rng.next1D();
+            px = (float) px_i + sx; py = (float) py_i + sy;
+            f3 o, d; float mint, maxt;
+            sample_ray(P, px, py, o, d, mint, maxt);
+            L = f3(0, 0, 0); T = f3(1, 1, 1); depth = 1; flags = F_EMITTED;
+            C.paths++;
+            ev = EV_NONE;
+            itsT = intersect_shape(S, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
+            if (itsT < 0) {
+                if (!S.hide_emitters) L = L + T * env;                         // volpath.cpp:194-201
+                ev = EV_PATH_DONE;
+            } else if (depth >= maxDepth && maxDepth != -1) ev = EV_PATH_DONE;
+            else {
+                (void) rng.next1D(); (void) rng.next1D();                      // null bsdf->sample(..., nextSample2D())
+                const f3 ro = o + d * itsT;
+                bool medium = true;
+                if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
+                else { itsT = intersect_shape(S, ro, d, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); if (!itsValid) medium = false; }
+                depth++;
+                if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
+                else if (!medium) { if (!S.hide_emitters) L = L + T * env; ev = EV_PATH_DONE; }
+                else { C.segments++; ps = ro; dsave = d; ev = W.begin(P, rng, C, K_FREE, ro, d, itsT); }
+            }
+            st = ST_MARCH;
+        }
+        if (ev == EV_NONE) break;                  // marching again: K_march takes over
+
+        // ---------------------------------------------------------------- one event
+        if (ev == EV_ARRIVED) {
+            ev = W.on_arrived(P, rng, C, sigma);
+        } else if (ev == EV_EXITED) {
+            ev = (W.kind == K_FREE) ? EV_FAIL : EV_WALK_END;
+        } else if (ev == EV_GATE_FAIL) {
+            if (W.kind == K_FREE) ev = EV_PATH_DONE;          // transmittance 0 => nothing further contributes
+            else { trv = f3(0, 0, 0); ev = EV_TR_DONE; }
+        } else if (ev == EV_WALK_END) {
+            W.trsum += W.Tr; W.walk++;
+            if (W.walk < nwalks) ev = W.begin(P, rng, C, W.kind, ps, W.kind == K_NEE ? dd : dsave, itsT, false);
+            else {
+                if (SIGMA == MER_SIGMA_GRID) { const float tv = W.trsum / (float) nwalks; trv = f3(tv, tv, tv); }
+                else trv = homogeneous_transmittance(P, -W.dist);                    // heterogeneousrefractive.cpp:393-400
+                ev = EV_TR_DONE;
+            }
+        } else if (ev == EV_REAL) {
+            // ---- medium interaction: volpath.cpp:104-118
+            MRec m;
+            finish_free_flight(P, C, W, true, sigma, m);
+            bool success = true;
+            if (SIGMA == MER_SIGMA_HOMOGENEOUS) {
+                if (m.p.x == ps.x && m.p.y == ps.y && m.p.z == ps.z) success = false;   // no forward progress
+            }
+            if (!success) { ev = EV_FAIL; continue; }
+            C.real++;
+            if (depth >= maxDepth && maxDepth != -1) { ev = EV_PATH_DONE; continue; }
+            if (hasEmission && SIGMA == MER_SIGMA_GRID)
+                L = L + T * f3(S.emission[0], S.emission[1], S.emission[2]) * m.refRatioSq;
+            T = T * (m.sigmaS * m.transmittance / m.pdfSuccess);
+            if (CURVED) T = T * m.refRatioSq;                                         // edge.cpp:91-93
+            wi = CURVED ? normalize(-m.d) : -W.v;                                     // vertex.cpp:251-255
+            ps = m.p;
+            if (hasEnv) {
+                // ---- luminaire sampling: scene.cpp:854-874, constant.cpp:179-214
+                C.nee++;
+                const int interactions = maxDepth - depth - 1;
+                const float s2x = rng.next1D(), s2y = rng.next1D();
+                dd = square_to_uniform_sphere(s2x, s2y);
+                W.kind = K_NEE;
+                if (interactions != 0) {                                              // scene.cpp:619-678: one null crossing
+                    float tExit = 0.0f;
+                    if (!CURVED) tExit = intersect_shape(S, ps, dd, 0.0f, MER_INF);
+                    if (tExit >= 0) {
+                        itsT = tExit;
+                        ev = W.begin(P, rng, C, K_NEE, ps, dd, tExit);
+                        if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - tExit);
+                    } else { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
+                } else { trv = f3(0, 0, 0); ev = EV_TR_DONE; }
+            } else ev = EV_PHASE;
+        } else if (ev == EV_TR_DONE) {
+            const f3 tr = trv;
+            if (W.kind == K_NEE) {
+                const float dpdf = MER_INV_FOURPI;
+                f3 value = env / dpdf;
+                value = value * tr;
+                if (!is_zero(value)) {
+                    const float phaseVal = phase_eval(S.phase, S.g, wi, dd);
+                    if (phaseVal != 0) {
+                        const float weight = mi_weight(dpdf, phaseVal);              // env emitter is "on surface": constant.cpp:47
+                        L = L + T * value * phaseVal * weight;
+                    }
+                }
+                ev = EV_PHASE;
+            } else {
+                // emitter look-up along the phase-sampled direction: volpath.cpp:162-173,370-428
+                const int maxInteractions = maxDepth - depth - 1;
+                const bool blocked = (maxInteractions == 0) && (CURVED || itsValid);
+                if (!blocked && !is_zero(tr)) {
+                    const f3 value = tr * env;
+                    L = L + T * value * mi_weight(phasePdf, MER_INV_FOURPI);
+                }
+                ev = EV_AFTER_LOOKUP;
+            }
+        } else if (ev == EV_PHASE) {
+            // ---- phase function sampling: volpath.cpp:149-160
+            const float p2x = rng.next1D(), p2y = rng.next1D();
+            f3 wo;
+            phase_sample(S.phase, S.g, wi, p2x, p2y, wo, phasePdf);
+            dsave = wo;
+            if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
+            else { itsT = intersect_shape(S, ps, wo, 0.0f, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
+            if (hasEnv) {
+                W.kind = K_LOOKUP;
+                if (!CURVED && !itsValid) { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
+                else {
+                    ev = W.begin(P, rng, C, K_LOOKUP, ps, wo, itsT);
+                    if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - itsT);
+                }
+            } else ev = EV_AFTER_LOOKUP;
+        } else if (ev == EV_AFTER_LOOKUP) {
+            SET_FLAG(F_EMITTED, false);                                               // ERadianceNoEmission
+            ev = EV_NONE;
+            bool alive = true;
+            if (depth++ >= S.rr_depth) {                                              // volpath.cpp:326-336
+                const float q = fminf(max3(T) * 1.0f * 1.0f, 0.95f);
+                if (rng.next1D() >= q) { ev = EV_PATH_DONE; alive = false; }
+                else T = T / q;
+            }
+            if (alive) {
+                SET_FLAG(F_SCATTERED, true);
+                if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
+                else { C.segments++; ev = W.begin(P, rng, C, K_FREE, ps, dsave, itsT); }
+            }
+        } else if (ev == EV_FAIL) {
+            // ---- no medium interaction: volpath.cpp:183-201,289-301
+            MRec m;
+            finish_free_flight(P, C, W, false, 0.0f, m);
+            T = T * (m.transmittance / m.pdfFailure);
+            if (CURVED) { T = T * m.refRatioSq; SET_FLAG(F_ITSVALID, true); }         // edge.cpp:45-60
+            ev = EV_PATH_DONE;
+            if (!itsValid) {
+                if (emitted && (!S.hide_emitters || scattered)) L = L + T * env;
+            } else if (!(depth >= maxDepth && maxDepth != -1)) {
+                (void) rng.next1D(); (void) rng.next1D();                             // null BSDF sample
+                SET_FLAG(F_EMITTED, !scattered);
+                depth++;
+                if (depth <= maxDepth || maxDepth < 0)
+                    if (emitted && (!S.hide_emitters || scattered)) L = L + T * env;
+            }
+        } else {  // EV_PATH_DONE: ImageBlock::put (imageblock.h:124-205)
+            if (P.path_out) {
+                float *q = P.path_out + ((size_t) py_i * S.width + px_i) * 3;
+                q[0] = L.x; q[1] = L.y; q[2] = L.z;
+            } else film_put(P, px, py, L, 1.0f);
+            st = ST_NEW;
+            ev = EV_NONE;
+        }
+    }
+#undef scattered
+#undef emitted
+#undef itsValid
+#undef SET_FLAG
+
+    // ---- park the lane
+    if (st == ST_DONE) { SLOT(H_FLAGS) = ST_DONE; atomicAdd(P.live, 1u); }      // live[0] counts finished slots
+    else {
+        store_hot(P, i, ST_MARCH, EV_NONE, W, rng, 0.0f);
+        SLOT(H_PIXEL) = pixel; SLOT(H_SAMPLE) = sample;
+        SLOT(CO_PXF) = __float_as_uint(px); SLOT(CO_PYF) = __float_as_uint(py);
+        SLOT(CO_LX) = __float_as_uint(L.x); SLOT(CO_LY) = __float_as_uint(L.y); SLOT(CO_LZ) = __float_as_uint(L.z);
+        SLOT(CO_TX) = __float_as_uint(T.x); SLOT(CO_TY) = __float_as_uint(T.y); SLOT(CO_TZ) = __float_as_uint(T.z);
+        SLOT(CO_DEPTH) = (uint32_t) depth; SLOT(CO_PFLAGS) = (uint32_t) flags;
+        SLOT(CO_PSX) = __float_as_uint(ps.x); SLOT(CO_PSY) = __float_as_uint(ps.y); SLOT(CO_PSZ) = __float_as_uint(ps.z);
+        SLOT(CO_DSX) = __float_as_uint(dsave.x); SLOT(CO_DSY) = __float_as_uint(dsave.y); SLOT(CO_DSZ) = __float_as_uint(dsave.z);
+        SLOT(CO_DDX) = __float_as_uint(dd.x); SLOT(CO_DDY) = __float_as_uint(dd.y); SLOT(CO_DDZ) = __float_as_uint(dd.z);
+        SLOT(CO_WIX) = __float_as_uint(wi.x); SLOT(CO_WIY) = __float_as_uint(wi.y); SLOT(CO_WIZ) = __float_as_uint(wi.z);
+        SLOT(CO_PHASEPDF) = __float_as_uint(phasePdf); SLOT(CO_ITST) = __float_as_uint(itsT);
+        SLOT(CO_N0) = __float_as_uint(W.n0); SLOT(CO_TRSUM) = __float_as_uint(W.trsum);
+        SLOT(CO_SDENS) = __float_as_uint(W.sdens); SLOT(CO_TMIN) = __float_as_uint(W.tmin);
+    }
+    }   // j < count
+    flush_counters(P, C, 0);
+}
+
+#undef SLOT
+#undef SLOTF
+
+}  // namespace mer

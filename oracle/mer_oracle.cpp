@@ -211,29 +211,33 @@ struct Grid {
     }
 };
 
-/* trilinear value + analytic gradient of the interpolant, cell clamped to the grid (new: SURVEY D2).
-   value keeps the blend order of gridvolume.cpp:364-367. */
+/* trilinear value + analytic gradient of the interpolant, cell clamped to the grid (new: SURVEY D2 --
+   gridvolume has no value()/gradient()).  Being new functionality its arithmetic is a definition, not a
+   restatement: fused lerps lerp(a,b,f) = fma(f, b-a, a), the same expression tree the HIP kernel uses. */
 template <typename FLOAT>
 inline void trilinearValueGrad(const Grid &g, const V3<FLOAT> &pw, FLOAT &val, V3<FLOAT> &grad) {
-    const FLOAT px = (FLOAT) g.m[0][0] * pw.x + (FLOAT) g.m[0][3];
-    const FLOAT py = (FLOAT) g.m[1][1] * pw.y + (FLOAT) g.m[1][3];
-    const FLOAT pz = (FLOAT) g.m[2][2] * pw.z + (FLOAT) g.m[2][3];
+    const FLOAT px = std::fma((FLOAT) g.m[0][0], pw.x, (FLOAT) g.m[0][3]);
+    const FLOAT py = std::fma((FLOAT) g.m[1][1], pw.y, (FLOAT) g.m[1][3]);
+    const FLOAT pz = std::fma((FLOAT) g.m[2][2], pw.z, (FLOAT) g.m[2][3]);
     int x1 = (int) std::floor(px), y1 = (int) std::floor(py), z1 = (int) std::floor(pz);
     x1 = std::min(std::max(x1, 0), g.res[0] - 2);
     y1 = std::min(std::max(y1, 0), g.res[1] - 2);
     z1 = std::min(std::max(z1, 0), g.res[2] - 2);
-    const FLOAT fx = px - x1, fy = py - y1, fz = pz - z1, _fx = 1 - fx, _fy = 1 - fy, _fz = 1 - fz;
+    const FLOAT fx = px - x1, fy = py - y1, fz = pz - z1;
     const float *D = (const float *) g.data;
     const int base = (z1 * g.res[1] + y1) * g.res[0] + x1, sy = g.res[0], sz = g.res[0] * g.res[1];
     const FLOAT d000 = D[base], d001 = D[base + 1], d010 = D[base + sy], d011 = D[base + sy + 1],
                 d100 = D[base + sz], d101 = D[base + sz + 1], d110 = D[base + sz + sy], d111 = D[base + sz + sy + 1];
-    const FLOAT c00 = d000 * _fx + d001 * fx, c01 = d010 * _fx + d011 * fx,
-                c10 = d100 * _fx + d101 * fx, c11 = d110 * _fx + d111 * fx;
-    const FLOAT c0 = c00 * _fy + c01 * fy, c1 = c10 * _fy + c11 * fy;
-    val = c0 * _fz + c1 * fz;
-    const FLOAT gx = ((d001 - d000) * _fy + (d011 - d010) * fy) * _fz + ((d101 - d100) * _fy + (d111 - d110) * fy) * fz;
-    const FLOAT gy = (c01 - c00) * _fz + (c11 - c10) * fz;
+    const FLOAT dx00 = d001 - d000, dx01 = d011 - d010, dx10 = d101 - d100, dx11 = d111 - d110;
+    const FLOAT c00 = std::fma(fx, dx00, d000), c01 = std::fma(fx, dx01, d010),
+                c10 = std::fma(fx, dx10, d100), c11 = std::fma(fx, dx11, d110);
+    const FLOAT dy0 = c01 - c00, dy1 = c11 - c10;
+    const FLOAT c0 = std::fma(fy, dy0, c00), c1 = std::fma(fy, dy1, c10);
     const FLOAT gz = c1 - c0;
+    val = std::fma(fz, gz, c0);
+    const FLOAT gy = std::fma(fz, dy1 - dy0, dy0);
+    const FLOAT gxa = std::fma(fy, dx01 - dx00, dx00), gxb = std::fma(fy, dx11 - dx10, dx10);
+    const FLOAT gx = std::fma(fz, gxb - gxa, gxa);
     grad = V3<FLOAT>(gx * (FLOAT) g.m[0][0], gy * (FLOAT) g.m[1][1], gz * (FLOAT) g.m[2][2]);
 }
 
@@ -608,23 +612,31 @@ template <typename FLOAT> struct Tracer {
             v += SplineConst<FLOAT>::half() * h * R.gradient(p, C);
             opt += h * n;
         } else {
-            FLOAT n1, n2, n3, n4; V3<FLOAT> g1, g2, g3, g4;
+            /* classic RK4 (new), defined with fused multiply-adds; same expression tree as the kernel */
+            auto fma3 = [](FLOAT sc, const V3<FLOAT> &a, const V3<FLOAT> &b) {
+                return V3<FLOAT>(std::fma(sc, a.x, b.x), std::fma(sc, a.y, b.y), std::fma(sc, a.z, b.z));
+            };
+            FLOAT n; V3<FLOAT> gr;
             const FLOAT hh = (FLOAT) 0.5 * h;
-            R.valueAndGradient(p, n1, g1, C);
-            V3<FLOAT> kp1 = v / n1;
-            V3<FLOAT> v2 = v + hh * g1;
-            R.valueAndGradient(p + hh * kp1, n2, g2, C);
-            V3<FLOAT> kp2 = v2 / n2;
-            V3<FLOAT> v3 = v + hh * g2;
-            R.valueAndGradient(p + hh * kp2, n3, g3, C);
-            V3<FLOAT> kp3 = v3 / n3;
-            V3<FLOAT> v4 = v + h * g3;
-            R.valueAndGradient(p + h * kp3, n4, g4, C);
-            V3<FLOAT> kp4 = v4 / n4;
-            const FLOAT h6 = h / (FLOAT) 6;
-            p += h6 * (kp1 + (FLOAT) 2 * kp2 + (FLOAT) 2 * kp3 + kp4);
-            v += h6 * (g1 + (FLOAT) 2 * g2 + (FLOAT) 2 * g3 + g4);
-            opt += h6 * (n1 + (FLOAT) 2 * n2 + (FLOAT) 2 * n3 + n4);
+            R.valueAndGradient(p, n, gr, C);
+            V3<FLOAT> kp = v * ((FLOAT) 1 / n);
+            V3<FLOAT> ps = kp, vs = gr; FLOAT ns = n;
+            V3<FLOAT> vv = fma3(hh, gr, v);
+            R.valueAndGradient(fma3(hh, kp, p), n, gr, C);
+            kp = vv * ((FLOAT) 1 / n);
+            ps = fma3((FLOAT) 2, kp, ps); vs = fma3((FLOAT) 2, gr, vs); ns = std::fma((FLOAT) 2, n, ns);
+            vv = fma3(hh, gr, v);
+            R.valueAndGradient(fma3(hh, kp, p), n, gr, C);
+            kp = vv * ((FLOAT) 1 / n);
+            ps = fma3((FLOAT) 2, kp, ps); vs = fma3((FLOAT) 2, gr, vs); ns = std::fma((FLOAT) 2, n, ns);
+            vv = fma3(h, gr, v);
+            R.valueAndGradient(fma3(h, kp, p), n, gr, C);
+            kp = vv * ((FLOAT) 1 / n);
+            ps = ps + kp; vs = vs + gr; ns = ns + n;
+            const FLOAT h6 = h * ((FLOAT) 1 / (FLOAT) 6);
+            p = fma3(h6, ps, p);
+            v = fma3(h6, vs, v);
+            opt = std::fma(h6, ns, opt);
         }
     }
     /* heterogeneousrefractive.cpp:671-691 */
