@@ -39,7 +39,7 @@ struct mer_context {
     hipDeviceProp_t prop;
     // wavefront path-state slots
     uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
-    uint32_t *queue = nullptr, *qcount = nullptr;
+    uint32_t *queue = nullptr, *qcount = nullptr, *mqueue = nullptr, *mcount = nullptr;
     int last_passes = 0;
 };
 
@@ -61,6 +61,10 @@ static void fill_dgrid(const Volume &v, DGrid &g) {
     g.data = v.dense; g.cell8 = v.cell8; g.coeff = v.coeff;
     g.layout = v.cell8 ? MER_LAYOUT_CELL8 : MER_LAYOUT_DENSE;
     g.channels = v.desc.channels; g.dtype = v.desc.dtype;
+    {
+        const uint64_t bytes = v.cell8 ? (uint64_t) (v.desc.res[0] - 1) * (v.desc.res[1] - 1) * (v.desc.res[2] - 1) * 32ull : (uint64_t) v.bytes_dense;
+        g.buf_bytes = bytes < 0xFFFFFFFFull && !getenv("MER_NO_BUFFER_LOADS") ? (uint32_t) bytes : 0u;
+    }
     for (int i = 0; i < 3; i++) {
         g.res[i] = v.desc.res[i];
         g.bmin[i] = v.desc.aabb_min[i]; g.bmax[i] = v.desc.aabb_max[i];
@@ -181,7 +185,7 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P) {
         if (!(sc->sph_radius > 0)) return fail(ctx, "medium shape: sphere radius must be positive");
     } else return fail(ctx, "unknown medium boundary");
     P.counters = ctx->counters;
-    P.work_counter = ctx->counters + MER_C_COUNT;
+    P.work_counter = ctx->counters + MER_C_COUNT * MER_COUNTER_REPLICAS;
     return 0;
 }
 
@@ -194,13 +198,27 @@ template <typename F> static int dispatch_modes(mer_context *ctx, const mer_scen
         return f(std::integral_constant<bool, false>(), std::integral_constant<int, MER_RIF_TRILINEAR>(),
                  std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_HOMOGENEOUS>());
     }
+    // internal fetch kind of the trilinear RIF (mer_device.hpp): layout x {global, buffer} loads
+    int rifk = sc->rif_mode;
+    if (sc->rif_mode == MER_RIF_TRILINEAR) {
+        const Volume &rv = ctx->volumes.find(sc->rif)->second;
+        DGrid tmp; fill_dgrid(rv, tmp);
+        if (tmp.layout == MER_LAYOUT_CELL8) rifk = tmp.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
+        else rifk = tmp.buf_bytes ? RIFK_DENSE_BUF : MER_RIF_TRILINEAR;
+    }
 #define MER_CASE(R, S, G)                                                                                         \
-    if (sc->rif_mode == R && sc->stepper == S && (int) grid == G)                                                 \
+    if (rifk == R && sc->stepper == S && (int) grid == G)                                                         \
         return f(std::integral_constant<bool, true>(), std::integral_constant<int, R>(), std::integral_constant<int, S>(), \
                  std::integral_constant<int, G>());
     MER_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET, 1) MER_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4, 1)
+    MER_CASE(RIFK_DENSE_BUF, MER_STEP_VERLET, 1) MER_CASE(RIFK_DENSE_BUF, MER_STEP_RK4, 1)
+    MER_CASE(RIFK_CELL8, MER_STEP_VERLET, 1) MER_CASE(RIFK_CELL8, MER_STEP_RK4, 1)
+    MER_CASE(RIFK_CELL8_BUF, MER_STEP_VERLET, 1) MER_CASE(RIFK_CELL8_BUF, MER_STEP_RK4, 1)
     MER_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET, 1) MER_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4, 1)
     MER_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET, 0) MER_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4, 0)
+    MER_CASE(RIFK_DENSE_BUF, MER_STEP_VERLET, 0) MER_CASE(RIFK_DENSE_BUF, MER_STEP_RK4, 0)
+    MER_CASE(RIFK_CELL8, MER_STEP_VERLET, 0) MER_CASE(RIFK_CELL8, MER_STEP_RK4, 0)
+    MER_CASE(RIFK_CELL8_BUF, MER_STEP_VERLET, 0) MER_CASE(RIFK_CELL8_BUF, MER_STEP_RK4, 0)
     MER_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET, 0) MER_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4, 0)
 #undef MER_CASE
     return fail(ctx, "unsupported rif_mode / stepper combination");
@@ -245,8 +263,8 @@ int mer_context_create(int32_t device_id, mer_context **out) {
     if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess) {
         g_create_error = "mer_context_create: hipSetDevice failed"; delete ctx; return 1;
     }
-    if (hipMalloc((void **) &ctx->counters, sizeof(unsigned long long) * (MER_C_COUNT + 8)) != hipSuccess ||
-        hipMemset(ctx->counters, 0, sizeof(unsigned long long) * (MER_C_COUNT + 8)) != hipSuccess ||
+    if (hipMalloc((void **) &ctx->counters, sizeof(unsigned long long) * (MER_C_COUNT * MER_COUNTER_REPLICAS + 8)) != hipSuccess ||
+        hipMemset(ctx->counters, 0, sizeof(unsigned long long) * (MER_C_COUNT * MER_COUNTER_REPLICAS + 8)) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         g_create_error = "mer_context_create: device allocation failed"; delete ctx; return 1;
     }
@@ -267,6 +285,8 @@ void mer_context_destroy(mer_context *ctx) {
     if (ctx->live) (void) hipFree(ctx->live);
     if (ctx->queue) (void) hipFree(ctx->queue);
     if (ctx->qcount) (void) hipFree(ctx->qcount);
+    if (ctx->mqueue) (void) hipFree(ctx->mqueue);
+    if (ctx->mcount) (void) hipFree(ctx->mcount);
     if (ctx->host_live) (void) hipHostFree(ctx->host_live);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
@@ -450,31 +470,36 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     if (ctx->nslots != want) {
         if (ctx->slots) (void) hipFree(ctx->slots);
         if (ctx->queue) (void) hipFree(ctx->queue);
-        ctx->slots = nullptr; ctx->queue = nullptr; ctx->nslots = 0;
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->slots, (size_t) want * SLOT_WORDS * sizeof(uint32_t)));
+        if (ctx->mqueue) (void) hipFree(ctx->mqueue);
+        ctx->slots = nullptr; ctx->queue = nullptr; ctx->mqueue = nullptr; ctx->nslots = 0;
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->slots, (size_t) want * MER_SLOT_WORDS * sizeof(uint32_t)));
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->queue, (size_t) want * sizeof(uint32_t)));
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->mqueue, (size_t) want * 2 * sizeof(uint32_t)));
         ctx->nslots = want;
     }
     if (!ctx->live) {
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->live, MER_LIVE_SLOTS * sizeof(uint32_t)));
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->qcount, MER_LIVE_SLOTS * sizeof(uint32_t)));
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->mcount, MER_LIVE_SLOTS * sizeof(uint32_t)));
         HIP_CHECK(ctx, hipHostMalloc((void **) &ctx->host_live, sizeof(uint32_t)));
     }
     uint32_t nslots = ctx->nslots;
     const uint64_t need_slots = (P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
     if (need_slots < nslots) nslots = (uint32_t) need_slots;
-    P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.queue = ctx->queue; P.qcount = ctx->qcount;
+    P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.queue = ctx->queue; P.qcount = ctx->qcount; P.mqueue = ctx->mqueue; P.mcount = ctx->mcount;
     P.ksteps = 32;
     { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) P.ksteps = atoi(e); }
-    HIP_CHECK(ctx, hipMemsetAsync(ctx->slots + (size_t) H_FLAGS * nslots, 0, (size_t) nslots * sizeof(uint32_t), ctx->stream));
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->slots, 0, (size_t) nslots * MER_SLOT_WORDS * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->qcount, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->mcount, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
     return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
         auto kev = event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
         auto kma = march_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
         const unsigned blocks = nslots / MER_BLOCK;
         HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         const uint32_t check_every = 8;
+        const int k0 = P.ksteps; const bool adaptive = getenv("MER_FIXED_K") == nullptr;
         uint32_t pass = 0;
         for (;;) {
             hipLaunchKernelGGL(kev, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
@@ -485,6 +510,10 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
                 HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_live, ctx->live, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
                 HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
                 if (*ctx->host_live >= nslots) break;
+                if (adaptive) {          // tail: few lanes left => longer passes, fewer launches
+                    const uint32_t alive = nslots - *ctx->host_live;
+                    P.ksteps = alive < nslots / 64 ? k0 * 32 : (alive < nslots / 16 ? k0 * 8 : (alive < nslots / 4 ? k0 * 2 : k0));
+                }
                 if (pass > (1u << 24)) return fail(ctx, "mer_render: pass limit exceeded");
             }
         }
@@ -522,11 +551,16 @@ int mer_last_kernel_ms(mer_context *ctx, float *ms) {
 
 int mer_counters_read(mer_context *ctx, uint64_t out[MER_C_COUNT]) {
     HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_CHECK(ctx, hipMemcpy(out, ctx->counters, sizeof(uint64_t) * MER_C_COUNT, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> all((size_t) MER_C_COUNT * MER_COUNTER_REPLICAS);
+    HIP_CHECK(ctx, hipMemcpy(all.data(), ctx->counters, sizeof(uint64_t) * all.size(), hipMemcpyDeviceToHost));
+    for (int k = 0; k < MER_C_COUNT; k++) {
+        out[k] = 0;
+        for (int r = 0; r < MER_COUNTER_REPLICAS; r++) out[k] += all[(size_t) r * MER_C_COUNT + k];
+    }
     return 0;
 }
 int mer_counters_reset(mer_context *ctx) {
-    HIP_CHECK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(uint64_t) * MER_C_COUNT, ctx->stream));
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(uint64_t) * MER_C_COUNT * MER_COUNTER_REPLICAS, ctx->stream));
     return 0;
 }
 
@@ -580,11 +614,19 @@ int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0,
     DevBuf a(ctx), b(ctx), c(ctx), op(ctx), ov(ctx), od(ctx), oo(ctx), ok(ctx);
     if (a.upload(p0, n * 12) || b.upload(d0, n * 12) || c.upload(dist, n * 4) || op.alloc(n * 12) || ov.alloc(n * 12) ||
         od.alloc(n * 4) || oo.alloc(n * 4) || ok.alloc(n * 4)) return 1;
+    int rifk = scene->rif_mode;
+    if (scene->rif_mode == MER_RIF_TRILINEAR) {
+        if (P.rif.layout == MER_LAYOUT_CELL8) rifk = P.rif.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
+        else rifk = P.rif.buf_bytes ? RIFK_DENSE_BUF : MER_RIF_TRILINEAR;
+    }
 #define MER_TRACE_CASE(R, S)                                                                                       \
-    if (scene->rif_mode == R && scene->stepper == S)                                                               \
+    if (rifk == R && scene->stepper == S)                                                                          \
         hipLaunchKernelGGL((er_trace_kernel<R, S>), dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), \
                            c.as<float>(), n, op.as<float>(), ov.as<float>(), od.as<float>(), oo.as<float>(), ok.as<int32_t>());
     MER_TRACE_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET) MER_TRACE_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4)
+    MER_TRACE_CASE(RIFK_DENSE_BUF, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_DENSE_BUF, MER_STEP_RK4)
+    MER_TRACE_CASE(RIFK_CELL8, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_CELL8, MER_STEP_RK4)
+    MER_TRACE_CASE(RIFK_CELL8_BUF, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_CELL8_BUF, MER_STEP_RK4)
     MER_TRACE_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET) MER_TRACE_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4)
 #undef MER_TRACE_CASE
     HIP_CHECK(ctx, hipGetLastError());

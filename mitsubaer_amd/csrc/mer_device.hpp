@@ -71,6 +71,7 @@ struct DGrid {
     float   s[3], t[3];       // worldToGrid diagonal + translation (gridvolume.cpp:188-195, toWorld = identity)
     float   bmin[3], bmax[3];
     float   lim_min[3], lim_max[3];   // spline interpolatable limits (splinevolume.cpp:280-281)
+    uint32_t buf_bytes;               // byte size of data / cell8 when it fits a buffer descriptor (< 4 GiB), else 0
 };
 
 // include/mitsuba/core/aabb.h:308-339 (dRcp = 1/d as Ray::setDirection)
@@ -159,6 +160,18 @@ struct CellCache {
     __device__ __forceinline__ void reset() { cell = -1; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f; }
 };
 
+// Internal fetch kinds of the trilinear RIF (template parameter RIF of the kernels):
+//   MER_RIF_TRILINEAR (1): dense grid, global loads (any size)      RIFK_DENSE_BUF (3): dense grid, buffer loads
+//   RIFK_CELL8 (4): cell-major grid, global loads                   RIFK_CELL8_BUF (5): cell-major, buffer loads
+// Buffer loads take a 32-bit byte offset against a wave-uniform descriptor: one VGPR of address arithmetic per
+// fetch instead of eight 64-bit adds, and the +row / +slice strides ride in the scalar offset operand.
+#define RIFK_DENSE_BUF 3
+#define RIFK_CELL8 4
+#define RIFK_CELL8_BUF 5
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int RIFK>
 __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &cc, f3 p, float &val, f3 &grad) {
     const float px = __builtin_fmaf(g.s[0], p.x, g.t[0]), py = __builtin_fmaf(g.s[1], p.y, g.t[1]), pz = __builtin_fmaf(g.s[2], p.z, g.t[2]);
     int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
@@ -167,11 +180,29 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
     const int base = (z1 * g.res[1] + y1) * g.res[0] + x1;
     if (base != cc.cell) {
         cc.cell = base;
-        if (g.layout == MER_LAYOUT_CELL8) {
+        if (RIFK == RIFK_CELL8 || RIFK == RIFK_CELL8_BUF) {
             const int cell = (z1 * (g.res[1] - 1) + y1) * (g.res[0] - 1) + x1;
-            const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
-            const float4 a = c[0], b = c[1];
+            float4 a, b;
+            if (RIFK == RIFK_CELL8_BUF) {
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
+                const u32x4 ua = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cell * 32, 0, 0);
+                const u32x4 ub = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cell * 32 + 16, 0, 0);
+                a = make_float4(__uint_as_float(ua.x), __uint_as_float(ua.y), __uint_as_float(ua.z), __uint_as_float(ua.w));
+                b = make_float4(__uint_as_float(ub.x), __uint_as_float(ub.y), __uint_as_float(ub.z), __uint_as_float(ub.w));
+            } else {
+                const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
+                a = c[0]; b = c[1];
+            }
             cc.d000 = a.x; cc.d001 = a.y; cc.d010 = a.z; cc.d011 = a.w; cc.d100 = b.x; cc.d101 = b.y; cc.d110 = b.z; cc.d111 = b.w;
+        } else if (RIFK == RIFK_DENSE_BUF) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.data, 0, (int) g.buf_bytes, 0x00020000);
+            const int sy4 = g.res[0] * 4, sz4 = g.res[0] * g.res[1] * 4;
+            const u32x2 r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, 0, 0);
+            const u32x2 r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sy4, 0);
+            const u32x2 r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sz4, 0);
+            const u32x2 r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sz4 + sy4, 0);
+            cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
+            cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
         } else {
             const float *D = (const float *) g.data;
             const int sy = g.res[0], sz = g.res[0] * g.res[1];
@@ -246,7 +277,7 @@ __device__ __forceinline__ bool inside_volume_limits(const DGrid &g, f3 p) {   /
 }
 
 template <int RIF> __device__ __forceinline__ void rif_value_grad(const DGrid &g, CellCache &cc, f3 p, float &n, f3 &gr) {
-    if (RIF == MER_RIF_TRILINEAR) trilinear_value_grad(g, cc, p, n, gr);
+    if (RIF != MER_RIF_BSPLINE3) trilinear_value_grad<RIF>(g, cc, p, n, gr);
     else bspline_value_grad(g, p, n, gr);
 }
 
@@ -361,6 +392,7 @@ struct Params {
     uint32_t *slots; uint32_t nslots; int32_t ksteps;
     uint32_t *live;                     // live[0]: number of finished slots
     uint32_t *queue, *qcount;           // event queue (slot indices) and its length per pass (ring of MER_LIVE_SLOTS)
+    uint32_t *mqueue, *mcount;          // march lists (double-buffered by pass parity) and their lengths
 };
 #define MER_LIVE_SLOTS 4096
 

@@ -15,7 +15,7 @@ namespace mer {
 
 // hot words (K_march reads/writes these)
 enum { H_PX = 0, H_PY, H_PZ, H_VX, H_VY, H_VZ, H_OPT, H_DIST, H_REM, H_HPREV, H_TR, H_T, H_TMAX, H_STEPS, H_FLAGS,
-       H_RNG_LO, H_RNG_HI, H_PIXEL, H_SAMPLE, H_SIGMA, H_COUNT };
+       H_RNG_LO, H_RNG_HI, H_PIXEL, H_SAMPLE, H_SIGMA, H_COUNT };   // record order of load_hot / store_hot
 // cold words (K_event only)
 enum { CO_PXF = H_COUNT, CO_PYF, CO_LX, CO_LY, CO_LZ, CO_TX, CO_TY, CO_TZ, CO_DEPTH, CO_PFLAGS, CO_PSX, CO_PSY, CO_PSZ,
        CO_DSX, CO_DSY, CO_DSZ, CO_DDX, CO_DDY, CO_DDZ, CO_WIX, CO_WIY, CO_WIZ, CO_PHASEPDF, CO_ITST, CO_N0, CO_TRSUM,
@@ -27,41 +27,85 @@ __device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg
            ((uint32_t) walk << 10);
 }
 
-#define SLOT(k) P.slots[(size_t) (k) * P.nslots + i]
+// Slot i is one 256-byte record: words [0,20) hot, [20,48) cold, rest padding.  Lanes reach their slot through the
+// compacted march / event lists, i.e. by gather: a record-per-slot layout turns each lane's state access into a few
+// whole 16-byte pieces of two cache lines instead of 20-48 scattered dwords of a struct-of-arrays.
+#define MER_SLOT_WORDS 64
+#define SLOT(k) P.slots[(size_t) i * MER_SLOT_WORDS + (k)]
 #define SLOTF(k) __uint_as_float(SLOT(k))
 
 template <class WalkT>
-__device__ __forceinline__ void load_hot(const Params &P, uint32_t i, uint32_t fl, WalkT &W, Rng &rng, uint32_t &pixel, uint32_t &sample) {
-    W.p = f3(SLOTF(H_PX), SLOTF(H_PY), SLOTF(H_PZ));
-    W.v = f3(SLOTF(H_VX), SLOTF(H_VY), SLOTF(H_VZ));
-    W.opt = SLOTF(H_OPT); W.dist = SLOTF(H_DIST); W.rem = SLOTF(H_REM); W.hprev = SLOTF(H_HPREV); W.Tr = SLOTF(H_TR);
-    W.t = SLOTF(H_T); W.tmax = SLOTF(H_TMAX); W.steps_left = (int) SLOT(H_STEPS);
+__device__ __forceinline__ void load_hot(const Params &P, uint32_t i, uint32_t &fl, WalkT &W, Rng &rng, uint32_t &pixel, uint32_t &sample, float &sigma) {
+    const uint4 *r = (const uint4 *) (P.slots + (size_t) i * MER_SLOT_WORDS);
+    const uint4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4];
+    W.p = f3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+    W.v = f3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+    W.opt = __uint_as_float(b.z); W.dist = __uint_as_float(b.w);
+    W.rem = __uint_as_float(c.x); W.hprev = __uint_as_float(c.y); W.Tr = __uint_as_float(c.z); W.t = __uint_as_float(c.w);
+    W.tmax = __uint_as_float(d.x); W.steps_left = (int) d.y; fl = d.z;
+    rng.state = (uint64_t) d.w | ((uint64_t) e.x << 32);
+    pixel = e.y; sample = e.z; sigma = __uint_as_float(e.w);
     W.kind = (fl >> 6) & 3; W.seg_inf = (fl >> 8) & 1; W.backstep = (fl >> 9) & 1; W.walk = (fl >> 10) & 3;
-    pixel = SLOT(H_PIXEL); sample = SLOT(H_SAMPLE);
-    rng.state = (uint64_t) SLOT(H_RNG_LO) | ((uint64_t) SLOT(H_RNG_HI) << 32);
     rng.inc = (((((uint64_t) sample) << 32) | (uint64_t) pixel) << 1) | 1ULL;
 }
 template <class WalkT>
-__device__ __forceinline__ void store_hot(const Params &P, uint32_t i, int st, int ev, const WalkT &W, const Rng &rng, float sigma) {
-    SLOT(H_PX) = __float_as_uint(W.p.x); SLOT(H_PY) = __float_as_uint(W.p.y); SLOT(H_PZ) = __float_as_uint(W.p.z);
-    SLOT(H_VX) = __float_as_uint(W.v.x); SLOT(H_VY) = __float_as_uint(W.v.y); SLOT(H_VZ) = __float_as_uint(W.v.z);
-    SLOT(H_OPT) = __float_as_uint(W.opt); SLOT(H_DIST) = __float_as_uint(W.dist); SLOT(H_REM) = __float_as_uint(W.rem);
-    SLOT(H_HPREV) = __float_as_uint(W.hprev); SLOT(H_TR) = __float_as_uint(W.Tr); SLOT(H_T) = __float_as_uint(W.t);
-    SLOT(H_TMAX) = __float_as_uint(W.tmax); SLOT(H_STEPS) = (uint32_t) W.steps_left;
-    SLOT(H_FLAGS) = pack_flags(st, ev, W.kind, W.seg_inf, W.backstep, W.walk);
-    SLOT(H_RNG_LO) = (uint32_t) rng.state; SLOT(H_RNG_HI) = (uint32_t) (rng.state >> 32);
-    SLOT(H_SIGMA) = __float_as_uint(sigma);
+__device__ __forceinline__ void store_hot(const Params &P, uint32_t i, int st, int ev, const WalkT &W, const Rng &rng,
+                                          uint32_t pixel, uint32_t sample, float sigma) {
+    uint4 *r = (uint4 *) (P.slots + (size_t) i * MER_SLOT_WORDS);
+    r[0] = make_uint4(__float_as_uint(W.p.x), __float_as_uint(W.p.y), __float_as_uint(W.p.z), __float_as_uint(W.v.x));
+    r[1] = make_uint4(__float_as_uint(W.v.y), __float_as_uint(W.v.z), __float_as_uint(W.opt), __float_as_uint(W.dist));
+    r[2] = make_uint4(__float_as_uint(W.rem), __float_as_uint(W.hprev), __float_as_uint(W.Tr), __float_as_uint(W.t));
+    r[3] = make_uint4(__float_as_uint(W.tmax), (uint32_t) W.steps_left, pack_flags(st, ev, W.kind, W.seg_inf, W.backstep, W.walk),
+                      (uint32_t) rng.state);
+    r[4] = make_uint4((uint32_t) (rng.state >> 32), pixel, sample, __float_as_uint(sigma));
 }
 
+// Counter flush: one set of atomics per BLOCK, spread over MER_COUNTER_REPLICAS copies (summed on the host), so
+// that a pass of thousands of blocks does not serialise on nine addresses (one word sustains ~88 atomics/us).
+#define MER_COUNTER_REPLICAS 64
 __device__ __forceinline__ void flush_counters(const Params &P, const LaneCounters &C, uint32_t lane_slots) {
-    const uint32_t sums[8] = {wave_sum(C.paths), wave_sum(C.steps), wave_sum(C.rif_evals), wave_sum(C.tentative),
-                              wave_sum(C.real), wave_sum(C.segments), wave_sum(C.nee), wave_sum(C.marched)};
-    const uint32_t slots = wave_sum(lane_slots);
-    if ((threadIdx.x & 63) == 0) {
+    __shared__ uint32_t sh[MER_BLOCK / 64][9];
+    const uint32_t sums[9] = {wave_sum(C.paths), wave_sum(C.steps), wave_sum(C.rif_evals), wave_sum(C.tentative),
+                              wave_sum(C.real), wave_sum(C.segments), wave_sum(C.nee), wave_sum(C.marched), wave_sum(lane_slots)};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 7; k++) if (sums[k]) atomicAdd(P.counters + k, (unsigned long long) sums[k]);
-        if (slots) atomicAdd(P.counters + MER_C_LOOP_ITERS, (unsigned long long) slots);
-        if (sums[7]) atomicAdd(P.counters + MER_C_ACTIVE_LANES, (unsigned long long) sums[7]);
+        for (int k = 0; k < 9; k++) sh[wave][k] = sums[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < MER_BLOCK / 64; w++) tot += sh[w][threadIdx.x];
+        if (tot) {
+            const int k = threadIdx.x;
+            const int dst = k < 7 ? k : (k == 7 ? MER_C_ACTIVE_LANES : MER_C_LOOP_ITERS);
+            atomicAdd(P.counters + (size_t) (blockIdx.x % MER_COUNTER_REPLICAS) * MER_C_COUNT + dst, (unsigned long long) tot);
+        }
+    }
+}
+
+// Block-aggregated append of slot index i to a queue: one atomic per block.  Must be reached by every thread of the
+// block (it contains barriers).
+__device__ __forceinline__ void queue_push(uint32_t *queue, uint32_t *count, bool pred, uint32_t i) {
+    __shared__ uint32_t wcount[MER_BLOCK / 64];
+    __shared__ uint32_t bbase;
+    const unsigned long long mask = __ballot(pred);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();                                   // protects wcount / bbase against the previous push
+    if (lane == 0) wcount[wave] = (uint32_t) __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < MER_BLOCK / 64; w++) tot += wcount[w];
+        bbase = tot ? atomicAdd(count, tot) : 0u;
+    }
+    __syncthreads();
+    if (pred) {
+        uint32_t off = bbase;
+        for (int w = 0; w < wave; w++) off += wcount[w];
+        queue[off + (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL))] = i;
     }
 }
 
@@ -70,18 +114,21 @@ __device__ __forceinline__ void flush_counters(const Params &P, const LaneCounte
 // delta-tracking loop (heterogeneous.cpp:633-656, :562-585) for whichever ray the lane is on.
 template <bool CURVED, int RIF, int STEPPER, int SIGMA>
 __global__ void __launch_bounds__(MER_BLOCK) march_kernel(const Params P, uint32_t pass) {
-    const uint32_t i = blockIdx.x * MER_BLOCK + threadIdx.x;
-    if (i >= P.nslots) return;
-    const uint32_t fl = SLOT(H_FLAGS);
+    const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
+    if (j >= P.nslots) return;
+    // sweep the compacted list of marching slots: dense waves in the steady state and in the tail alike
+    const uint32_t count = P.mcount[pass & (MER_LIVE_SLOTS - 1)];
     LaneCounters C; C.clear();
-    uint32_t iters = 0;
-    bool has_event = false;
-    if ((fl & 3u) == ST_MARCH && ((fl >> 2) & 15u) == EV_NONE) {
+    uint32_t iters = 0, i = 0;
+    bool has_event = false, still_marching = false;
+    if (j < count) {
+        i = P.mqueue[(size_t) (pass & 1u) * P.nslots + j];
+        uint32_t fl;
         Walk<CURVED, RIF, STEPPER, SIGMA> W;
-        Rng rng; uint32_t pixel, sample;
-        load_hot(P, i, fl, W, rng, pixel, sample);
+        Rng rng; uint32_t pixel, sample; float sigma;
+        load_hot(P, i, fl, W, rng, pixel, sample, sigma);
         W.cc.reset(); W.n0 = 1.0f; W.tmin = 0.0f; W.trsum = 0.0f; W.sdens = 0.0f;
-        int ev = EV_NONE; float sigma = 0.0f;
+        int ev = EV_NONE; sigma = 0.0f;
         const int K = P.ksteps;
         for (int k = 0; k < K; ++k) {
             ev = W.advance(P, rng, C);
@@ -89,21 +136,13 @@ __global__ void __launch_bounds__(MER_BLOCK) march_kernel(const Params P, uint32
             iters++;
             if (ev != EV_NONE) break;
         }
-        store_hot(P, i, ST_MARCH, ev, W, rng, sigma);
+        store_hot(P, i, ST_MARCH, ev, W, rng, pixel, sample, sigma);
         has_event = ev != EV_NONE;
+        still_marching = !has_event;
     }
-    // compaction: lanes parked on an event append their slot to the queue K_event will sweep (wave-aggregated)
-    {
-        const unsigned long long mask = __ballot(has_event);
-        if (mask) {
-            const int lane = threadIdx.x & 63;
-            const int leader = __ffsll((long long) mask) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(P.qcount + ((pass + 1) & (MER_LIVE_SLOTS - 1)), (uint32_t) __popcll(mask));
-            base = (uint32_t) __shfl((int) base, leader, 64);
-            if (has_event) P.queue[base + (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL))] = i;
-        }
-    }
+    // compaction: lanes parked on an event go to K_event's queue, the others straight to the next march list
+    queue_push(P.queue, P.qcount + ((pass + 1) & (MER_LIVE_SLOTS - 1)), has_event, i);
+    queue_push(P.mqueue + (size_t) ((pass + 1) & 1u) * P.nslots, P.mcount + ((pass + 1) & (MER_LIVE_SLOTS - 1)), still_marching, i);
     // lane-slot accounting: every lane of the wave is held for as many trips as its slowest lane
     uint32_t wave_iters = iters;
 #pragma unroll
@@ -123,10 +162,11 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     if (j >= P.nslots) return;
     // pass 0: every slot is new; later passes: the compacted list of slots K_march parked on an event
     const uint32_t count = pass == 0 ? P.nslots : P.qcount[pass & (MER_LIVE_SLOTS - 1)];
-    if (j == 0) P.qcount[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0;     // ring hygiene: K_march of pass+1 adds to this entry
+    if (j == 0) { P.qcount[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0; P.mcount[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0; }   // ring hygiene
     LaneCounters C; C.clear();
+    bool marching = false; uint32_t i = 0;
     if (j < count) {
-    const uint32_t i = pass == 0 ? j : P.queue[j];
+    i = pass == 0 ? j : P.queue[j];
     const uint32_t fl = SLOT(H_FLAGS);
     int st = fl & 3u, ev = (fl >> 2) & 15u;
 
@@ -148,8 +188,8 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     f3 L(0, 0, 0), T(1, 1, 1), ps(0, 0, 0), dsave(0, 0, 1), dd(0, 0, 1), wi(0, 0, 1), trv(1, 1, 1);
     int depth = 1, flags = F_EMITTED, px_i = 0, py_i = 0;
     if (st == ST_MARCH) {
-        load_hot(P, i, fl, W, rng, pixel, sample);
-        sigma = SLOTF(H_SIGMA);
+        uint32_t fl2;
+        load_hot(P, i, fl2, W, rng, pixel, sample, sigma);
         px = SLOTF(CO_PXF); py = SLOTF(CO_PYF);
         L = f3(SLOTF(CO_LX), SLOTF(CO_LY), SLOTF(CO_LZ)); T = f3(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ));
         depth = (int) SLOT(CO_DEPTH); flags = (int) SLOT(CO_PFLAGS);
@@ -337,8 +377,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     // ---- park the lane
     if (st == ST_DONE) { SLOT(H_FLAGS) = ST_DONE; atomicAdd(P.live, 1u); }      // live[0] counts finished slots
     else {
-        store_hot(P, i, ST_MARCH, EV_NONE, W, rng, 0.0f);
-        SLOT(H_PIXEL) = pixel; SLOT(H_SAMPLE) = sample;
+        store_hot(P, i, ST_MARCH, EV_NONE, W, rng, pixel, sample, 0.0f);
         SLOT(CO_PXF) = __float_as_uint(px); SLOT(CO_PYF) = __float_as_uint(py);
         SLOT(CO_LX) = __float_as_uint(L.x); SLOT(CO_LY) = __float_as_uint(L.y); SLOT(CO_LZ) = __float_as_uint(L.z);
         SLOT(CO_TX) = __float_as_uint(T.x); SLOT(CO_TY) = __float_as_uint(T.y); SLOT(CO_TZ) = __float_as_uint(T.z);
@@ -350,8 +389,10 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
         SLOT(CO_PHASEPDF) = __float_as_uint(phasePdf); SLOT(CO_ITST) = __float_as_uint(itsT);
         SLOT(CO_N0) = __float_as_uint(W.n0); SLOT(CO_TRSUM) = __float_as_uint(W.trsum);
         SLOT(CO_SDENS) = __float_as_uint(W.sdens); SLOT(CO_TMIN) = __float_as_uint(W.tmin);
+        marching = true;
     }
     }   // j < count
+    queue_push(P.mqueue + (size_t) (pass & 1u) * P.nslots, P.mcount + (pass & (MER_LIVE_SLOTS - 1)), marching, i);
     flush_counters(P, C, 0);
 }
 
