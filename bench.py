@@ -53,17 +53,28 @@ def algorithmic_bytes(c, p):
         + 40.0 * float(c[capi.C_PATHS])
 
 
+def host_cores():
+    """Threads the CPU baseline may use: the affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(p, target_seconds=20.0):
     """The CPU oracle (kind 'port': the restatement of the reference's routines) on a bounded sample of the same
     workload: whole image, few spp, all host cores."""
     from oracle import orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     orc.build()
     t0 = time.time()
-    orc.render(p, 0, 1, 0, nthreads=cores, rows=(p.height // 2 - 8, p.height // 2 + 8))      # calibration: 16 rows
-    dt = max(time.time() - t0, 1e-3)
-    per_spp = dt * p.height / 16.0
-    spp = int(max(1, min(16, target_seconds / per_spp)))
+    orc.render(p, 0, 1, 0, nthreads=cores)                                # calibration: one sample per pixel
+    per_spp = max(time.time() - t0, 1e-3)
+    spp = int(max(1, min(64, round(target_seconds / per_spp))))
     t0 = time.time()
     _, c = orc.render(p, 0, spp, 0, nthreads=cores)
     dt = time.time() - t0
@@ -81,7 +92,7 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--layout", default="dense", choices=["dense", "cell8"])
+    ap.add_argument("--layout", default="cell8", choices=["dense", "cell8"])
     ap.add_argument("--shard", default="samples", choices=["samples", "tiles"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -125,13 +136,15 @@ def main():
         step(1000 + i)
     barrier()
     ctx.counters_reset()
-    kernel_ms = []
+    kernel_ms = []; march_ms = []; event_ms = []; passes = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
         # HIP events recorded by libmer around the render kernel on the launch stream; reading them waits for
         # this step's kernel only (steps are dependent through the film anyway)
         kernel_ms.append(ctx.last_kernel_ms())
+        n_, m_, e_ = ctx.last_render_stats()
+        passes.append(n_); march_ms.append(m_); event_ms.append(e_)
     barrier()
     elapsed = time.perf_counter() - t0
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -145,9 +158,15 @@ def main():
     total_paths = float(ct[capi.C_PATHS].item())
 
     if rank == 0:
-        k_ms = float(np.mean(kernel_ms))
-        b_alg = algorithmic_bytes(counters, p) / max(args.steps, 1)      # per launch, this rank
-        achieved = b_alg / (k_ms * 1e-3) / 1e9
+        k_ms = float(np.mean(kernel_ms))                                  # whole render (all wavefront passes)
+        m_ms = float(np.mean(march_ms)); e_ms = float(np.mean(event_ms)); n_pass = float(np.mean(passes))
+        b_alg = algorithmic_bytes(counters, p) / max(args.steps, 1)      # per step (one full render), this rank
+        # the dominant kernel is K_march: it performs every field fetch; the film write (40 B/path) is K_event's
+        b_march = (b_alg - 40.0 * paths_rank / max(args.steps, 1))
+        per_launch_bytes = b_march / max(n_pass, 1.0)
+        per_launch_ms = m_ms / max(n_pass, 1.0)
+        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+        achieved_step = b_alg / (k_ms * 1e-3) / 1e9
         lane_eff = float(counters[capi.C_ACTIVE_LANES] / max(counters[capi.C_LOOP_ITERS], 1.0))
         name, cus, hbm = ctx.device_info()
         out = {
@@ -161,8 +180,10 @@ def main():
                        "stepsize": p.stepsize, "estimator": "volpath + delta tracking on eikonal rays, ratio-tracking NEE",
                        "device": name, "cus": cus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "render_kernel<curved,trilinear,rk4,grid>", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": b_alg,
+                         "traffic": None, "kernel": "mer::march_kernel<curved, cell8/buffer trilinear, rk4, grid>",
+                         "kernel_avg_launch_ms": per_launch_ms, "launches_per_step": n_pass, "algorithmic_bytes_per_launch": per_launch_bytes,
+                         "kernel_ms_per_step": m_ms, "event_kernel_ms_per_step": e_ms,
+                         "whole_step": {"ms": k_ms, "algorithmic_bytes": b_alg, "achieved": achieved_step, "frac": achieved_step / HBM_PEAK_GBS},
                          "counters_per_launch": {"paths": paths_rank / args.steps, "steps": counters[capi.C_STEPS] / args.steps,
                                                  "tentative": counters[capi.C_TENTATIVE] / args.steps, "real": counters[capi.C_REAL] / args.steps},
                          "active_lane_fraction": lane_eff},

@@ -120,12 +120,15 @@ int  mer_film_free(mer_context *ctx, float *film_dev);
 
 /* ---- the hot path: replaces SamplingIntegrator::render -> renderBlock -> Li -> ImageBlock::put
         (src/librender/integrator.cpp:95-188, src/integrators/path/volpath.cpp:84-343).
-        Accumulates (R,G,B,alpha,weight) splats into film_dev.  Asynchronous on the context stream. ---- */
+        Accumulates (R,G,B,alpha,weight) splats into film_dev.  Launches on the context stream; returns when the
+        last wavefront pass has been issued and found no live path (it synchronises the stream internally). ---- */
 int  mer_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard,
                 uint64_t seed, float *film_dev);
 int  mer_synchronize(mer_context *ctx);
 /* HIP-event time of the last mer_render kernel in ms (synchronizes) */
 int  mer_last_kernel_ms(mer_context *ctx, float *ms);
+/* wavefront passes of the last mer_render and the summed HIP-event device time of its K_march / K_event launches */
+int  mer_last_render_stats(mer_context *ctx, int32_t *passes, float *march_ms, float *event_ms);
 int  mer_counters_read(mer_context *ctx, uint64_t out[MER_C_COUNT]);    /* StatsCounter analogue */
 int  mer_counters_reset(mer_context *ctx);
 

@@ -6,7 +6,7 @@ import numpy as np
 from . import params as P
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmer.so")
+LIB_PATH = os.environ.get("MER_LIB", os.path.join(_HERE, "libmer.so"))
 _LIB = None
 
 C_PATHS, C_STEPS, C_RIF_EVALS, C_TENTATIVE, C_REAL, C_SEGMENTS, C_NEE, C_LOOP_ITERS, C_ACTIVE_LANES = range(9)
@@ -18,7 +18,7 @@ SYMBOLS = [
     "mer_abi_version", "mer_context_create", "mer_context_destroy", "mer_last_error", "mer_context_set_stream",
     "mer_device_info", "mer_volume_upload", "mer_volume_upload_dev", "mer_volume_build_spline",
     "mer_volume_download_spline", "mer_volume_destroy", "mer_film_alloc", "mer_film_zero", "mer_film_download",
-    "mer_film_free", "mer_render", "mer_synchronize", "mer_last_kernel_ms", "mer_counters_read",
+    "mer_film_free", "mer_render", "mer_synchronize", "mer_last_kernel_ms", "mer_last_render_stats", "mer_counters_read",
     "mer_counters_reset", "mer_lookup_trilinear", "mer_lookup_trilinear_rgb", "mer_rif_value_grad", "mer_er_trace",
     "mer_sample_distance", "mer_eval_transmittance", "mer_phase_sample", "mer_phase_eval", "mer_camera_rays",
     "mer_render_paths", "mer_rng_floats", "mer_synth_field_dev", "mer_device_free",
@@ -258,6 +258,11 @@ class Context:
         ms = C.c_float()
         self._check(lib().mer_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
+
+    def last_render_stats(self):
+        n = C.c_int32(); a = C.c_float(); b = C.c_float()
+        self._check(lib().mer_last_render_stats(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value, b.value
 
     def counters(self):
         out = np.zeros(C_COUNT, np.uint64)

@@ -41,6 +41,8 @@ struct mer_context {
     uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
     uint32_t *queue = nullptr, *qcount = nullptr, *mqueue = nullptr, *mcount = nullptr;
     int last_passes = 0;
+    float last_march_ms = 0, last_event_ms = 0;
+    std::vector<hipEvent_t> pass_events;          // 3 per pass: before K_event, between, after K_march
 };
 
 #define HIP_CHECK(ctx, call)                                                                              \
@@ -290,6 +292,7 @@ void mer_context_destroy(mer_context *ctx) {
     if (ctx->host_live) (void) hipHostFree(ctx->host_live);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->pass_events) (void) hipEventDestroy(e);
     delete ctx;
 }
 
@@ -464,7 +467,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         });
     }
     // ---- wavefront: K_event / K_march passes over the path-state slots until no lane is alive
-    uint32_t want = (uint32_t) ctx->prop.multiProcessorCount * 2048u * 2u;          // 2 x the resident lanes of the chip
+    uint32_t want = (uint32_t) ctx->prop.multiProcessorCount * 2048u * 4u;          // 4 x the resident lanes of the chip
     { const char *e = getenv("MER_NSLOTS"); if (e && atoi(e) > 0) want = (uint32_t) atoi(e); }
     want = (want + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
     if (ctx->nslots != want) {
@@ -487,7 +490,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     const uint64_t need_slots = (P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
     if (need_slots < nslots) nslots = (uint32_t) need_slots;
     P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.queue = ctx->queue; P.qcount = ctx->qcount; P.mqueue = ctx->mqueue; P.mcount = ctx->mcount;
-    P.ksteps = 32;
+    P.ksteps = 64;
     { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) P.ksteps = atoi(e); }
     HIP_CHECK(ctx, hipMemsetAsync(ctx->slots, 0, (size_t) nslots * MER_SLOT_WORDS * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
@@ -502,8 +505,14 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         const int k0 = P.ksteps; const bool adaptive = getenv("MER_FIXED_K") == nullptr;
         uint32_t pass = 0;
         for (;;) {
+            while (ctx->pass_events.size() < (size_t) (pass + 1) * 3) {
+                hipEvent_t e; HIP_CHECK(ctx, hipEventCreate(&e)); ctx->pass_events.push_back(e);
+            }
+            HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 0], ctx->stream));
             hipLaunchKernelGGL(kev, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
+            HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 1], ctx->stream));
             hipLaunchKernelGGL(kma, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
+            HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 2], ctx->stream));
             pass++;
             if (pass % check_every == 0) {
                 HIP_CHECK(ctx, hipGetLastError());
@@ -519,6 +528,17 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         }
         HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         ctx->timed = true; ctx->last_passes = (int) pass;
+        {   // per-kernel device time of this render, from HIP events on the launch stream
+            HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+            double em = 0, mm = 0;
+            for (uint32_t q = 0; q < pass; q++) {
+                float a = 0, b = 0;
+                (void) hipEventElapsedTime(&a, ctx->pass_events[q * 3 + 0], ctx->pass_events[q * 3 + 1]);
+                (void) hipEventElapsedTime(&b, ctx->pass_events[q * 3 + 1], ctx->pass_events[q * 3 + 2]);
+                em += a; mm += b;
+            }
+            ctx->last_event_ms = (float) em; ctx->last_march_ms = (float) mm;
+        }
         if (getenv("MER_VERBOSE")) { float ms = 0; (void) hipEventSynchronize(ctx->ev1); (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); fprintf(stderr, "[mer] wavefront: %u passes, K=%d, nslots=%u, %.3f ms\n", pass, P.ksteps, nslots, ms); }
         return 0;
     });
@@ -546,6 +566,14 @@ int mer_last_kernel_ms(mer_context *ctx, float *ms) {
     if (!ctx->timed) return fail(ctx, "no render has been launched");
     HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
     HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
+int mer_last_render_stats(mer_context *ctx, int32_t *passes, float *march_ms, float *event_ms) {
+    if (!ctx->timed) return fail(ctx, "no render has been launched");
+    if (passes) *passes = ctx->last_passes;
+    if (march_ms) *march_ms = ctx->last_march_ms;
+    if (event_ms) *event_ms = ctx->last_event_ms;
     return 0;
 }
 

@@ -112,8 +112,11 @@ __device__ __forceinline__ void queue_push(uint32_t *queue, uint32_t *count, boo
 // ---------------------------------------------------------------------------------------------------
 // K_march: the hot loop.  trace() / traceTillBoundary (heterogeneousrefractive.cpp:671-691,742-776) and the
 // delta-tracking loop (heterogeneous.cpp:633-656, :562-585) for whichever ray the lane is on.
+#ifndef MER_MARCH_WAVES
+#define MER_MARCH_WAVES 4
+#endif
 template <bool CURVED, int RIF, int STEPPER, int SIGMA>
-__global__ void __launch_bounds__(MER_BLOCK) march_kernel(const Params P, uint32_t pass) {
+__global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const Params P, uint32_t pass) {
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
     // sweep the compacted list of marching slots: dense waves in the steady state and in the tail alike
