@@ -1,0 +1,42 @@
+// mer_render -- minimal driver over the C++ host mirror:  mer_render [-D key=value]... [-s spp] [-o out.npy] scene.xml
+// (the reference's `mitsuba` CLI, src/mitsuba/mitsuba.cpp:154-246, reduced to what the hot path needs)
+#include "mer_host.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+int main(int argc, char **argv) {
+    std::map<std::string, std::string> defines;
+    std::string out = "out.npy", scenePath;
+    int spp = 0, device = 0, layout = MER_LAYOUT_CELL8; unsigned long long seed = 0; bool raw = false;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "-D" && i + 1 < argc) { std::string kv = argv[++i]; size_t q = kv.find('='); if (q == std::string::npos) { std::fprintf(stderr, "-D expects key=value\n"); return 2; } defines[kv.substr(0, q)] = kv.substr(q + 1); }
+        else if (a.rfind("-D", 0) == 0 && a.size() > 2) { std::string kv = a.substr(2); size_t q = kv.find('='); if (q != std::string::npos) defines[kv.substr(0, q)] = kv.substr(q + 1); }
+        else if (a == "-o" && i + 1 < argc) out = argv[++i];
+        else if (a == "-s" && i + 1 < argc) spp = std::atoi(argv[++i]);
+        else if (a == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], NULL, 10);
+        else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+        else if (a == "--dense") layout = MER_LAYOUT_DENSE;
+        else if (a == "--raw") raw = true;
+        else if (a == "-h" || a == "--help") { std::printf("usage: mer_render [-D key=value]... [-s spp] [-o out.npy|out.pfm] [--raw] [--dense] [--device n] scene.xml\n"); return 0; }
+        else scenePath = a;
+    }
+    if (scenePath.empty()) { std::fprintf(stderr, "mer_render: no scene file given\n"); return 2; }
+    try {
+        auto scene = merhost::loadScene(scenePath, defines);
+        const int w = scene->sensor->film->width, h = scene->sensor->film->height;
+        std::vector<float> film = scene->integrator->render(*scene, device, spp, seed, layout);
+        if (raw) merhost::writeNpy(out, film.data(), h, w, 5);
+        else {
+            std::vector<float> rgb = merhost::develop(film, w, h);
+            if (out.size() > 4 && out.substr(out.size() - 4) == ".pfm") merhost::writePfm(out, rgb.data(), h, w);
+            else merhost::writeNpy(out, rgb.data(), h, w, 3);
+        }
+        std::printf("wrote %s (%dx%d)\n", out.c_str(), w, h);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "mer_render: %s\n", e.what());      // reference: the worker catches std::runtime_error and cancels
+        return 1;
+    }
+    return 0;
+}

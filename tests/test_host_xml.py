@@ -1,0 +1,105 @@
+"""C++ host mirror (libmer_host.so): scene-XML subset -> plugin objects -> flat scene.  Parsing and validation run on
+the CPU; the render test needs the GPU."""
+import os
+import numpy as np
+import pytest
+from mitsubaer_amd import host, params as P, synth, volio, capi
+from tests import scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SC = os.path.join(ROOT, "scenes")
+
+
+def _vols(tmp_path, N=16):
+    d = str(tmp_path / "density.vol"); r = str(tmp_path / "rif.vol")
+    volio.write_vol(d, synth.density_field(N), [-1] * 3, [1] * 3)
+    volio.write_vol(r, synth.linear_rif(N), [-1] * 3, [1] * 3)
+    return d, r
+
+
+def test_cfg1_scene_flattens_to_reference_defaults():
+    d, spp = host.flatten_xml(os.path.join(SC, "cfg1_homogeneous_box.xml"), {"samples": 16})
+    assert (d.width, d.height, spp) == (128, 128, 16)
+    assert d.sigma_mode == P.SIGMA_HOMOGENEOUS and d.phase == P.PHASE_ISOTROPIC and d.rif_mode == P.RIF_CONST
+    assert np.allclose(list(d.sigma_s), [0.5, 3.5, 7.5]) and np.allclose(list(d.sigma_a), [0.05] * 3)
+    assert d.strategy == P.STRATEGY_BALANCE and d.medium_sampling_weight == -1          # homogeneous.cpp defaults
+    assert (d.max_depth, d.rr_depth, d.hide_emitters) == (-1, 5, 0)                        # integrator.cpp:190-225
+    assert d.rfilter == P.FILTER_GAUSSIAN and d.rfilter_param == 0.5
+    assert abs(d.fov_x_deg - 95.8402) < 1e-4 and abs(d.near_clip - 1e-2) < 1e-9 and d.far_clip == 1e4
+    assert np.allclose(np.array(list(d.cam_to_world)).reshape(3, 4), P.look_at([-3, 0, 0], [-2, 0, 0], [0, 1, 0]), atol=1e-6)
+    assert list(d.bmin) == [-1, -1, -1] and list(d.bmax) == [1, 1, 1] and d.boundary == P.BOUNDARY_AABB
+    assert list(d.env_radiance) == [1, 1, 1]
+
+
+def test_cfg3_scene_and_substitution(tmp_path):
+    dens, rif = _vols(tmp_path)
+    defs = {"samples": 4, "size": 64, "density": dens, "rif": rif, "riftype": "gridvolume", "stepper": "rk4", "stepsize": 0.05}
+    d, spp = host.flatten_xml(os.path.join(SC, "cfg3_refractive.xml"), defs)
+    assert d.sigma_mode == P.SIGMA_GRID and d.rif_mode == P.RIF_TRILINEAR and d.stepper == P.STEP_RK4
+    assert abs(d.stepsize - 0.05) < 1e-9 and d.density_scale == 4 and d.tr_estimator == P.TR_RATIO
+    assert d.phase == P.PHASE_HG and abs(d.g - 0.8) < 1e-7 and np.allclose(list(d.albedo), 0.9)
+    defs["riftype"] = "splinevolume"; defs["stepper"] = "verlet"
+    d, _ = host.flatten_xml(os.path.join(SC, "cfg3_refractive.xml"), defs)
+    assert d.rif_mode == P.RIF_BSPLINE3 and d.stepper == P.STEP_VERLET
+    del defs["rif"]
+    with pytest.raises(host.HostError, match=r"\$rif.*never specified"):
+        host.flatten_xml(os.path.join(SC, "cfg3_refractive.xml"), defs)
+
+
+def _scene(tmp_path, body):
+    f = str(tmp_path / "s.xml")
+    open(f, "w").write('<scene version="0.5.0">' + body + '</scene>')
+    return f
+
+
+CAM = '<sensor type="perspective"><film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/></film></sensor>'
+
+
+@pytest.mark.parametrize("body,msg", [
+    ('<integrator type="volpath"><integer name="rrDepth" value="0"/></integrator>', "rrDepth"),
+    ('<integrator type="volpath"><integer name="maxDepth" value="0"/></integrator>', "maxDepth"),
+    ('<integrator type="bdpt"/>', "only 'volpath'"),
+    ('<integrator type="volpath"/>' + CAM + '<medium type="homogeneous" id="m"><spectrum name="sigmaS" value="1"/><phase type="hg"><float name="g" value="1.0"/></phase></medium>', "asymmetry parameter"),
+    ('<integrator type="volpath"/>' + CAM + '<medium type="heterogeneous" id="m"/>', "No density specified!"),
+    ('<integrator type="volpath"/>' + CAM + '<medium type="heterogeneous" id="m"><spectrum name="sigmaS" value="1"/></medium>', "only supported by homogeneous media"),
+    ('<integrator type="volpath"/>' + CAM + '<medium type="heterogeneous" id="m"><string name="method" value="montecarlo"/></medium>', "Unsupported integration method"),
+    ('<integrator type="volpath"/>' + CAM + '<medium type="heterogeneousrefractive" id="m"><spectrum name="sigmaS" value="1"/></medium>', "No RIF specified!"),
+    ('<integrator type="volpath"/>' + CAM + '<medium type="homogeneous" id="m"><spectrum name="sigmaS" value="1"/><spectrum name="sigmaT" value="1"/></medium>', "no other combinations"),
+    ('<integrator type="volpath"/>' + CAM + '<medium type="homogeneous" id="m"><spectrum name="sigmaS" value="1"/><string name="strategy" value="bogus"/></medium>', "unknown sampling strategy"),
+    ('<integrator type="volpath"/>' + CAM + '<medium type="homogeneous" id="m"><spectrum name="sigmaS" value="1"/></medium><shape type="cube"><ref name="inside" id="m"/></shape>', "must be named 'interior' or 'exterior'"),
+    ('<integrator type="volpath"/>' + CAM + '<shape type="cube"><ref name="interior" id="nope"/></shape>', "not found"),
+    ('<integrator type="volpath"/>' + CAM, "No shape with an 'interior' medium"),
+    ('<integrator type="volpath"/>', "no sensor"),
+])
+def test_errors_mirror_the_reference(tmp_path, body, msg):
+    with pytest.raises(host.HostError, match=msg):
+        host.flatten_xml(_scene(tmp_path, body))
+
+
+def test_volume_file_errors(tmp_path):
+    bad = str(tmp_path / "bad.vol"); open(bad, "wb").write(b"VOX\x03" + b"\0" * 44)
+    body = ('<integrator type="volpath"/>' + CAM + '<medium type="heterogeneous" id="m"><volume name="density" type="gridvolume">'
+            '<string name="filename" value="%s"/></volume></medium>' % bad)
+    with pytest.raises(host.HostError, match="incorrect header identifier"):
+        host.flatten_xml(_scene(tmp_path, body))
+    body = body.replace(bad, str(tmp_path / "missing.vol"))
+    with pytest.raises(host.HostError, match="does not exist"):
+        host.flatten_xml(_scene(tmp_path, body))
+
+
+@pytest.mark.gpu
+def test_xml_render_equals_direct_c_abi_render(tmp_path, ctx):
+    N = 16
+    dens, rif = _vols(tmp_path, N)
+    defs = {"samples": 4, "size": 48, "density": dens, "rif": rif, "riftype": "gridvolume", "stepper": "rk4", "stepsize": 0.5 * 2.0 / (N - 1)}
+    film = host.render_xml(os.path.join(SC, "cfg3_refractive.xml"), defs, seed=3, layout=capi.LAYOUT_DENSE)
+    p = scenes.curved_scene(N=N, w=48, h=48, rfilter=P.FILTER_BOX, rfilter_param=0.5, stepper=P.STEP_RK4, tr_estimator=P.TR_RATIO)
+    sc, vols = ctx.upload_scene(p)
+    ref = ctx.render_to_host(sc, 0, 4, seed=3)
+    assert np.allclose(film, ref, rtol=1e-5, atol=1e-6)
+    # config 1 through the XML path vs the oracle
+    from oracle import orc
+    film1 = host.render_xml(os.path.join(SC, "cfg1_homogeneous_box.xml"), {"samples": 4}, seed=1)
+    p1 = scenes.homogeneous_scene(w=128, h=128)
+    ref1, _ = orc.render(p1, 0, 4, 1, nthreads=8)
+    assert np.linalg.norm(film1 - ref1) / np.linalg.norm(ref1) < 2e-2
