@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--layout", default="cell8", choices=["dense", "cell8"])
     ap.add_argument("--shard", default="samples", choices=["samples", "tiles"])
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--device", type=int, default=None, help="force this GPU index for every rank (rehearsal on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
@@ -101,7 +103,9 @@ def main():
     import numpy as np
     import torch
     from mitsubaer_amd import capi, dist as mdist
-    rank, world, local = mdist.init_process_group()
+    rank, world, local = mdist.init_process_group(args.backend)
+    if args.device is not None:
+        local = args.device
     if world != args.gpus:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)

@@ -26,7 +26,7 @@ def init_process_group(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local)           # one process per GPU; "nccl" is RCCL on ROCm
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
