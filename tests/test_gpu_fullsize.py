@@ -1,0 +1,80 @@
+"""BASELINE.json's full grid / film sizes (256^3 fields, 512^2 film), checked through size-independent properties
+the domain offers -- the oracle would need minutes per sample here, so it is not the checker."""
+import numpy as np
+import pytest
+from mitsubaer_amd import params as P, synth, capi
+
+pytestmark = pytest.mark.gpu
+N, SIZE = 256, 512
+
+
+@pytest.fixture(scope="module")
+def fields():
+    return synth.density_field(N), synth.linear_rif(N)
+
+
+def _params(fields, **kw):
+    base = dict(width=SIZE, height=SIZE, density=fields[0], rfilter=P.FILTER_BOX, rfilter_param=0.5)
+    base.update(kw)
+    return P.SceneParams(**base)
+
+
+def test_cfg2_furnace_at_full_size(ctx, fields):
+    """non-absorbing medium + unit environment + straight rays: every path carries radiance exactly 1 in expectation
+    (NEE and phase-sampling MIS weights sum to one; delta tracking is unbiased)."""
+    p = _params(fields, albedo=[1, 1, 1], rr_depth=1000)
+    sc, vols = ctx.upload_scene(p)
+    ctx.counters_reset()
+    film = ctx.render_to_host(sc, 0, 4, seed=11)
+    c = ctx.counters()
+    assert c[capi.C_PATHS] == SIZE * SIZE * 4
+    w = film[..., 4]
+    # one box-filter weight per sample (radius 0.5 + 1e-5: a sample within 1e-5 of a pixel edge reaches two pixels)
+    assert np.abs(w - np.median(w)).max() < 1.01 and abs(w.sum() / (SIZE * SIZE * 4) - 1.0) < 1e-3
+    img = film[..., :3] / film[..., 4:5]
+    hit = np.abs(img[..., 0] - 1.0) > 1e-6                                                  # pixels whose samples entered the cube
+    assert 0.15 < hit.mean() < 0.25                                                         # cube covers ~20% of the 95.8 deg view
+    assert abs(img[hit].mean() - 1.0) < 5e-3
+    for v in vols:
+        v.destroy()
+
+
+def test_cfg3_layouts_shards_and_invariants_at_full_size(ctx, fields):
+    p = _params(fields, rif_mode=P.RIF_TRILINEAR, rif=fields[1], stepper=P.STEP_RK4, stepsize=0.5 * 2.0 / (N - 1))
+    sc_d, vd = ctx.upload_scene(p, layout=capi.LAYOUT_DENSE)
+    sc_c, vc = ctx.upload_scene(p, layout=capi.LAYOUT_CELL8)
+    a = ctx.render_paths(sc_d, 0, seed=5)
+    b = ctx.render_paths(sc_c, 0, seed=5)
+    assert np.array_equal(a, b)                              # the cell address is a pure function of the (x,y,z) index
+    assert np.isfinite(a).all() and a.min() >= 0
+    miss = a[0, 0]                                           # corner pixels miss the cube: L = env exactly
+    assert np.array_equal(miss, [1, 1, 1])
+    ctx.counters_reset()
+    full = ctx.render_to_host(sc_c, 0, 4, seed=6)
+    c = ctx.counters()
+    assert c[capi.C_PATHS] == SIZE * SIZE * 4
+    assert c[capi.C_RIF_EVALS] >= 4 * c[capi.C_STEPS]        # RK4: 4 field evaluations per step (+ segment end points)
+    assert c[capi.C_REAL] <= c[capi.C_TENTATIVE]
+    steps_per_path = c[capi.C_STEPS] / c[capi.C_PATHS]
+    assert 150 < steps_per_path < 400                        # ~245 at h = half a voxel (SURVEY 8d order of magnitude)
+    parts = sum(ctx.render_to_host(sc_c, r, 2, seed=6, spp_stride=2) for r in range(2))
+    assert np.allclose(full, parts, rtol=1e-4, atol=1e-4)    # sample-interleaved shards add up (float atomics order)
+    tiles = sum(ctx.render_to_host(sc_c, 0, 4, seed=6, tile_rank=r, tile_count=8) for r in range(8))
+    assert np.allclose(full, tiles, rtol=1e-4, atol=1e-4)    # 8 tile shards = the 8-GPU partition of config 4
+    for v in vd + vc:
+        v.destroy()
+
+
+def test_device_synthetic_fields_match_host_generators(ctx):
+    """mer_synth_field_dev (used for the 1024^3 config) against the numpy generators, via the lookup entry point."""
+    n = 64
+    rng = np.random.RandomState(0)
+    idx = rng.randint(0, n - 1, size=(4096, 3))
+    pts = (-1 + 2 * idx / (n - 1)).astype(np.float32) + 1e-5
+    for kind, ref in ((0, synth.density_field(n)), (1, synth.linear_rif(n)), (2, synth.radial_rif(n))):
+        vol = ctx.synth_volume(kind, n)
+        v, ii = ctx.lookup_trilinear(vol, pts)
+        want = ref[ii[:, 2], ii[:, 1], ii[:, 0]]
+        ok = ii[:, 3] >= 0
+        assert np.abs(v[ok] - want[ok]).max() < 2e-3          # value at (almost) the node; device sin() vs numpy
+        vol.destroy()
