@@ -39,7 +39,8 @@ struct mer_context {
     hipDeviceProp_t prop;
     // wavefront path-state slots
     uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
-    uint32_t *queue = nullptr, *qcount = nullptr, *mqueue = nullptr, *mcount = nullptr;
+    uint32_t *queue = nullptr, *qcount = nullptr, *mqueue = nullptr, *mcount = nullptr, *queue2 = nullptr, *q2count = nullptr;
+    unsigned long long *hitq = nullptr, *hitq_ctr = nullptr; unsigned long long hitq_cap = 0;
     int last_passes = 0;
     float last_march_ms = 0, last_event_ms = 0;
     std::vector<hipEvent_t> pass_events;          // 3 per pass: before K_event, between, after K_march
@@ -289,6 +290,10 @@ void mer_context_destroy(mer_context *ctx) {
     if (ctx->qcount) (void) hipFree(ctx->qcount);
     if (ctx->mqueue) (void) hipFree(ctx->mqueue);
     if (ctx->mcount) (void) hipFree(ctx->mcount);
+    if (ctx->queue2) (void) hipFree(ctx->queue2);
+    if (ctx->q2count) (void) hipFree(ctx->q2count);
+    if (ctx->hitq) (void) hipFree(ctx->hitq);
+    if (ctx->hitq_ctr) (void) hipFree(ctx->hitq_ctr);
     if (ctx->host_live) (void) hipHostFree(ctx->host_live);
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
@@ -474,31 +479,44 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         if (ctx->slots) (void) hipFree(ctx->slots);
         if (ctx->queue) (void) hipFree(ctx->queue);
         if (ctx->mqueue) (void) hipFree(ctx->mqueue);
-        ctx->slots = nullptr; ctx->queue = nullptr; ctx->mqueue = nullptr; ctx->nslots = 0;
+        if (ctx->queue2) (void) hipFree(ctx->queue2);
+        if (ctx->hitq) (void) hipFree(ctx->hitq);
+        ctx->slots = nullptr; ctx->queue = nullptr; ctx->mqueue = nullptr; ctx->queue2 = nullptr; ctx->hitq = nullptr; ctx->nslots = 0;
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->slots, (size_t) want * MER_SLOT_WORDS * sizeof(uint32_t)));
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->queue, (size_t) want * sizeof(uint32_t)));
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->mqueue, (size_t) want * 2 * sizeof(uint32_t)));
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->queue2, (size_t) want * 2 * sizeof(uint32_t)));
+        ctx->hitq_cap = 1; while (ctx->hitq_cap < (unsigned long long) want * 2) ctx->hitq_cap <<= 1;
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->hitq, (size_t) ctx->hitq_cap * sizeof(unsigned long long)));
         ctx->nslots = want;
     }
     if (!ctx->live) {
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->live, MER_LIVE_SLOTS * sizeof(uint32_t)));
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->qcount, MER_LIVE_SLOTS * sizeof(uint32_t)));
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->mcount, MER_LIVE_SLOTS * sizeof(uint32_t)));
-        HIP_CHECK(ctx, hipHostMalloc((void **) &ctx->host_live, sizeof(uint32_t)));
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->q2count, MER_LIVE_SLOTS * sizeof(uint32_t)));
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->hitq_ctr, 64 * sizeof(unsigned long long)));
+        HIP_CHECK(ctx, hipHostMalloc((void **) &ctx->host_live, 4 * sizeof(uint32_t)));
     }
     uint32_t nslots = ctx->nslots;
     const uint64_t need_slots = (P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
     if (need_slots < nslots) nslots = (uint32_t) need_slots;
-    P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.queue = ctx->queue; P.qcount = ctx->qcount; P.mqueue = ctx->mqueue; P.mcount = ctx->mcount;
+    P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.queue = ctx->queue; P.qcount = ctx->qcount; P.mqueue = ctx->mqueue; P.mcount = ctx->mcount; P.queue2 = ctx->queue2; P.q2count = ctx->q2count;
+    P.hitq = ctx->hitq; P.hitq_cap = ctx->hitq_cap; P.hitq_ctr = ctx->hitq_ctr; P.gen_iters = 8; P.gen_all = getenv("MER_GEN_ALL") ? 1 : 0;
     P.ksteps = 64;
     { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) P.ksteps = atoi(e); }
     HIP_CHECK(ctx, hipMemsetAsync(ctx->slots, 0, (size_t) nslots * MER_SLOT_WORDS * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->qcount, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->mcount, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->q2count, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
+    HIP_CHECK(ctx, hipMemsetAsync(ctx->hitq_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
     return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
         auto kev = event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
         auto kma = march_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
+        auto kge = gen_kernel<decltype(curved)::value>;
+        const unsigned gen_blocks = std::max(1u, std::min(nslots / MER_BLOCK, 1024u));      // 4096 waves x 512 ids per launch
+        bool work_left = true;
         const unsigned blocks = nslots / MER_BLOCK;
         HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         const uint32_t check_every = 8;
@@ -509,6 +527,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
                 hipEvent_t e; HIP_CHECK(ctx, hipEventCreate(&e)); ctx->pass_events.push_back(e);
             }
             HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 0], ctx->stream));
+            for (int g = 0; work_left && g < (pass == 0 ? 6 : 1); g++) hipLaunchKernelGGL(kge, dim3(gen_blocks), dim3(MER_BLOCK), 0, ctx->stream, P);
             hipLaunchKernelGGL(kev, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
             HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 1], ctx->stream));
             hipLaunchKernelGGL(kma, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
@@ -517,8 +536,10 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
             if (pass % check_every == 0) {
                 HIP_CHECK(ctx, hipGetLastError());
                 HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_live, ctx->live, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_live + 2, P.work_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
                 HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
                 if (*ctx->host_live >= nslots) break;
+                work_left = *(unsigned long long *) (ctx->host_live + 2) < P.total_work;
                 if (adaptive) {          // tail: few lanes left => longer passes, fewer launches
                     const uint32_t alive = nslots - *ctx->host_live;
                     P.ksteps = alive < nslots / 64 ? k0 * 32 : (alive < nslots / 16 ? k0 * 8 : (alive < nslots / 4 ? k0 * 2 : k0));

@@ -393,6 +393,10 @@ struct Params {
     uint32_t *live;                     // live[0]: number of finished slots
     uint32_t *queue, *qcount;           // event queue (slot indices) and its length per pass (ring of MER_LIVE_SLOTS)
     uint32_t *mqueue, *mcount;          // march lists (double-buffered by pass parity) and their lengths
+    uint32_t *queue2, *q2count;         // slots that found no work last pass (double-buffered) and their count
+    unsigned long long *hitq; unsigned long long hitq_cap;     // ring of work ids that will march (power-of-two capacity)
+    unsigned long long *hitq_ctr;       // [0] produced (tail), [1] consumed (head)
+    int32_t gen_iters, gen_all;
 };
 #define MER_LIVE_SLOTS 4096
 

@@ -19,7 +19,7 @@ enum { H_PX = 0, H_PY, H_PZ, H_VX, H_VY, H_VZ, H_OPT, H_DIST, H_REM, H_HPREV, H_
 // cold words (K_event only)
 enum { CO_PXF = H_COUNT, CO_PYF, CO_LX, CO_LY, CO_LZ, CO_TX, CO_TY, CO_TZ, CO_DEPTH, CO_PFLAGS, CO_PSX, CO_PSY, CO_PSZ,
        CO_DSX, CO_DSY, CO_DSZ, CO_DDX, CO_DDY, CO_DDZ, CO_WIX, CO_WIY, CO_WIZ, CO_PHASEPDF, CO_ITST, CO_N0, CO_TRSUM,
-       CO_SDENS, CO_TMIN, SLOT_WORDS };
+       CO_SDENS, CO_TMIN, CO_WNEXT_LO, CO_WNEXT_HI, CO_WLEFT, SLOT_WORDS };
 
 // H_FLAGS: st[1:0] ev[5:2] kind[7:6] seg_inf[8] backstep[9] walk[11:10]
 __device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg_inf, int backstep, int walk) {
@@ -31,6 +31,10 @@ __device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg
 // compacted march / event lists, i.e. by gather: a record-per-slot layout turns each lane's state access into a few
 // whole 16-byte pieces of two cache lines instead of 20-48 scattered dwords of a struct-of-arrays.
 #define MER_SLOT_WORDS 64
+#define MER_HITQ_HEAD 32          // hitq_ctr[0] = produced (tail), hitq_ctr[32] = consumed (head): separate 256-B lines
+#ifndef MER_WORK_BATCH
+#define MER_WORK_BATCH 8
+#endif
 #define SLOT(k) P.slots[(size_t) i * MER_SLOT_WORDS + (k)]
 #define SLOTF(k) __uint_as_float(SLOT(k))
 
@@ -85,6 +89,75 @@ __device__ __forceinline__ void flush_counters(const Params &P, const LaneCounte
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K_gen: pixel-sample generation (SamplingIntegrator::renderBlock, src/librender/integrator.cpp:162-187) run in bulk at
+// full SIMD efficiency.  A camera sample whose path ends before any marching -- it misses the medium shape, or maxDepth
+// forbids entering it -- is retired here (environment radiance + film splat); a sample that will march is handed to
+// K_event as a work id through the hit ring.  Without this, K_event's regeneration is a per-lane loop with a geometric
+// trip count (80% of the bench scene's camera rays miss) that leaves most lanes of every wave idle.
+template <bool CURVED>
+__global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
+    const mer_scene_desc &S = P.sc;
+    const f3 env(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
+    LaneCounters C; C.clear();
+    const int maxDepth = S.max_depth;
+    // one returning atomic per WAVE: it reserves 64 x gen_iters consecutive work ids (sample-major, 8x8 pixel patches)
+    const int lane = threadIdx.x & 63;
+    unsigned long long wave_base = 0; int go = 0;
+    if (lane == 0) {
+        // throttle: enough hits waiting for K_event already (the head is stable while K_gen runs)
+        const unsigned long long tl = P.hitq_ctr[0], hd = P.hitq_ctr[MER_HITQ_HEAD];
+        if (tl - min(tl, hd) <= P.hitq_cap / 2 && *P.work_counter < P.total_work) {
+            wave_base = atomicAdd(P.work_counter, (unsigned long long) (64 * P.gen_iters));
+            go = 1;
+        }
+    }
+    go = __shfl(go, 0, 64);
+    wave_base = ((unsigned long long) (uint32_t) __shfl((int) (wave_base >> 32), 0, 64) << 32) | (uint32_t) __shfl((int) (uint32_t) wave_base, 0, 64);
+    for (int it = 0; go && it < P.gen_iters; ++it) {
+        const uint64_t w = wave_base + (unsigned long long) it * 64ULL + (unsigned long long) lane;
+        bool hit = false;
+        if (w < P.total_work) {
+            int x, y; uint32_t sample;
+            if (P.gen_all) hit = true;
+            else if (decode_work(P, w, x, y, sample)) {
+                Rng rng; rng.seed(P.seed, (uint32_t) (y * S.width + x), sample);
+                const float sx = rng.next1D(), sy = rng.next1D();
+                const float px = (float) x + sx, py = (float) y + sy;
+                f3 o, d; float mint, maxt;
+                sample_ray(P, px, py, o, d, mint, maxt);
+                f3 L(0, 0, 0);
+                const float itsT = intersect_shape(S, o, d, mint, maxt);
+                if (itsT < 0) { if (!S.hide_emitters) L = env; }
+                else if (1 >= maxDepth && maxDepth != -1) { }
+                else {
+                    bool medium = true;
+                    if (!CURVED) { const f3 ro = o + d * itsT; medium = intersect_shape(S, ro, d, MER_EPSILON, MER_INF) >= 0; }
+                    if (!(2 <= maxDepth || maxDepth < 0)) { }
+                    else if (!medium) { if (!S.hide_emitters) L = env; }
+                    else hit = true;
+                }
+                if (!hit) {
+                    C.paths++;
+                    if (P.path_out) { float *q = P.path_out + ((size_t) y * S.width + x) * 3; q[0] = L.x; q[1] = L.y; q[2] = L.z; }
+                    else film_put(P, px, py, L, 1.0f);
+                }
+            }
+        }
+        // wave-aggregated push of the hits
+        const unsigned long long mask = __ballot(hit);
+        if (mask) {
+            const int leader = __ffsll((long long) mask) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(P.hitq_ctr, (unsigned long long) __popcll(mask));
+            base = ((unsigned long long) (uint32_t) __shfl((int) (base >> 32), leader, 64) << 32) | (uint32_t) __shfl((int) (uint32_t) base, leader, 64);
+            if (hit) P.hitq[(base + (unsigned long long) __popcll(mask & ((1ULL << lane) - 1ULL))) & (P.hitq_cap - 1)] = w;
+        }
+        if (wave_base + (unsigned long long) (it + 1) * 64ULL >= P.total_work) break;
+    }
+    flush_counters(P, C, 0);
+}
+
 // Block-aggregated append of slot index i to a queue: one atomic per block.  Must be reached by every thread of the
 // block (it contains barriers).
 __device__ __forceinline__ void queue_push(uint32_t *queue, uint32_t *count, bool pred, uint32_t i) {
@@ -119,6 +192,9 @@ template <bool CURVED, int RIF, int STEPPER, int SIGMA>
 __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const Params P, uint32_t pass) {
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
+    // K_event pops the hit ring with a bare atomicAdd and overshoots its tail when it starves; nothing touches the ring
+    // while K_march runs, so this is the race-free place to clamp the head before K_gen produces again
+    if (j == 0) { const unsigned long long t = P.hitq_ctr[0], h = P.hitq_ctr[MER_HITQ_HEAD]; if (h > t) P.hitq_ctr[MER_HITQ_HEAD] = t; }
     // sweep the compacted list of marching slots: dense waves in the steady state and in the tail alike
     const uint32_t count = P.mcount[pass & (MER_LIVE_SLOTS - 1)];
     LaneCounters C; C.clear();
@@ -164,12 +240,14 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
     // pass 0: every slot is new; later passes: the compacted list of slots K_march parked on an event
-    const uint32_t count = pass == 0 ? P.nslots : P.qcount[pass & (MER_LIVE_SLOTS - 1)];
-    if (j == 0) { P.qcount[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0; P.mcount[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0; }   // ring hygiene
+    const uint32_t nq = pass == 0 ? P.nslots : P.qcount[pass & (MER_LIVE_SLOTS - 1)];
+    const uint32_t ns = pass == 0 ? 0u : P.q2count[pass & (MER_LIVE_SLOTS - 1)];      // slots left without work last pass
+    const uint32_t count = nq + ns;
+    if (j == 0) { P.qcount[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0; P.mcount[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0; P.q2count[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0; }   // ring hygiene
     LaneCounters C; C.clear();
-    bool marching = false; uint32_t i = 0;
+    bool marching = false, starved_out = false; uint32_t i = 0;
     if (j < count) {
-    i = pass == 0 ? j : P.queue[j];
+    i = pass == 0 ? j : (j < nq ? P.queue[j] : P.queue2[(size_t) (pass & 1u) * P.nslots + (j - nq)]);
     const uint32_t fl = SLOT(H_FLAGS);
     int st = fl & 3u, ev = (fl >> 2) & 15u;
 
@@ -190,6 +268,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     float px = 0, py = 0, sigma = 0, phasePdf = 0, itsT = 0;
     f3 L(0, 0, 0), T(1, 1, 1), ps(0, 0, 0), dsave(0, 0, 1), dd(0, 0, 1), wi(0, 0, 1), trv(1, 1, 1);
     int depth = 1, flags = F_EMITTED, px_i = 0, py_i = 0;
+    bool starved = false;
     if (st == ST_MARCH) {
         uint32_t fl2;
         load_hot(P, i, fl2, W, rng, pixel, sample, sigma);
@@ -207,13 +286,23 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
         rng.state = 0; rng.inc = 1;
     }
 
+    // ring tail and work counter are stable while K_event runs (K_gen is not running): read them once, and keep them on
+    // cache lines of their own -- the head's line is hammered by the pop atomics
+    const unsigned long long tail = P.hitq_ctr[0], work_issued = *P.work_counter;
     for (;;) {
         // ---------------------------------------------------------------- regeneration (integrator.cpp:162-187)
         if (st == ST_NEW) {
-            const uint64_t w = atomicAdd(P.work_counter, 1ULL);
-            if (w >= P.total_work) { st = ST_DONE; break; }
+            // K_gen has already retired the camera samples that never reach the medium; what is left to do here is to
+            // pop one sample that does (a work id from the hit ring) and replay its deterministic prologue
+            const unsigned long long idx = atomicAdd(P.hitq_ctr + MER_HITQ_HEAD, 1ULL);
+            if (idx >= tail) {
+                // nothing to pop: finished if the work counter is exhausted too, otherwise wait for the next pass
+                if (work_issued >= P.total_work) st = ST_DONE; else starved = true;
+                break;
+            }
+            const uint64_t w = P.hitq[idx & (P.hitq_cap - 1)];
             int x, y;
-            if (!decode_work(P, w, x, y, sample)) continue;      // pixel of a partial edge tile
+            decode_work(P, w, x, y, sample);
             px_i = x; py_i = y; pixel = (uint32_t) (y * S.width + x);
             rng.seed(P.seed, pixel, sample);
             const float sx = rng.next1D(), sy = rng.next1D();
@@ -379,6 +468,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
 
     // ---- park the lane
     if (st == ST_DONE) { SLOT(H_FLAGS) = ST_DONE; atomicAdd(P.live, 1u); }      // live[0] counts finished slots
+    else if (starved) { SLOT(H_FLAGS) = ST_NEW; starved_out = true; }
     else {
         store_hot(P, i, ST_MARCH, EV_NONE, W, rng, pixel, sample, 0.0f);
         SLOT(CO_PXF) = __float_as_uint(px); SLOT(CO_PYF) = __float_as_uint(py);
@@ -396,6 +486,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     }
     }   // j < count
     queue_push(P.mqueue + (size_t) (pass & 1u) * P.nslots, P.mcount + (pass & (MER_LIVE_SLOTS - 1)), marching, i);
+    queue_push(P.queue2 + (size_t) ((pass + 1) & 1u) * P.nslots, P.q2count + ((pass + 1) & (MER_LIVE_SLOTS - 1)), starved_out, i);
     flush_counters(P, C, 0);
 }
 
