@@ -156,8 +156,9 @@ __device__ __forceinline__ f3 lookup_spectrum(const DGrid &g, f3 p) {
 // the same cell most of the time, so the gather is re-issued only when the cell index changes.
 struct CellCache {
     int cell;                 // linear index of the cached cell's base corner, -1 = empty
+    float cx, cy, cz;         // the cached cell's base corner in grid coordinates (exact small integers)
     float d000, d001, d010, d011, d100, d101, d110, d111;
-    __device__ __forceinline__ void reset() { cell = -1; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f; }
+    __device__ __forceinline__ void reset() { cell = -1; cx = cy = cz = -1.0e30f; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f; }
 };
 
 // Internal fetch kinds of the trilinear RIF (template parameter RIF of the kernels):
@@ -174,40 +175,46 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int RIFK>
 __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &cc, f3 p, float &val, f3 &grad) {
     const float px = __builtin_fmaf(g.s[0], p.x, g.t[0]), py = __builtin_fmaf(g.s[1], p.y, g.t[1]), pz = __builtin_fmaf(g.s[2], p.z, g.t[2]);
-    int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
-    x1 = min(max(x1, 0), g.res[0] - 2); y1 = min(max(y1, 0), g.res[1] - 2); z1 = min(max(z1, 0), g.res[2] - 2);
-    const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1;
-    const int base = (z1 * g.res[1] + y1) * g.res[0] + x1;
-    if (base != cc.cell) {
-        cc.cell = base;
-        if (RIFK == RIFK_CELL8 || RIFK == RIFK_CELL8_BUF) {
-            const int cell = (z1 * (g.res[1] - 1) + y1) * (g.res[0] - 1) + x1;
-            float4 a, b;
-            if (RIFK == RIFK_CELL8_BUF) {
-                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
-                const u32x4 ua = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cell * 32, 0, 0);
-                const u32x4 ub = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cell * 32 + 16, 0, 0);
-                a = make_float4(__uint_as_float(ua.x), __uint_as_float(ua.y), __uint_as_float(ua.z), __uint_as_float(ua.w));
-                b = make_float4(__uint_as_float(ub.x), __uint_as_float(ub.y), __uint_as_float(ub.z), __uint_as_float(ub.w));
+    // fast path: the point is still in the cached cell  <=>  0 <= q - corner < 1 on every axis (the subtraction is
+    // exact, so this is the same decision as floor(q) == corner); the four RK4 stages of a half-voxel step mostly are
+    float fx = px - cc.cx, fy = py - cc.cy, fz = pz - cc.cz;
+    if (!(fminf(fx, fminf(fy, fz)) >= 0.0f && fmaxf(fx, fmaxf(fy, fz)) < 1.0f)) {
+        int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
+        x1 = min(max(x1, 0), g.res[0] - 2); y1 = min(max(y1, 0), g.res[1] - 2); z1 = min(max(z1, 0), g.res[2] - 2);
+        cc.cx = (float) x1; cc.cy = (float) y1; cc.cz = (float) z1;
+        fx = px - cc.cx; fy = py - cc.cy; fz = pz - cc.cz;
+        const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);
+        if (base != cc.cell) {
+            cc.cell = base;
+            if (RIFK == RIFK_CELL8 || RIFK == RIFK_CELL8_BUF) {
+                const int cell = (int) (__umul24(__umul24(z1, g.res[1] - 1) + y1, g.res[0] - 1) + x1);
+                float4 a, b;
+                if (RIFK == RIFK_CELL8_BUF) {
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
+                    const u32x4 ua = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cell * 32, 0, 0);
+                    const u32x4 ub = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cell * 32 + 16, 0, 0);
+                    a = make_float4(__uint_as_float(ua.x), __uint_as_float(ua.y), __uint_as_float(ua.z), __uint_as_float(ua.w));
+                    b = make_float4(__uint_as_float(ub.x), __uint_as_float(ub.y), __uint_as_float(ub.z), __uint_as_float(ub.w));
+                } else {
+                    const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
+                    a = c[0]; b = c[1];
+                }
+                cc.d000 = a.x; cc.d001 = a.y; cc.d010 = a.z; cc.d011 = a.w; cc.d100 = b.x; cc.d101 = b.y; cc.d110 = b.z; cc.d111 = b.w;
+            } else if (RIFK == RIFK_DENSE_BUF) {
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.data, 0, (int) g.buf_bytes, 0x00020000);
+                const int sy4 = g.res[0] * 4, sz4 = g.res[0] * g.res[1] * 4;
+                const u32x2 r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, 0, 0);
+                const u32x2 r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sy4, 0);
+                const u32x2 r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sz4, 0);
+                const u32x2 r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sz4 + sy4, 0);
+                cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
+                cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
             } else {
-                const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
-                a = c[0]; b = c[1];
+                const float *D = (const float *) g.data;
+                const int sy = g.res[0], sz = g.res[0] * g.res[1];
+                cc.d000 = D[base]; cc.d001 = D[base + 1]; cc.d010 = D[base + sy]; cc.d011 = D[base + sy + 1];
+                cc.d100 = D[base + sz]; cc.d101 = D[base + sz + 1]; cc.d110 = D[base + sz + sy]; cc.d111 = D[base + sz + sy + 1];
             }
-            cc.d000 = a.x; cc.d001 = a.y; cc.d010 = a.z; cc.d011 = a.w; cc.d100 = b.x; cc.d101 = b.y; cc.d110 = b.z; cc.d111 = b.w;
-        } else if (RIFK == RIFK_DENSE_BUF) {
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.data, 0, (int) g.buf_bytes, 0x00020000);
-            const int sy4 = g.res[0] * 4, sz4 = g.res[0] * g.res[1] * 4;
-            const u32x2 r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, 0, 0);
-            const u32x2 r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sy4, 0);
-            const u32x2 r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sz4, 0);
-            const u32x2 r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sz4 + sy4, 0);
-            cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
-            cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
-        } else {
-            const float *D = (const float *) g.data;
-            const int sy = g.res[0], sz = g.res[0] * g.res[1];
-            cc.d000 = D[base]; cc.d001 = D[base + 1]; cc.d010 = D[base + sy]; cc.d011 = D[base + sy + 1];
-            cc.d100 = D[base + sz]; cc.d101 = D[base + sz + 1]; cc.d110 = D[base + sz + sy]; cc.d111 = D[base + sz + sy + 1];
         }
     }
     const float dx00 = cc.d001 - cc.d000, dx01 = cc.d011 - cc.d010, dx10 = cc.d101 - cc.d100, dx11 = cc.d111 - cc.d110;
@@ -281,6 +288,13 @@ template <int RIF> __device__ __forceinline__ void rif_value_grad(const DGrid &g
     else bspline_value_grad(g, p, n, gr);
 }
 
+// RK4 is new functionality: its 1/n is the hardware reciprocal (v_rcp_f32, <= 1 ulp) instead of the ~12-
+// instruction IEEE division sequence; the Verlet form (the reference's er_step) keeps the correctly rounded division.
+#ifdef MER_IEEE_RCP
+#define MER_RCP(x) (1.0f / (x))
+#else
+#define MER_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
 __device__ __forceinline__ f3 fma3(float s, f3 a, f3 b) {           // s*a + b, fused per component
     return f3(__builtin_fmaf(s, a.x, b.x), __builtin_fmaf(s, a.y, b.y), __builtin_fmaf(s, a.z, b.z));
 }
@@ -303,19 +317,19 @@ __device__ __forceinline__ void er_step(const DGrid &g, CellCache &cc, f3 &p, f3
         float n; f3 gr;
         const float hh = 0.5f * h;
         rif_value_grad<RIF>(g, cc, p, n, gr);                       // k1
-        f3 kp = v * (1.0f / n);
+        f3 kp = v * MER_RCP(n);
         f3 ps = kp, vs = gr; float ns = n;
         f3 vv = fma3(hh, gr, v);
         rif_value_grad<RIF>(g, cc, fma3(hh, kp, p), n, gr);          // k2
-        kp = vv * (1.0f / n);
+        kp = vv * MER_RCP(n);
         ps = fma3(2.0f, kp, ps); vs = fma3(2.0f, gr, vs); ns = __builtin_fmaf(2.0f, n, ns);
         vv = fma3(hh, gr, v);
         rif_value_grad<RIF>(g, cc, fma3(hh, kp, p), n, gr);          // k3
-        kp = vv * (1.0f / n);
+        kp = vv * MER_RCP(n);
         ps = fma3(2.0f, kp, ps); vs = fma3(2.0f, gr, vs); ns = __builtin_fmaf(2.0f, n, ns);
         vv = fma3(h, gr, v);
         rif_value_grad<RIF>(g, cc, fma3(h, kp, p), n, gr);           // k4
-        kp = vv * (1.0f / n);
+        kp = vv * MER_RCP(n);
         ps = ps + kp; vs = vs + gr; ns = ns + n;
         const float h6 = h * (1.0f / 6.0f);
         p = fma3(h6, ps, p);
