@@ -31,7 +31,8 @@ def build_workload(name, res, size, spp):
         p = P.SceneParams(density=dens, rif_mode=P.RIF_CONST, **common)
         desc = "%d^3 sigma_t grid, constant RIF (straight rays), HG g=0.8, %d^2 x %d spp" % (res, size, spp)
     elif name == "cfg3":
-        p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.linear_rif(res), stepper=P.STEP_RK4,
+        rres = int(os.environ.get("BENCH_RIF_RES", res))
+        p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.linear_rif(rres), stepper=P.STEP_RK4,
                           stepsize=0.5 * 2.0 / (res - 1), **common)
         desc = "%d^3 sigma_t grid + %d^3 linear-gradient RIF, RK4 eikonal curved rays, HG g=0.8, %d^2 x %d spp" % (res, res, size, spp)
     elif name == "cfg4":

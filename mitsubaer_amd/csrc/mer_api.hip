@@ -39,7 +39,7 @@ struct mer_context {
     hipDeviceProp_t prop;
     // wavefront path-state slots
     uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
-    uint32_t *queue = nullptr, *qcount = nullptr, *mqueue = nullptr, *mcount = nullptr, *queue2 = nullptr, *q2count = nullptr;
+    SegQueue eq{}, mq[2]{}, sq[2]{};
     unsigned long long *hitq = nullptr, *hitq_ctr = nullptr; unsigned long long hitq_cap = 0;
     int last_passes = 0;
     float last_march_ms = 0, last_event_ms = 0;
@@ -286,12 +286,7 @@ void mer_context_destroy(mer_context *ctx) {
     if (ctx->counters) (void) hipFree(ctx->counters);
     if (ctx->slots) (void) hipFree(ctx->slots);
     if (ctx->live) (void) hipFree(ctx->live);
-    if (ctx->queue) (void) hipFree(ctx->queue);
-    if (ctx->qcount) (void) hipFree(ctx->qcount);
-    if (ctx->mqueue) (void) hipFree(ctx->mqueue);
-    if (ctx->mcount) (void) hipFree(ctx->mcount);
-    if (ctx->queue2) (void) hipFree(ctx->queue2);
-    if (ctx->q2count) (void) hipFree(ctx->q2count);
+    for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1]}) { if (q->items) (void) hipFree(q->items); if (q->counts) (void) hipFree(q->counts); }
     if (ctx->hitq) (void) hipFree(ctx->hitq);
     if (ctx->hitq_ctr) (void) hipFree(ctx->hitq_ctr);
     if (ctx->host_live) (void) hipHostFree(ctx->host_live);
@@ -477,39 +472,36 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     want = (want + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
     if (ctx->nslots != want) {
         if (ctx->slots) (void) hipFree(ctx->slots);
-        if (ctx->queue) (void) hipFree(ctx->queue);
-        if (ctx->mqueue) (void) hipFree(ctx->mqueue);
-        if (ctx->queue2) (void) hipFree(ctx->queue2);
         if (ctx->hitq) (void) hipFree(ctx->hitq);
-        ctx->slots = nullptr; ctx->queue = nullptr; ctx->mqueue = nullptr; ctx->queue2 = nullptr; ctx->hitq = nullptr; ctx->nslots = 0;
+        ctx->slots = nullptr; ctx->hitq = nullptr; ctx->nslots = 0;
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->slots, (size_t) want * MER_SLOT_WORDS * sizeof(uint32_t)));
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->queue, (size_t) want * sizeof(uint32_t)));
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->mqueue, (size_t) want * 2 * sizeof(uint32_t)));
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->queue2, (size_t) want * 2 * sizeof(uint32_t)));
+        for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1]}) {
+            if (q->items) (void) hipFree(q->items);
+            q->items = nullptr;
+            q->segcap = 2u * (want / MER_NSEG) + 256u;          // two producer kernels may feed one segment
+            HIP_CHECK(ctx, hipMalloc((void **) &q->items, (size_t) q->segcap * MER_NSEG * sizeof(uint32_t)));
+            if (!q->counts) HIP_CHECK(ctx, hipMalloc((void **) &q->counts, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t)));
+        }
         ctx->hitq_cap = 1; while (ctx->hitq_cap < (unsigned long long) want * 2) ctx->hitq_cap <<= 1;
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->hitq, (size_t) ctx->hitq_cap * sizeof(unsigned long long)));
         ctx->nslots = want;
     }
     if (!ctx->live) {
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->live, MER_LIVE_SLOTS * sizeof(uint32_t)));
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->qcount, MER_LIVE_SLOTS * sizeof(uint32_t)));
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->mcount, MER_LIVE_SLOTS * sizeof(uint32_t)));
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->q2count, MER_LIVE_SLOTS * sizeof(uint32_t)));
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->hitq_ctr, 64 * sizeof(unsigned long long)));
         HIP_CHECK(ctx, hipHostMalloc((void **) &ctx->host_live, 4 * sizeof(uint32_t)));
+        HIP_CHECK(ctx, hipMalloc((void **) &ctx->hitq_ctr, 64 * sizeof(unsigned long long)));
     }
     uint32_t nslots = ctx->nslots;
     const uint64_t need_slots = (P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
     if (need_slots < nslots) nslots = (uint32_t) need_slots;
-    P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.queue = ctx->queue; P.qcount = ctx->qcount; P.mqueue = ctx->mqueue; P.mcount = ctx->mcount; P.queue2 = ctx->queue2; P.q2count = ctx->q2count;
+    P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.eq = ctx->eq; P.mq[0] = ctx->mq[0]; P.mq[1] = ctx->mq[1]; P.sq[0] = ctx->sq[0]; P.sq[1] = ctx->sq[1];
     P.hitq = ctx->hitq; P.hitq_cap = ctx->hitq_cap; P.hitq_ctr = ctx->hitq_ctr; P.gen_iters = 8; P.gen_all = getenv("MER_GEN_ALL") ? 1 : 0;
     P.ksteps = 64;
     { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) P.ksteps = atoi(e); }
     HIP_CHECK(ctx, hipMemsetAsync(ctx->slots, 0, (size_t) nslots * MER_SLOT_WORDS * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
-    HIP_CHECK(ctx, hipMemsetAsync(ctx->qcount, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
-    HIP_CHECK(ctx, hipMemsetAsync(ctx->mcount, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
-    HIP_CHECK(ctx, hipMemsetAsync(ctx->q2count, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
+    for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1]})
+        HIP_CHECK(ctx, hipMemsetAsync(q->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->hitq_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
     return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
         auto kev = event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;

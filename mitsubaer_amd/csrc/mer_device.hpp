@@ -382,6 +382,14 @@ __device__ __forceinline__ float phase_sample(int kind, float g, f3 wi, float sx
 }
 
 // ------------------------------------------------------------------------------------------------
+// A segmented work list (mer_wavefront.hpp)
+#define MER_NSEG 16
+struct SegQueue {
+    uint32_t *items;          // [MER_NSEG][segcap]
+    uint32_t *counts;         // [MER_LIVE_SLOTS][MER_NSEG], row = pass & (MER_LIVE_SLOTS-1)
+    uint32_t segcap;
+};
+
 // Everything a render / leaf kernel needs, passed by value as the kernel argument.
 struct Params {
     mer_scene_desc sc;
@@ -405,9 +413,7 @@ struct Params {
     // wavefront path-state slots (struct of arrays, word k of slot i at slots[k*nslots + i])
     uint32_t *slots; uint32_t nslots; int32_t ksteps;
     uint32_t *live;                     // live[0]: number of finished slots
-    uint32_t *queue, *qcount;           // event queue (slot indices) and its length per pass (ring of MER_LIVE_SLOTS)
-    uint32_t *mqueue, *mcount;          // march lists (double-buffered by pass parity) and their lengths
-    uint32_t *queue2, *q2count;         // slots that found no work last pass (double-buffered) and their count
+    SegQueue eq, mq[2], sq[2];          // event queue, march lists (by pass parity), starved lists (by pass parity)
     unsigned long long *hitq; unsigned long long hitq_cap;     // ring of work ids that will march (power-of-two capacity)
     unsigned long long *hitq_ctr;       // [0] produced (tail), [1] consumed (head)
     int32_t gen_iters, gen_all;

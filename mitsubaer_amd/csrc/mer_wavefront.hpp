@@ -64,28 +64,20 @@ __device__ __forceinline__ void store_hot(const Params &P, uint32_t i, int st, i
     r[4] = make_uint4((uint32_t) (rng.state >> 32), pixel, sample, __float_as_uint(sigma));
 }
 
-// Counter flush: one set of atomics per BLOCK, spread over MER_COUNTER_REPLICAS copies (summed on the host), so
-// that a pass of thousands of blocks does not serialise on nine addresses (one word sustains ~88 atomics/us).
+// Counter flush: one set of atomics per wave, spread over MER_COUNTER_REPLICAS copies (summed on the host) so that a
+// pass of thousands of waves does not serialise on nine addresses (one word sustains ~88 atomics/us).  No barrier:
+// a wave that is done must not wait for its block mates while holding registers.
 #define MER_COUNTER_REPLICAS 64
 __device__ __forceinline__ void flush_counters(const Params &P, const LaneCounters &C, uint32_t lane_slots) {
-    __shared__ uint32_t sh[MER_BLOCK / 64][9];
     const uint32_t sums[9] = {wave_sum(C.paths), wave_sum(C.steps), wave_sum(C.rif_evals), wave_sum(C.tentative),
                               wave_sum(C.real), wave_sum(C.segments), wave_sum(C.nee), wave_sum(C.marched), wave_sum(lane_slots)};
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) {
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t wave_id = (blockIdx.x * MER_BLOCK + threadIdx.x) >> 6;
+        unsigned long long *dst = P.counters + (size_t) (wave_id % MER_COUNTER_REPLICAS) * MER_C_COUNT;
 #pragma unroll
-        for (int k = 0; k < 9; k++) sh[wave][k] = sums[k];
-    }
-    __syncthreads();
-    if (threadIdx.x < 9) {
-        uint32_t tot = 0;
-#pragma unroll
-        for (int w = 0; w < MER_BLOCK / 64; w++) tot += sh[w][threadIdx.x];
-        if (tot) {
-            const int k = threadIdx.x;
-            const int dst = k < 7 ? k : (k == 7 ? MER_C_ACTIVE_LANES : MER_C_LOOP_ITERS);
-            atomicAdd(P.counters + (size_t) (blockIdx.x % MER_COUNTER_REPLICAS) * MER_C_COUNT + dst, (unsigned long long) tot);
-        }
+        for (int k = 0; k < 7; k++) if (sums[k]) atomicAdd(dst + k, (unsigned long long) sums[k]);
+        if (sums[7]) atomicAdd(dst + MER_C_ACTIVE_LANES, (unsigned long long) sums[7]);
+        if (sums[8]) atomicAdd(dst + MER_C_LOOP_ITERS, (unsigned long long) sums[8]);
     }
 }
 
@@ -158,28 +150,39 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
     flush_counters(P, C, 0);
 }
 
-// Block-aggregated append of slot index i to a queue: one atomic per block.  Must be reached by every thread of the
-// block (it contains barriers).
-__device__ __forceinline__ void queue_push(uint32_t *queue, uint32_t *count, bool pred, uint32_t i) {
-    __shared__ uint32_t wcount[MER_BLOCK / 64];
-    __shared__ uint32_t bbase;
+// Work lists (event queue, march lists, starved list) are MER_NSEG independent segments.  A wave appends to the segment
+// picked by its own position in the grid with ONE wave-aggregated atomic -- no block barrier (a finished wave must not
+// wait for its block mates while holding 90 VGPRs), and no hot word: a pass of 32 K waves spreads over 16 counters.
+// Segment s only ever receives the lanes of the waves w with w % MER_NSEG == s, so its capacity is bounded.
+__device__ __forceinline__ void queue_push(const SegQueue &q, uint32_t row, bool pred, uint32_t i) {
     const unsigned long long mask = __ballot(pred);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();                                   // protects wcount / bbase against the previous push
-    if (lane == 0) wcount[wave] = (uint32_t) __popcll(mask);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
+    if (mask) {
+        const int lane = threadIdx.x & 63;
+        const uint32_t seg = ((blockIdx.x * MER_BLOCK + threadIdx.x) >> 6) & (MER_NSEG - 1);
+        const int leader = __ffsll((long long) mask) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG + seg, (uint32_t) __popcll(mask));
+        base = (uint32_t) __shfl((int) base, leader, 64);
+        if (pred) q.items[(size_t) seg * q.segcap + base + (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL))] = i;
+    }
+}
+__device__ __forceinline__ uint32_t queue_total(const SegQueue &q, uint32_t row) {
+    const uint32_t *c = q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG;
+    uint32_t t = 0;
 #pragma unroll
-        for (int w = 0; w < MER_BLOCK / 64; w++) tot += wcount[w];
-        bbase = tot ? atomicAdd(count, tot) : 0u;
-    }
-    __syncthreads();
-    if (pred) {
-        uint32_t off = bbase;
-        for (int w = 0; w < wave; w++) off += wcount[w];
-        queue[off + (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL))] = i;
-    }
+    for (int s = 0; s < MER_NSEG; s++) t += c[s];
+    return t;
+}
+/// j-th item of the concatenated segments (j < queue_total)
+__device__ __forceinline__ uint32_t queue_item(const SegQueue &q, uint32_t row, uint32_t j) {
+    const uint32_t *c = q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG;
+    uint32_t seg = 0, off = j;
+#pragma unroll
+    for (int s = 0; s < MER_NSEG - 1; s++) { const uint32_t n = c[s]; if (seg == (uint32_t) s && off >= n) { off -= n; seg = s + 1; } }
+    return q.items[(size_t) seg * q.segcap + off];
+}
+__device__ __forceinline__ void queue_clear_row(const SegQueue &q, uint32_t row, uint32_t j) {
+    if (j < MER_NSEG) q.counts[(size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG + j] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -196,12 +199,12 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
     // while K_march runs, so this is the race-free place to clamp the head before K_gen produces again
     if (j == 0) { const unsigned long long t = P.hitq_ctr[0], h = P.hitq_ctr[MER_HITQ_HEAD]; if (h > t) P.hitq_ctr[MER_HITQ_HEAD] = t; }
     // sweep the compacted list of marching slots: dense waves in the steady state and in the tail alike
-    const uint32_t count = P.mcount[pass & (MER_LIVE_SLOTS - 1)];
+    const uint32_t count = queue_total(P.mq[pass & 1u], pass);
     LaneCounters C; C.clear();
     uint32_t iters = 0, i = 0;
     bool has_event = false, still_marching = false;
     if (j < count) {
-        i = P.mqueue[(size_t) (pass & 1u) * P.nslots + j];
+        i = queue_item(P.mq[pass & 1u], pass, j);
         uint32_t fl;
         Walk<CURVED, RIF, STEPPER, SIGMA> W;
         Rng rng; uint32_t pixel, sample; float sigma;
@@ -220,8 +223,8 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
         still_marching = !has_event;
     }
     // compaction: lanes parked on an event go to K_event's queue, the others straight to the next march list
-    queue_push(P.queue, P.qcount + ((pass + 1) & (MER_LIVE_SLOTS - 1)), has_event, i);
-    queue_push(P.mqueue + (size_t) ((pass + 1) & 1u) * P.nslots, P.mcount + ((pass + 1) & (MER_LIVE_SLOTS - 1)), still_marching, i);
+    queue_push(P.eq, pass + 1, has_event, i);
+    queue_push(P.mq[(pass + 1) & 1u], pass + 1, still_marching, i);
     // lane-slot accounting: every lane of the wave is held for as many trips as its slowest lane
     uint32_t wave_iters = iters;
 #pragma unroll
@@ -240,14 +243,15 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
     // pass 0: every slot is new; later passes: the compacted list of slots K_march parked on an event
-    const uint32_t nq = pass == 0 ? P.nslots : P.qcount[pass & (MER_LIVE_SLOTS - 1)];
-    const uint32_t ns = pass == 0 ? 0u : P.q2count[pass & (MER_LIVE_SLOTS - 1)];      // slots left without work last pass
+    const uint32_t nq = pass == 0 ? P.nslots : queue_total(P.eq, pass);
+    const uint32_t ns = pass == 0 ? 0u : queue_total(P.sq[pass & 1u], pass);      // slots left without work last pass
     const uint32_t count = nq + ns;
-    if (j == 0) { P.qcount[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0; P.mcount[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0; P.q2count[(pass + 2) & (MER_LIVE_SLOTS - 1)] = 0; }   // ring hygiene
+    // ring hygiene: the rows K_march / K_event of pass+1 will add to
+    queue_clear_row(P.eq, pass + 2, j); queue_clear_row(P.mq[pass & 1u], pass + 2, j); queue_clear_row(P.sq[pass & 1u], pass + 2, j);
     LaneCounters C; C.clear();
     bool marching = false, starved_out = false; uint32_t i = 0;
     if (j < count) {
-    i = pass == 0 ? j : (j < nq ? P.queue[j] : P.queue2[(size_t) (pass & 1u) * P.nslots + (j - nq)]);
+    i = pass == 0 ? j : (j < nq ? queue_item(P.eq, pass, j) : queue_item(P.sq[pass & 1u], pass, j - nq));
     const uint32_t fl = SLOT(H_FLAGS);
     int st = fl & 3u, ev = (fl >> 2) & 15u;
 
@@ -485,8 +489,8 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
         marching = true;
     }
     }   // j < count
-    queue_push(P.mqueue + (size_t) (pass & 1u) * P.nslots, P.mcount + (pass & (MER_LIVE_SLOTS - 1)), marching, i);
-    queue_push(P.queue2 + (size_t) ((pass + 1) & 1u) * P.nslots, P.q2count + ((pass + 1) & (MER_LIVE_SLOTS - 1)), starved_out, i);
+    queue_push(P.mq[pass & 1u], pass, marching, i);
+    queue_push(P.sq[(pass + 1) & 1u], pass + 1, starved_out, i);
     flush_counters(P, C, 0);
 }
 
