@@ -193,6 +193,16 @@ def main():
                                                  "tentative": counters[capi.C_TENTATIVE] / args.steps, "real": counters[capi.C_REAL] / args.steps},
                          "active_lane_fraction": lane_eff},
         }
+        # HBM traffic cannot be counted inside this process: it comes from separate `rocprofv3 --pmc` passes of this very
+        # command (FETCH_SIZE / WRITE_SIZE, gfx950 read correction applied), committed under profiles/
+        tf = os.path.join(ROOT, "profiles", "round1", "pmc_traffic_cfg3_n1.json")
+        if args.workload == "cfg3" and args.res == 256 and args.size == 512 and args.spp == 256 and args.layout == "cell8" and os.path.exists(tf):
+            try:
+                t = json.load(open(tf))["march_kernel"]
+                out["roofline"]["traffic"] = t["traffic_bytes_per_launch_with_gfx950_x2_read_correction"]
+                out["roofline"]["traffic_source"] = "profiles/round1/pmc_traffic_cfg3_n1.json (separate rocprofv3 --pmc passes; bytes per K_march launch)"
+            except Exception:
+                pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(p, args.cpu_seconds)
         print(json.dumps(out))
