@@ -152,6 +152,10 @@ int  mer_sample_distance(mer_context *ctx, const mer_scene_desc *scene, const fl
 /* Medium::evalTransmittance (heterogeneous.cpp:546-587 / ratio tracking) */
 int  mer_eval_transmittance(mer_context *ctx, const mer_scene_desc *scene, const float *o, const float *d,
                             const float *maxt, int64_t n, uint64_t seed, float *out_tr);
+/* HeterogeneousRefractiveMedium::eval -> makeDirectConnections (heterogeneousrefractive.cpp:571-640,798-1163): connect p1 to p2
+   (both inside the medium shape) by a curved ray; out stride 12: ok, weight, dirToP2[3] (optical momentum at p1),
+   revDirToP1[3], distance, opticalLength, 0, 0; RNG stream of item i = (seed, pixel=i, sample=0) */
+int  mer_connect(mer_context *ctx, const mer_scene_desc *scene, const float *p1, const float *p2, int64_t n, uint64_t seed, float *out);
 /* PhaseFunction::sample / eval (src/phase/hg.cpp:74-110, src/phase/isotropic.cpp:62-78) */
 int  mer_phase_sample(mer_context *ctx, int32_t phase, float g, const float *wi, const float *u2, int64_t n, float *wo, float *pdf);
 int  mer_phase_eval(mer_context *ctx, int32_t phase, float g, const float *wi, const float *wo, int64_t n, float *val);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "mer_volume_download_spline", "mer_volume_destroy", "mer_film_alloc", "mer_film_zero", "mer_film_download",
     "mer_film_free", "mer_render", "mer_synchronize", "mer_last_kernel_ms", "mer_last_render_stats", "mer_counters_read",
     "mer_counters_reset", "mer_lookup_trilinear", "mer_lookup_trilinear_rgb", "mer_rif_value_grad", "mer_er_trace",
-    "mer_sample_distance", "mer_eval_transmittance", "mer_phase_sample", "mer_phase_eval", "mer_camera_rays",
+    "mer_sample_distance", "mer_connect", "mer_eval_transmittance", "mer_phase_sample", "mer_phase_eval", "mer_camera_rays",
     "mer_render_paths", "mer_rng_floats", "mer_synth_field_dev", "mer_device_free",
 ]
 
@@ -304,6 +304,12 @@ class Context:
         rec = np.empty((n, 20), np.float32)
         self._check(lib().mer_sample_distance(self.h, C.byref(scene), _fp(o), _fp(d), _fp(maxt), C.c_int64(n), C.c_uint64(seed), _fp(rec)))
         return rec
+
+    def connect(self, scene, p1, p2, seed):
+        p1 = _f32(p1); p2 = _f32(p2); n = p1.shape[0]
+        out = np.zeros((n, 12), np.float32)
+        self._check(lib().mer_connect(self.h, C.byref(scene), _fp(p1), _fp(p2), C.c_int64(n), C.c_uint64(seed), _fp(out)))
+        return out
 
     def eval_transmittance(self, scene, o, d, maxt, seed):
         o = _f32(o); d = _f32(d); maxt = _f32(maxt); n = o.shape[0]

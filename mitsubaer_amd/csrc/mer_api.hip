@@ -676,6 +676,25 @@ int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0,
     return 0;
 }
 
+int mer_connect(mer_context *ctx, const mer_scene_desc *scene, const float *p1, const float *p2, int64_t n, uint64_t seed, float *out) {
+    Params P;
+    if (make_params(ctx, scene, P)) return 1;
+    if (scene->rif_mode == MER_RIF_CONST) return fail(ctx, "mer_connect needs a RIF volume");
+    P.seed = seed;
+    DevBuf a(ctx), b(ctx), r(ctx);
+    if (a.upload(p1, n * 12) || b.upload(p2, n * 12) || r.alloc(n * 48)) return 1;
+    int rifk = scene->rif_mode;
+    if (scene->rif_mode == MER_RIF_TRILINEAR) {
+        if (P.rif.layout == MER_LAYOUT_CELL8) rifk = P.rif.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
+        else rifk = P.rif.buf_bytes ? RIFK_DENSE_BUF : MER_RIF_TRILINEAR;
+    }
+#define MER_CONNECT_CASE(R) if (rifk == R) hipLaunchKernelGGL((connect_kernel<R>), dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), n, r.as<float>());
+    MER_CONNECT_CASE(MER_RIF_TRILINEAR) MER_CONNECT_CASE(MER_RIF_BSPLINE3) MER_CONNECT_CASE(RIFK_DENSE_BUF) MER_CONNECT_CASE(RIFK_CELL8) MER_CONNECT_CASE(RIFK_CELL8_BUF)
+#undef MER_CONNECT_CASE
+    HIP_CHECK(ctx, hipGetLastError());
+    return r.download(out, n * 48);
+}
+
 int mer_sample_distance(mer_context *ctx, const mer_scene_desc *scene, const float *o, const float *d, const float *maxt, int64_t n,
                         uint64_t seed, float *rec) {
     Params P;

@@ -1,0 +1,288 @@
+// mer_connect.hpp -- K_connect: curved-ray connection p1 -> p2 through the refractive-index field.
+//
+// Reference: HeterogeneousRefractiveMedium::eval -> makeDirectConnections -> computefdfBDPT / er_derivativestep /
+// computePathLengthsTillClosestP2 (src/medium/heterogeneousrefractive.cpp:571-640, 798-1030, 1087-1163).  The shooting
+// problem "find the initial optical momentum v0 (|v0| = n(p1)) whose eikonal ray passes through p2" is solved per lane:
+// residual r(v0) = p(t*) - p2 at the closest approach t* (sign change of (p-p2).v, bisected), analytic Jacobian from the
+// 3x3 sensitivities dp/dv0, dv/dv0 integrated with the Hessian of n, multi-restart with Russian roulette and the
+// (iterations-1) solution-count weight exactly as the reference.  The reference minimises with Ceres LINE_SEARCH/BFGS
+// (un-vendored, unpinned); here a Levenberg-damped Gauss-Newton on the same residual/Jacobian -- parity unpinned for the
+// iterates, pinned on the converged ray.  Both end points must lie inside the medium shape: the boundary branch (Snell
+// refraction + its Jacobian, :873-919) belongs to the hdielectric boundary, a "next" row.
+#pragma once
+#include "mer_walk.hpp"
+
+namespace mer {
+
+struct m33 {
+    float m[3][3];
+    __device__ __forceinline__ m33() {}
+    __device__ __forceinline__ explicit m33(float d) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) m[i][j] = i == j ? d : 0.0f;
+    }
+};
+__device__ __forceinline__ m33 outer(f3 a, f3 b) {            // Matrix3x3(v1, v2): include/mitsuba/core/matrix.h:716-720
+    m33 r; const float A[3] = {a.x, a.y, a.z}, B[3] = {b.x, b.y, b.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = A[i] * B[j];
+    return r;
+}
+__device__ __forceinline__ m33 mul(const m33 &a, const m33 &b) {
+    m33 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { float s = 0; for (int k = 0; k < 3; k++) s += a.m[i][k] * b.m[k][j]; r.m[i][j] = s; }
+    return r;
+}
+__device__ __forceinline__ m33 scale(const m33 &a, float s) { m33 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = a.m[i][j] * s;
+    return r; }
+__device__ __forceinline__ m33 add(const m33 &a, const m33 &b) { m33 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = a.m[i][j] + b.m[i][j];
+    return r; }
+__device__ __forceinline__ f3 premult(const m33 &M, f3 v) {   // matrix.h:640-644: v^T M
+    return f3(v.x * M.m[0][0] + v.y * M.m[1][0] + v.z * M.m[2][0], v.x * M.m[0][1] + v.y * M.m[1][1] + v.z * M.m[2][1],
+              v.x * M.m[0][2] + v.y * M.m[1][2] + v.z * M.m[2][2]);
+}
+
+// Second-derivative B-spline weights (include/mitsuba/core/basisspline.h:91-97: |x|<=1: 3|x|-2 ; 1<|x|<=2: 2-|x|)
+__device__ __forceinline__ void bspline_weights2(float t, float d2[4]) {
+    d2[0] = 2.0f - (t + 1.0f); d2[1] = 3.0f * t - 2.0f; d2[2] = 3.0f * (1.0f - t) - 2.0f; d2[3] = 2.0f - (2.0f - t);
+}
+
+// Spline<3>::valueGradientAndHessian (basisspline.h:539-606) / Hessian of the trilinear interpolant (mixed terms only)
+template <int RIF>
+__device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, f3 p, float &val, f3 &grad, m33 &H) {
+    if (RIF == MER_RIF_BSPLINE3) {
+        const float px = (p.x - g.bmin[0]) * g.s[0], py = (p.y - g.bmin[1]) * g.s[1], pz = (p.z - g.bmin[2]) * g.s[2];
+        const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
+        float wx[4], dx[4], ex[4], wy[4], dy[4], ey[4], wz[4], dz[4], ez[4];
+        bspline_weights(px - flx, wx, dx); bspline_weights2(px - flx, ex);
+        bspline_weights(py - fly, wy, dy); bspline_weights2(py - fly, ey);
+        bspline_weights(pz - flz, wz, dz); bspline_weights2(pz - flz, ez);
+        int ix = min(max((int) flx - 1, 0), g.res[0] - 4), iy = min(max((int) fly - 1, 0), g.res[1] - 4), iz = min(max((int) flz - 1, 0), g.res[2] - 4);
+        const float *C = g.coeff + ((size_t) iz * g.res[1] + iy) * g.res[0] + ix;
+        const int sy = g.res[0], sz = g.res[0] * g.res[1];
+        float f = 0, gx = 0, gy = 0, gz = 0, hxx = 0, hyy = 0, hzz = 0, hxy = 0, hyz = 0, hzx = 0;
+        for (int k = 0; k < 4; k++)
+            for (int j = 0; j < 4; j++) {
+                const float *row = C + k * sz + j * sy;
+                const float c0 = row[0], c1 = row[1], c2 = row[2], c3 = row[3];
+                const float r0 = c0 * wx[0] + c1 * wx[1] + c2 * wx[2] + c3 * wx[3];
+                const float r1 = c0 * dx[0] + c1 * dx[1] + c2 * dx[2] + c3 * dx[3];
+                const float r2 = c0 * ex[0] + c1 * ex[1] + c2 * ex[2] + c3 * ex[3];
+                f += r0 * wy[j] * wz[k];
+                gx += r1 * wy[j] * wz[k]; gy += r0 * dy[j] * wz[k]; gz += r0 * wy[j] * dz[k];
+                hxx += r2 * wy[j] * wz[k]; hyy += r0 * ey[j] * wz[k]; hzz += r0 * wy[j] * ez[k];
+                hxy += r1 * dy[j] * wz[k]; hyz += r0 * dy[j] * dz[k]; hzx += r1 * wy[j] * dz[k];
+            }
+        val = f; grad = f3(gx * g.s[0], gy * g.s[1], gz * g.s[2]);
+        H.m[0][0] = hxx * g.s[0] * g.s[0]; H.m[1][1] = hyy * g.s[1] * g.s[1]; H.m[2][2] = hzz * g.s[2] * g.s[2];
+        H.m[0][1] = H.m[1][0] = hxy * g.s[0] * g.s[1]; H.m[1][2] = H.m[2][1] = hyz * g.s[1] * g.s[2]; H.m[0][2] = H.m[2][0] = hzx * g.s[2] * g.s[0];
+    } else {
+        CellCache cc; cc.reset();
+        trilinear_value_grad<RIF>(g, cc, p, val, grad);
+        const float fx = __builtin_fmaf(g.s[0], p.x, g.t[0]) - cc.cx, fy = __builtin_fmaf(g.s[1], p.y, g.t[1]) - cc.cy,
+                    fz = __builtin_fmaf(g.s[2], p.z, g.t[2]) - cc.cz;
+        const float hxy = ((cc.d011 - cc.d010 - cc.d001 + cc.d000) * (1 - fz) + (cc.d111 - cc.d110 - cc.d101 + cc.d100) * fz) * g.s[0] * g.s[1];
+        const float hyz = ((cc.d110 - cc.d100 - cc.d010 + cc.d000) * (1 - fx) + (cc.d111 - cc.d101 - cc.d011 + cc.d001) * fx) * g.s[1] * g.s[2];
+        const float hzx = ((cc.d101 - cc.d100 - cc.d001 + cc.d000) * (1 - fy) + (cc.d111 - cc.d110 - cc.d011 + cc.d010) * fy) * g.s[2] * g.s[0];
+        H = m33(0.0f);
+        H.m[0][1] = H.m[1][0] = hxy; H.m[1][2] = H.m[2][1] = hyz; H.m[0][2] = H.m[2][0] = hzx;
+    }
+}
+
+template <int RIF> struct Connector {
+    const Params &P;
+    float tol, rrweight; int precision, maxIter, maxSteps;
+    __device__ Connector(const Params &p) : P(p) {
+        tol = 1e-6f; rrweight = 1e-2f; precision = 3; maxIter = 20;                 // :209-213, :217
+        float diag = 0;
+        for (int i = 0; i < 3; i++) diag += (p.sc.bmax[i] - p.sc.bmin[i]) * (p.sc.bmax[i] - p.sc.bmin[i]);
+        if (p.sc.boundary == MER_BOUNDARY_SPHERE) diag = 4 * p.sc.sph_radius * p.sc.sph_radius;
+        maxSteps = min(100000, (int) (4 * sqrtf(diag) / p.sc.stepsize) + 16);        // the reference allows 1e5 (:829)
+    }
+    __device__ float rif_value(f3 p) const { float n; f3 g; CellCache cc; cc.reset(); rif_value_grad<RIF>(P.rif, cc, p, n, g); return n; }
+
+    // er_derivativestep (:798-814)
+    __device__ void dstep(f3 &p, f3 &v, m33 &dp, m33 &dv, float h) const {
+        float n; f3 G; m33 H;
+        rif_value_grad_hess<RIF>(P.rif, p, n, G, H);
+        v = v + 0.5f * h * G;
+        dv = add(dv, scale(mul(H, dp), 0.5f * h));
+        p = p + h * v / n;
+        rif_value_grad_hess<RIF>(P.rif, p, n, G, H);
+        const float invn = 1.0f / n;
+        dp = add(dp, scale(add(scale(mul(outer(v, G), dp), -invn * invn), scale(dv, invn)), h));
+        v = v + 0.5f * h * G;
+        dv = add(dv, scale(mul(H, dp), 0.5f * h));
+    }
+    // computefdfBDPT (:816-939), inside-shape branch; J[r][c] = d error_r / d v0_c
+    __device__ bool computefdf(f3 v_i, f3 p1, f3 p2, f3 &error, m33 &J) const {
+        m33 dp(0.0f), dv(1.0f);
+        error = p1 - p2; J = m33(0.0f);
+        if (RIF == MER_RIF_BSPLINE3 && !inside_volume_limits(P.rif, p1)) return false;
+        float h = P.sc.stepsize;
+        int nBisect = (int) ceilf((float) precision / 0.30102999566f);
+        f3 p = p1, oldp, v = v_i, oldv; m33 olddp, olddv;
+        const bool signOld = dot(p - p2, v) < 0.0f; bool signNew;
+        const float r = rif_value(p);
+        const float n1 = sqrtf(dot(v_i, v_i)), n2 = n1 * n1, n3 = n2 * n1;
+        { m33 a(n2); const m33 o = outer(v, v);
+          for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.m[i][j] -= o.m[i][j];
+          dv = mul(scale(a, r / n3), dv); }
+        v = v / n1 * r;
+        bool found = false;
+        for (int i = 0; i < maxSteps; i++) {
+            oldp = p; oldv = v; olddp = dp; olddv = dv;
+            dstep(p, v, dp, dv, h);
+            signNew = dot(p - p2, v) < 0.0f;
+            if (signNew != signOld) {
+                while (nBisect > 0) {
+                    nBisect--;
+                    p = oldp; v = oldv; dp = olddp; dv = olddv;
+                    h = h / 2;
+                    dstep(p, v, dp, dv, h);
+                    signNew = dot(p - p2, v) < 0.0f;
+                    if (signNew == signOld) { oldp = p; oldv = v; olddp = dp; olddv = dv; }
+                }
+                found = true;
+                break;
+            } else if (!inside_shape(P.sc, p)) return false;
+        }
+        if (!found) return false;
+        float rr; f3 dvdt; CellCache cc; cc.reset();
+        rif_value_grad<RIF>(P.rif, cc, p, rr, dvdt);
+        const f3 dpdt = v / rr;
+        const f3 dtstar = -(premult(dp, v) + premult(dv, p - p2)) / (dot(v, dpdt) + dot(p - p2, dvdt));
+        J = add(dp, outer(dpdt, dtstar));
+        error = p - p2;
+        return true;
+    }
+    // stand-in for ceres::Solve: damped Gauss-Newton, <= 20 iterations
+    __device__ float solve(f3 &x, f3 p1, f3 p2) const {
+        f3 e; m33 J;
+        bool ok = computefdf(x, p1, p2, e, J);
+        float cost = 0.5f * dot(e, e), lambda = 1e-4f;
+        for (int it = 0; it < maxIter && ok && cost >= tol * 1e-3f; ++it) {
+            float A[3][3], b[3]; const float E[3] = {e.x, e.y, e.z};
+            for (int i = 0; i < 3; i++) { b[i] = 0; for (int k = 0; k < 3; k++) b[i] -= J.m[k][i] * E[k];
+                for (int j = 0; j < 3; j++) { A[i][j] = 0; for (int k = 0; k < 3; k++) A[i][j] += J.m[k][i] * J.m[k][j]; } }
+            bool improved = false;
+            for (int tries = 0; tries < 6 && !improved; ++tries) {
+                float M[3][3];
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = A[i][j] + (i == j ? lambda * (A[i][i] + 1e-12f) : 0.0f);
+                const float det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                                  M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+                if (det == 0.0f || !isfinite(det)) { lambda *= 10; continue; }
+                float d[3];
+                d[0] = (b[0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (b[1] * M[2][2] - M[1][2] * b[2]) + M[0][2] * (b[1] * M[2][1] - M[1][1] * b[2])) / det;
+                d[1] = (M[0][0] * (b[1] * M[2][2] - M[1][2] * b[2]) - b[0] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * b[2] - b[1] * M[2][0])) / det;
+                d[2] = (M[0][0] * (M[1][1] * b[2] - b[1] * M[2][1]) - M[0][1] * (M[1][0] * b[2] - b[1] * M[2][0]) + b[0] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
+                f3 xn(x.x + d[0], x.y + d[1], x.z + d[2]), en; m33 Jn;
+                const bool okn = computefdf(xn, p1, p2, en, Jn);
+                const float cn = 0.5f * dot(en, en);
+                if (okn && cn < cost) { x = xn; e = en; J = Jn; cost = cn; lambda = fmaxf(lambda * 0.1f, 1e-9f); improved = true; }
+                else lambda *= 10;
+            }
+            if (!improved) break;
+        }
+        return ok ? cost : MER_INF;
+    }
+    // the reference's own Verlet step (:662-669)
+    __device__ void verlet(f3 &p, f3 &v, float h) const {
+        float n, n2; f3 G, G2; CellCache cc; cc.reset();
+        rif_value_grad<RIF>(P.rif, cc, p, n, G);
+        v = v + 0.5f * h * G;
+        p = p + h * v / n;
+        rif_value_grad<RIF>(P.rif, cc, p, n2, G2);
+        v = v + 0.5f * h * G2;
+    }
+    // computePathLengthsTillClosestP2 (:941-1030), inside-shape branch
+    __device__ bool path_lengths(f3 p1, f3 p2, f3 dirToP2, f3 &revDir, float &optDist, float &dist) const {
+        dist = 0; optDist = 0;
+        float h = P.sc.stepsize;
+        int nBisect = (int) ceilf((float) precision / 0.30102999566f);
+        f3 p = p1, oldp, v = dirToP2, oldv;
+        const bool signOld = dot(p - p2, v) < 0.0f; bool signNew;
+        for (int i = 0; i < maxSteps; i++) {
+            oldp = p; oldv = v;
+            verlet(p, v, h);
+            signNew = dot(p - p2, v) < 0.0f;
+            if (!inside_shape(P.sc, p)) return false;
+            if (signNew != signOld) {
+                while (nBisect > 0) {
+                    nBisect--;
+                    p = oldp; v = oldv; h = h / 2;
+                    verlet(p, v, h);
+                    signNew = dot(p - p2, v) < 0.0f;
+                    if (signNew == signOld) { dist += h; optDist += h * rif_value(0.5f * (p + oldp)); oldp = p; oldv = v; }
+                }
+                break;
+            } else { dist += h; optDist += h * rif_value(0.5f * (p + oldp)); }
+        }
+        if (dot(p - p2, p - p2) > tol) return false;
+        revDir = -normalize(v);
+        return true;
+    }
+    // uniformSample (:1078-1084) with squareToUniformHemisphere (src/libcore/warp.cpp:33-41)
+    __device__ f3 uniform_sample(f3 in, Rng &rng) const {
+        f3 ax, ay;
+        coordinate_system(in, ax, ay);
+        const float u1 = rng.next1D(), u2 = rng.next1D();
+        const float z = u1, tmp = safe_sqrt(1.0f - z * z), phi = 2.0f * MER_PI * u2;
+        return (cosf(phi) * tmp) * ax + (sinf(phi) * tmp) * ay + z * in;
+    }
+    // makeDirectConnections (:1087-1163)
+    __device__ bool connect(f3 p1, f3 p2, f3 d, Rng &rng, float &weight, f3 &dirToP2, f3 &revDir, float &optDist, float &dist) const {
+        f3 tempSol(0, 0, 0);
+        int iterations = 1;
+        if (RIF == MER_RIF_BSPLINE3 && !inside_volume_limits(P.rif, p1)) return false;
+        const float RIFp = rif_value(p1);
+        for (;;) {
+            f3 x = uniform_sample(d, rng) * RIFp;
+            const float cost = solve(x, p1, p2);
+            if (cost < tol) {
+                if (iterations == 1) { iterations++; tempSol = normalize(x); }
+                else iterations++;
+                dirToP2 = normalize(x);
+                if (dot(tempSol - dirToP2, tempSol - dirToP2) < 2 * tol) break;
+            }
+            if (rng.next1D() < rrweight) weight = weight / rrweight;
+            else { dirToP2 = normalize(x); return false; }
+            if (iterations > 64) return false;
+        }
+        dirToP2 = dirToP2 * RIFp;
+        weight *= (float) (iterations - 1);
+        return path_lengths(p1, p2, dirToP2, revDir, optDist, dist);
+    }
+};
+
+// leaf kernel: out stride 12: ok, weight, dirToP2[3], revDirToP1[3], dist, opticalDist, 0, 0; RNG stream (seed, i, 0)
+template <int RIF>
+__global__ void __launch_bounds__(64) connect_kernel(const Params P, const float *p1, const float *p2, int64_t n, float *out) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng rng; rng.seed(P.seed, (uint32_t) i, 0);
+    Connector<RIF> K(P);
+    const f3 a(p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]), b(p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]);
+    float w = 1.0f, od = 0, di = 0; f3 dir(0, 0, 0), rev(0, 0, 0);
+    const bool ok = K.connect(a, b, normalize(b - a), rng, w, dir, rev, od, di);
+    float *o = out + 12 * i;
+    o[0] = ok ? 1.0f : 0.0f; o[1] = w; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z;
+    o[5] = ok ? rev.x : 0.0f; o[6] = ok ? rev.y : 0.0f; o[7] = ok ? rev.z : 0.0f; o[8] = ok ? di : 0.0f; o[9] = ok ? od : 0.0f; o[10] = o[11] = 0.0f;
+}
+
+}  // namespace mer

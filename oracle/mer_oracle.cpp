@@ -466,6 +466,30 @@ template <typename FLOAT> struct Rif {
         FLOAT x[3] = {p.x, p.y, p.z};
         return spline.gradient(x);           /* splinevolume.cpp:338-344 */
     }
+    /* splinevolume.cpp:370-376 valueGradientAndHessian; H row-major.  Trilinear: Hessian of the interpolant (only the
+       mixed terms are non-zero inside a cell) -- new, SURVEY D2. */
+    inline void valueGradientAndHessian(const V3<FLOAT> &p, FLOAT &n, V3<FLOAT> &g, FLOAT H[9], Counters &C) const {
+        C.c[ORC_C_RIF_EVALS]++;
+        for (int i = 0; i < 9; i++) H[i] = 0;
+        if (mode == ORC_RIF_CONST) { n = cst; g = V3<FLOAT>(0, 0, 0); return; }
+        if (mode == ORC_RIF_BSPLINE3) { FLOAT x[3] = {p.x, p.y, p.z}; spline.valueGradientAndHessian(x, n, g, H); return; }
+        trilinearValueGrad<FLOAT>(grid, p, n, g);
+        const Grid &G = grid;
+        const FLOAT px = std::fma((FLOAT) G.m[0][0], p.x, (FLOAT) G.m[0][3]), py = std::fma((FLOAT) G.m[1][1], p.y, (FLOAT) G.m[1][3]),
+                    pz = std::fma((FLOAT) G.m[2][2], p.z, (FLOAT) G.m[2][3]);
+        int x1 = std::min(std::max((int) std::floor(px), 0), G.res[0] - 2), y1 = std::min(std::max((int) std::floor(py), 0), G.res[1] - 2),
+            z1 = std::min(std::max((int) std::floor(pz), 0), G.res[2] - 2);
+        const FLOAT fx = px - x1, fy = py - y1, fz = pz - z1;
+        const float *D = (const float *) G.data;
+        const int base = (z1 * G.res[1] + y1) * G.res[0] + x1, sy = G.res[0], sz = G.res[0] * G.res[1];
+        const FLOAT d000 = D[base], d001 = D[base + 1], d010 = D[base + sy], d011 = D[base + sy + 1],
+                    d100 = D[base + sz], d101 = D[base + sz + 1], d110 = D[base + sz + sy], d111 = D[base + sz + sy + 1];
+        const FLOAT sx = G.m[0][0], syy = G.m[1][1], szz = G.m[2][2];
+        const FLOAT hxy = ((d011 - d010 - d001 + d000) * (1 - fz) + (d111 - d110 - d101 + d100) * fz) * sx * syy;
+        const FLOAT hyz = ((d110 - d100 - d010 + d000) * (1 - fx) + (d111 - d101 - d011 + d001) * fx) * syy * szz;
+        const FLOAT hzx = ((d101 - d100 - d001 + d000) * (1 - fy) + (d111 - d110 - d011 + d010) * fy) * szz * sx;
+        H[1] = H[3] = hxy; H[5] = H[7] = hyz; H[2] = H[6] = hzx;
+    }
 };
 
 struct Scene {
@@ -639,6 +663,16 @@ template <typename FLOAT> struct Tracer {
             opt = std::fma(h6, ns, opt);
         }
     }
+    /* heterogeneousrefractive.cpp:662-669 (the connection code always uses the reference's own Verlet step) */
+    inline void er_step_verlet(V3<FLOAT> &p, V3<FLOAT> &v, FLOAT h, FLOAT &opt) const {
+        C.c[ORC_C_STEPS]++;
+        FLOAT n; V3<FLOAT> G;
+        R.valueAndGradient(p, n, G, C);
+        v += SplineConst<FLOAT>::half() * h * G;
+        p += h * v / n;
+        v += SplineConst<FLOAT>::half() * h * R.gradient(p, C);
+        opt += h * n;
+    }
     /* heterogeneousrefractive.cpp:671-691 */
     inline bool trace(V3<FLOAT> &p, V3<FLOAT> &v, FLOAT sampledDistance, FLOAT &distSurf, FLOAT &opt) const {
         const FLOAT h = (FLOAT) S.s.stepsize;
@@ -668,6 +702,7 @@ template <typename FLOAT> struct Tracer {
         }
     }
 };
+
 
 /* ------------------------------------------------------------------ A9 phase functions */
 /* src/libcore/util.cpp:606-615 */
@@ -713,6 +748,200 @@ inline Float phaseSample(int kind, Float g, const Vec &wi, Float sx, Float sy, V
     pdf = phaseEval(kind, g, wi, wo);
     return 1.0f;
 }
+
+/* ------------------------------------------------------------------ A12 curved-ray connection (config 5)
+   heterogeneousrefractive.cpp:798-1163 restated for two points INSIDE the medium shape (the boundary branch with Snell
+   refraction and its Jacobian, :873-919,:980-1001,:1036-1074, belongs to the `hdielectric` boundary = "next" row N2 and is
+   treated as a failed connection here).  The reference minimises 0.5|r|^2 with Ceres LINE_SEARCH/BFGS (<= 20
+   iterations, function tolerance tol2); Ceres is not available (un-vendored, unpinned) => a Levenberg-damped
+   Gauss-Newton with the same analytic Jacobian stands in: PARITY UNPINNED for the iterates, checked on the converged
+   direction only. */
+template <typename FLOAT> struct M33 {
+    FLOAT m[3][3];
+    M33() {}
+    explicit M33(FLOAT d) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] = i == j ? d : 0; }
+    static M33 outer(const V3<FLOAT> &a, const V3<FLOAT> &b) {          /* Matrix3x3(v1, v2), matrix.h:716-720 */
+        M33 r; const FLOAT A[3] = {a.x, a.y, a.z}, B[3] = {b.x, b.y, b.z};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = A[i] * B[j];
+        return r;
+    }
+    M33 operator*(const M33 &o) const { M33 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { FLOAT s = 0; for (int k = 0; k < 3; k++) s += m[i][k] * o.m[k][j]; r.m[i][j] = s; } return r; }
+    M33 operator*(FLOAT s) const { M33 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[i][j] * s; return r; }
+    M33 operator+(const M33 &o) const { M33 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[i][j] + o.m[i][j]; return r; }
+    M33 operator-(const M33 &o) const { M33 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = m[i][j] - o.m[i][j]; return r; }
+    V3<FLOAT> preMult(const V3<FLOAT> &v) const {                       /* matrix.h:640-644: v^T M */
+        return V3<FLOAT>(v.x * m[0][0] + v.y * m[1][0] + v.z * m[2][0], v.x * m[0][1] + v.y * m[1][1] + v.z * m[2][1],
+                         v.x * m[0][2] + v.y * m[1][2] + v.z * m[2][2]);
+    }
+};
+
+template <typename FLOAT> struct Connector {
+    const Scene &S; const Rif<FLOAT> &R; Counters &C; Pcg32 &rng;
+    FLOAT tol, rrweight; int precision, maxIter;
+    Connector(const Scene &s, Counters &c, Pcg32 &r) : S(s), R(s.rif<FLOAT>()), C(c), rng(r) {
+        tol = (FLOAT) 1e-6; rrweight = (FLOAT) 1e-2; precision = 3; maxIter = 20;     /* :209-213, :217 */
+    }
+    static M33<FLOAT> fromH(const FLOAT H[9]) { M33<FLOAT> r; for (int i = 0; i < 9; i++) r.m[i / 3][i % 3] = H[i]; return r; }
+    int maxSteps() const {
+        /* the reference allows 1e5 steps; bound by what a ray can travel inside the shape */
+        FLOAT diag = 0; for (int i = 0; i < 3; i++) diag += (S.s.bmax[i] - S.s.bmin[i]) * (S.s.bmax[i] - S.s.bmin[i]);
+        if (S.s.boundary == ORC_BOUNDARY_SPHERE) diag = 4 * S.s.sph_radius * S.s.sph_radius;
+        return std::min(100000, (int) (4 * std::sqrt(diag) / S.s.stepsize) + 16);
+    }
+    /* :798-814 */
+    void er_derivativestep(V3<FLOAT> &p, V3<FLOAT> &v, M33<FLOAT> &dpdv0, M33<FLOAT> &dvdv0, FLOAT h) const {
+        FLOAT n, invn, H[9]; V3<FLOAT> G;
+        R.valueGradientAndHessian(p, n, G, H, C);
+        v += SplineConst<FLOAT>::half() * h * G;
+        dvdv0 = dvdv0 + (fromH(H) * dpdv0) * (SplineConst<FLOAT>::half() * h);
+        p += h * v / n;
+        R.valueGradientAndHessian(p, n, G, H, C);
+        invn = 1 / n;
+        dpdv0 = dpdv0 + ((M33<FLOAT>::outer(v, G) * dpdv0) * (-invn * invn) + dvdv0 * invn) * h;
+        v += SplineConst<FLOAT>::half() * h * G;
+        dvdv0 = dvdv0 + (fromH(H) * dpdv0) * (SplineConst<FLOAT>::half() * h);
+        C.c[ORC_C_STEPS]++;
+    }
+    /* :816-939 (inside-shape branch).  J[r][c] = d error_r / d v0_c.  Returns false when the residual has no derivative. */
+    bool computefdf(const V3<FLOAT> &v_i, const V3<FLOAT> &p1, const V3<FLOAT> &p2, V3<FLOAT> &error, M33<FLOAT> &J) const {
+        M33<FLOAT> dpdv0((FLOAT) 0), dvdv0((FLOAT) 1);
+        error = p1 - p2; J = M33<FLOAT>((FLOAT) 0);
+        if (!R.insideVolumeLimits(p1)) return false;
+        FLOAT h = (FLOAT) S.s.stepsize;
+        long nBisect = (long) std::ceil(precision / std::log10(2.0));
+        V3<FLOAT> p = p1, oldp, v = v_i, oldv;
+        M33<FLOAT> olddp, olddv;
+        bool signOld = std::signbit(dot(p - p2, v)), signNew;
+        FLOAT r = R.value(p, C);
+        const FLOAT n1 = std::sqrt(dot(v_i, v_i)), n2 = n1 * n1, n3 = n2 * n1;
+        dvdv0 = ((M33<FLOAT>(n2) - M33<FLOAT>::outer(v, v)) * (r / n3)) * dvdv0;
+        v = v / n1 * r;
+        const int ms = maxSteps();
+        bool found = false;
+        for (int i = 0; i < ms; i++) {
+            oldp = p; oldv = v; olddp = dpdv0; olddv = dvdv0;
+            er_derivativestep(p, v, dpdv0, dvdv0, h);
+            signNew = std::signbit(dot(p - p2, v));
+            if (signNew != signOld) {
+                while (nBisect > 0) {
+                    nBisect--;
+                    p = oldp; v = oldv; dpdv0 = olddp; dvdv0 = olddv;
+                    h = h / 2;
+                    er_derivativestep(p, v, dpdv0, dvdv0, h);
+                    signNew = std::signbit(dot(p - p2, v));
+                    if (signNew == signOld) { oldp = p; oldv = v; olddp = dpdv0; olddv = dvdv0; }
+                }
+                found = true;
+                break;
+            } else if (!S.insideShape(p)) return false;       /* boundary branch: not built (N2) */
+        }
+        if (!found) return false;
+        V3<FLOAT> dvdt; FLOAT rr;
+        R.valueAndGradient(p, rr, dvdt, C);
+        const V3<FLOAT> dpdt = v / rr;
+        const V3<FLOAT> dtstar = -(dpdv0.preMult(v) + dvdv0.preMult(p - p2)) / (dot(v, dpdt) + dot(p - p2, dvdt));
+        J = dpdv0 + M33<FLOAT>::outer(dpdt, dtstar);
+        error = p - p2;
+        return true;
+    }
+    /* stand-in for ceres::Solve (LINE_SEARCH/BFGS, <= 20 iterations, function_tolerance tol2): damped Gauss-Newton */
+    FLOAT solve(V3<FLOAT> &x, const V3<FLOAT> &p1, const V3<FLOAT> &p2) const {
+        V3<FLOAT> e; M33<FLOAT> J;
+        bool ok = computefdf(x, p1, p2, e, J);
+        FLOAT cost = (FLOAT) 0.5 * dot(e, e), lambda = (FLOAT) 1e-4;
+        for (int it = 0; it < maxIter && ok && cost >= tol * (FLOAT) 1e-3; ++it) {
+            /* (J^T J + lambda I) d = -J^T e */
+            FLOAT A[3][3], b[3];
+            const FLOAT E[3] = {e.x, e.y, e.z};
+            for (int i = 0; i < 3; i++) { b[i] = 0; for (int k = 0; k < 3; k++) b[i] -= J.m[k][i] * E[k];
+                for (int j = 0; j < 3; j++) { A[i][j] = 0; for (int k = 0; k < 3; k++) A[i][j] += J.m[k][i] * J.m[k][j]; } }
+            bool improved = false;
+            for (int tries = 0; tries < 6 && !improved; ++tries) {
+                FLOAT M[3][3]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = A[i][j] + (i == j ? lambda * (A[i][i] + (FLOAT) 1e-12) : 0);
+                const FLOAT det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                                  M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+                if (det == 0 || !std::isfinite(det)) { lambda *= 10; continue; }
+                FLOAT d[3];
+                d[0] = (b[0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (b[1] * M[2][2] - M[1][2] * b[2]) + M[0][2] * (b[1] * M[2][1] - M[1][1] * b[2])) / det;
+                d[1] = (M[0][0] * (b[1] * M[2][2] - M[1][2] * b[2]) - b[0] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * b[2] - b[1] * M[2][0])) / det;
+                d[2] = (M[0][0] * (M[1][1] * b[2] - b[1] * M[2][1]) - M[0][1] * (M[1][0] * b[2] - b[1] * M[2][0]) + b[0] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
+                V3<FLOAT> xn(x.x + d[0], x.y + d[1], x.z + d[2]), en; M33<FLOAT> Jn;
+                const bool okn = computefdf(xn, p1, p2, en, Jn);
+                const FLOAT cn = (FLOAT) 0.5 * dot(en, en);
+                if (okn && cn < cost) { x = xn; e = en; J = Jn; cost = cn; lambda = std::max(lambda * (FLOAT) 0.1, (FLOAT) 1e-9); improved = true; }
+                else lambda *= 10;
+            }
+            if (!improved) break;
+        }
+        return ok ? cost : std::numeric_limits<FLOAT>::infinity();
+    }
+    /* :941-1030 (inside-shape branch) */
+    bool computePathLengths(const V3<FLOAT> &p1, const V3<FLOAT> &p2, const V3<FLOAT> &dirToP2, V3<FLOAT> &revDir, FLOAT &optDist, FLOAT &dist) const {
+        dist = 0; optDist = 0;
+        FLOAT h = (FLOAT) S.s.stepsize;
+        long nBisect = (long) std::ceil(precision / std::log10(2.0));
+        V3<FLOAT> p = p1, oldp, v = dirToP2, oldv;
+        const bool signOld = std::signbit(dot(p - p2, v)); bool signNew;
+        Tracer<FLOAT> T(S, C);
+        FLOAT dummy = 0;
+        const int ms = maxSteps();
+        const int saved = S.s.stepper;
+        for (int i = 0; i < ms; i++) {
+            oldp = p; oldv = v;
+            T.er_step_verlet(p, v, h, dummy);
+            signNew = std::signbit(dot(p - p2, v));
+            if (!S.insideShape(p)) return false;
+            if (signNew != signOld) {
+                while (nBisect > 0) {
+                    nBisect--;
+                    p = oldp; v = oldv; h = h / 2;
+                    T.er_step_verlet(p, v, h, dummy);
+                    signNew = std::signbit(dot(p - p2, v));
+                    if (signNew == signOld) { dist += h; optDist += h * R.value(SplineConst<FLOAT>::half() * (p + oldp), C); oldp = p; oldv = v; }
+                }
+                break;
+            } else { dist += h; optDist += h * R.value(SplineConst<FLOAT>::half() * (p + oldp), C); }
+        }
+        (void) saved;
+        if (dot(p - p2, p - p2) > tol) return false;
+        revDir = -normalize(v);
+        return true;
+    }
+    /* :1078-1084 */
+    V3<FLOAT> uniformSample(const V3<FLOAT> &in) {
+        Vec a((Float) in.x, (Float) in.y, (Float) in.z), ax, ay;
+        coordinateSystem(a, ax, ay);
+        const Float u1 = rng.next1D(), u2 = rng.next1D();
+        const Float z = u1, tmp = safe_sqrt(1.0f - z * z), phi = 2.0f * M_PI_F * u2;          /* warp.cpp:33-41 */
+        const Vec t(std::cos(phi) * tmp, std::sin(phi) * tmp, z);
+        return V3<FLOAT>((FLOAT) t.x * V3<FLOAT>(ax) + (FLOAT) t.y * V3<FLOAT>(ay) + (FLOAT) t.z * in);
+    }
+    /* :1087-1163 */
+    bool makeDirectConnections(const V3<FLOAT> &p1, const V3<FLOAT> &p2, const V3<FLOAT> &d, FLOAT &weight, V3<FLOAT> &dirToP2,
+                               V3<FLOAT> &revDir, FLOAT &optDist, FLOAT &dist) {
+        V3<FLOAT> tempSol(0, 0, 0);
+        int iterations = 1;
+        if (!R.insideVolumeLimits(p1)) return false;
+        const FLOAT RIFp = R.value(p1, C);
+        while (true) {
+            V3<FLOAT> x = uniformSample(d) * RIFp;
+            const FLOAT cost = solve(x, p1, p2);
+            if (cost < tol) {
+                if (iterations == 1) { iterations++; tempSol = normalize(x); }
+                else iterations++;
+                dirToP2 = normalize(x);
+                if (dot(tempSol - dirToP2, tempSol - dirToP2) < 2 * tol) break;
+            }
+            if (rng.next1D() < (Float) rrweight) weight = weight / rrweight;
+            else { dirToP2 = normalize(x); return false; }
+            if (iterations > 64) return false;       /* safety bound (the reference has none) */
+        }
+        dirToP2 = dirToP2 * RIFp;
+        weight *= (iterations - 1);
+        return computePathLengths(p1, p2, dirToP2, revDir, optDist, dist);
+    }
+};
+
 
 /* ------------------------------------------------------------------ media */
 struct Walker {
@@ -1230,6 +1459,30 @@ void orc_camera_rays(const orc_scene *s, const float *pos2, int64_t n, float *o,
 void orc_filter_table(int32_t rfilter, float param, float *values33, float *radius, float *scale) {
     Scene::filterTable(rfilter, param, values33, *radius, *scale);
 }
+/* A12 leaf: connect p1 -> p2 through the RIF.  out stride 12: ok, weight, dirToP2(3, momentum at p1), revDirToP1(3), dist, opticalDist, 0, 0 */
+void orc_connect(const orc_scene *s, const float *p1, const float *p2, int64_t n, uint64_t seed, float *out) {
+    SceneHolder H(s); Counters C;
+    for (int64_t i = 0; i < n; i++) {
+        Pcg32 rng; rng.seed(seed, (uint32_t) i, 0);
+        float *o = out + 12 * i;
+        for (int k = 0; k < 12; k++) o[k] = 0;
+        const Vec a(p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]), b(p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]);
+        if (s->rif_double) {
+            Connector<double> K(H.S, C, rng);
+            V3<double> A(a), B(b), dir, rev; double w = 1, od = 0, di = 0;
+            const bool ok = K.makeDirectConnections(A, B, normalize(B - A), w, dir, rev, od, di);
+            o[0] = ok; o[1] = (float) w; o[2] = (float) dir.x; o[3] = (float) dir.y; o[4] = (float) dir.z;
+            if (ok) { o[5] = (float) rev.x; o[6] = (float) rev.y; o[7] = (float) rev.z; o[8] = (float) di; o[9] = (float) od; }
+        } else {
+            Connector<float> K(H.S, C, rng);
+            V3<float> A(a), B(b), dir, rev; float w = 1, od = 0, di = 0;
+            const bool ok = K.makeDirectConnections(A, B, normalize(B - A), w, dir, rev, od, di);
+            o[0] = ok; o[1] = w; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z;
+            if (ok) { o[5] = rev.x; o[6] = rev.y; o[7] = rev.z; o[8] = di; o[9] = od; }
+        }
+    }
+}
+
 void orc_rng_floats(uint64_t seed, uint32_t pixel, uint32_t sample, int32_t n, float *out) {
     Pcg32 r; r.seed(seed, pixel, sample);
     for (int i = 0; i < n; i++) out[i] = r.next1D();

@@ -104,6 +104,8 @@ void orc_sample_distance(const orc_scene *s, const float *o, const float *d, con
 /* A4: evalTransmittance over straight segment [0,maxt] (or curved-to-boundary when RIF != const) */
 void orc_eval_transmittance(const orc_scene *s, const float *o, const float *d, const float *maxt, int64_t n,
                             uint64_t seed, float *out_tr /* n*3 */);
+/* A12: curved-ray connection p1 -> p2 (both inside the shape); out stride 12: ok, weight, dirToP2[3], revDirToP1[3], dist, opticalDist, 0, 0 */
+void orc_connect(const orc_scene *s, const float *p1, const float *p2, int64_t n, uint64_t seed, float *out);
 /* A9 */
 void orc_phase_sample(int32_t phase, float g, const float *wi, const float *u2, int64_t n, float *wo, float *pdf);
 void orc_phase_eval(int32_t phase, float g, const float *wi, const float *wo, int64_t n, float *val);

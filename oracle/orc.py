@@ -212,6 +212,15 @@ def eval_transmittance(p, o, d, maxt, seed):
     return out
 
 
+def connect(p, p1, p2, seed):
+    s, keep = make_scene(p)
+    p1 = np.ascontiguousarray(p1, np.float32); p2 = np.ascontiguousarray(p2, np.float32)
+    n = p1.shape[0]
+    out = np.zeros((n, 12), np.float32)
+    lib().orc_connect(C.byref(s), _fp(p1), _fp(p2), C.c_int64(n), C.c_uint64(seed), _fp(out))
+    return out
+
+
 def phase_sample(kind, g, wi, u2):
     wi = np.ascontiguousarray(wi, np.float32); u2 = np.ascontiguousarray(u2, np.float32)
     n = wi.shape[0]

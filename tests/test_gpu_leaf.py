@@ -183,3 +183,34 @@ def test_eval_transmittance(ctx, orc, est, curved):
     assert close.mean() > 0.995
     # both estimators are unbiased for exp(-integral sigma_t): compare means (MC tolerance)
     assert abs(a.mean() - b.mean()) < 5e-3
+
+
+@pytest.mark.parametrize("kind", ["bspline", "trilinear"])
+def test_curved_ray_connection(ctx, orc, kind):
+    """A12: the shooting solver finds the optical momentum at p1 whose eikonal ray passes through p2.  Parity with the
+    reference's Ceres iterates is unpinned; pinned here: the converged ray (direction, length, optical
+    length) against the oracle's solver, and the physical property itself -- tracing the found ray lands on p2."""
+    p = scenes.bspline_scene(N=24) if kind == "bspline" else scenes.curved_scene(N=24, rif="radial", stepper=P.STEP_VERLET)
+    sc, vols = ctx.upload_scene(p)
+    rng = np.random.RandomState(0)
+    n = 512
+    p1 = rng.uniform(-0.6, 0.6, (n, 3)).astype(np.float32); p2 = rng.uniform(-0.6, 0.6, (n, 3)).astype(np.float32)
+    a = ctx.connect(sc, p1, p2, 1)
+    b = orc.connect(p, p1, p2, 1)
+    ok = (a[:, 0] == 1) & (b[:, 0] == 1)
+    assert (a[:, 0] == 1).mean() > 0.85 and (a[:, 0] == b[:, 0]).mean() > 0.93
+    da = a[ok, 2:5] / np.linalg.norm(a[ok, 2:5], axis=1, keepdims=True)
+    db = b[ok, 2:5] / np.linalg.norm(b[ok, 2:5], axis=1, keepdims=True)
+    assert np.abs(da - db).max() < 5e-3                         # both solvers stop at |r|^2/2 < 1e-6
+    assert np.abs(a[ok, 8] - b[ok, 8]).max() < 5e-3 and np.abs(a[ok, 9] - b[ok, 9]).max() < 1e-2
+    assert np.all(a[ok, 1] >= 1.0)                              # weight = (#agreeing solutions) / RR probability
+    # the connection is a ray: re-trace it with the reference's Verlet trace() and land on p2
+    q = p.copy(stepper=P.STEP_VERLET)
+    scq, _ = ctx.upload_scene(q)
+    op, ov, ds, oo, okk = ctx.er_trace(scq, p1[ok], da, a[ok, 8])
+    assert np.abs(op - p2[ok]).max() < 3e-3                     # sqrt(2 tol2) = 1.4e-3 plus bisection granularity
+    # curved, not straight: the arc is longer than the chord and the launch direction differs from it
+    chord = np.linalg.norm(p2[ok] - p1[ok], axis=1)
+    assert (a[ok, 8] >= chord - 5e-3).all()                      # h = 0.043 here; closest approach within sqrt(2 tol2) of p2
+    n1, _ = ctx.rif_value_grad(vols[-1], P.RIF_BSPLINE3 if kind == "bspline" else P.RIF_TRILINEAR, p1[ok])
+    assert np.abs(np.linalg.norm(a[ok, 2:5], axis=1) - n1).max() < 1e-4       # |v0| = n(p1)
