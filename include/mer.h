@@ -75,6 +75,9 @@ typedef struct {
     /* emitter `constant` radiance; medium emission per unit density (config 5) */
     float   env_radiance[3];
     float   emission[3];
+    /* emitter `point` (src/emitters/point.cpp): position + radiant intensity; all-zero intensity = none.  With curved rays the
+       emitter must lie inside the medium shape and is reached by mer_connect's shooting solver. */
+    float   point_position[3], point_intensity[3];
 } mer_scene_desc;
 
 /* which part of the image-sample space this call renders (multi-GPU sharding):

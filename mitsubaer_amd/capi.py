@@ -49,6 +49,7 @@ class SceneDesc(C.Structure):
         ("phase", C.c_int32), ("g", C.c_float),
         ("tr_estimator", C.c_int32),
         ("env_radiance", C.c_float * 3), ("emission", C.c_float * 3),
+        ("point_position", C.c_float * 3), ("point_intensity", C.c_float * 3),
     ]
 
 
@@ -200,6 +201,7 @@ class Context:
         s.tr_estimator = p.tr_estimator
         s.env_radiance[:] = p.env_radiance
         s.emission[:] = p.emission
+        s.point_position[:] = p.point_position; s.point_intensity[:] = p.point_intensity
         return s
 
     def upload_scene(self, p, layout=LAYOUT_DENSE, rif_layout=None):

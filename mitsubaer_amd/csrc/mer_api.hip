@@ -187,6 +187,17 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P) {
     } else if (sc->boundary == MER_BOUNDARY_SPHERE) {
         if (!(sc->sph_radius > 0)) return fail(ctx, "medium shape: sphere radius must be positive");
     } else return fail(ctx, "unknown medium boundary");
+    {
+        const bool has_point = sc->point_intensity[0] != 0 || sc->point_intensity[1] != 0 || sc->point_intensity[2] != 0;
+        for (int i = 0; i < 3; i++) if (sc->point_intensity[i] < 0 || sc->env_radiance[i] < 0) return fail(ctx, "emitter radiance / intensity must be non-negative");
+        if (has_point && sc->rif_mode != MER_RIF_CONST) {
+            // curved-ray connections are solved for end points inside the medium shape only (boundary refraction = next row N2)
+            bool inside = true;
+            if (sc->boundary == MER_BOUNDARY_AABB) { for (int i = 0; i < 3; i++) inside = inside && sc->point_position[i] > sc->bmin[i] && sc->point_position[i] < sc->bmax[i]; }
+            else { float d2 = 0; for (int i = 0; i < 3; i++) d2 += (sc->point_position[i] - sc->sph_center[i]) * (sc->point_position[i] - sc->sph_center[i]); inside = d2 < sc->sph_radius * sc->sph_radius; }
+            if (!inside) return fail(ctx, "heterogeneousrefractive: a point emitter must lie inside the medium shape (boundary refraction of connections is not built yet)");
+        }
+    }
     P.counters = ctx->counters;
     P.work_counter = ctx->counters + MER_C_COUNT * MER_COUNTER_REPLICAS;
     return 0;
@@ -450,6 +461,8 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     if (P.total_work == 0) return 0;
     const char *mode = getenv("MER_MODE");
     if (mode && std::strcmp(mode, "mega") == 0) {
+        if (scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0)
+            return fail(ctx, "MER_MODE=mega does not sample point emitters; use the default wavefront mode");
         return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
             auto kern = render_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
             int per_cu = 0;
@@ -504,7 +517,9 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         HIP_CHECK(ctx, hipMemsetAsync(q->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->hitq_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
     return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
-        auto kev = event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
+        const bool has_point = scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0;
+        auto kev = has_point ? event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, true>
+                             : event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, false>;
         auto kma = march_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
         auto kge = gen_kernel<decltype(curved)::value>;
         const unsigned gen_blocks = std::max(1u, std::min(nslots / MER_BLOCK, 1024u));      // 4096 waves x 512 ids per launch

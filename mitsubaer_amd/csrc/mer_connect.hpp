@@ -270,6 +270,88 @@ template <int RIF> struct Connector {
     }
 };
 
+// Luminaire sampling of a point emitter at a medium interaction: PointEmitter::sampleDirect (src/emitters/point.cpp:
+// pdf 1, EDiscrete => no MIS partner) + Scene::evalTransmittance (straight rays, src/librender/scene.cpp:619-678) or
+// Medium::eval through the RIF (curved rays, heterogeneousrefractive.cpp:571-640).  Returns value * phase (to be
+// multiplied by the path throughput).  Synchronous: it runs inside K_event.
+template <bool CURVED, int RIF, int STEPPER, int SIGMA>
+__device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi, int depth) {
+    const mer_scene_desc &S = P.sc;
+    const f3 I(S.point_intensity[0], S.point_intensity[1], S.point_intensity[2]);
+    const f3 pp(S.point_position[0], S.point_position[1], S.point_position[2]);
+    const int interactions = S.max_depth - depth - 1;
+    const int nwalks = (SIGMA == MER_SIGMA_GRID && S.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
+    C.nee++;
+    if (!CURVED) {
+        f3 dvec = pp - ps;
+        const float dist = sqrtf(dot(dvec, dvec)), invDist = 1.0f / dist;
+        dvec = dvec * invDist;
+        f3 value = I * (invDist * invDist);
+        const float tExit = intersect_shape(S, ps, dvec, 0.0f, MER_INF);
+        const bool crosses = tExit >= 0 && tExit < dist;
+        const float L = crosses ? tExit : dist;
+        f3 tr(1, 1, 1);
+        if (crosses && interactions == 0) tr = f3(0, 0, 0);
+        else if (SIGMA == MER_SIGMA_HOMOGENEOUS) tr = homogeneous_transmittance(P, 0.0f - L);
+        else {
+            float mint, maxt;                                            // heterogeneous.cpp:546-587
+            if (aabb_intersect(P.density.bmin, P.density.bmax, ps, dvec, mint, maxt)) {
+                mint = fmaxf(mint, 0.0f); maxt = fminf(maxt, L);
+                float result = 0.0f;
+                for (int w = 0; w < nwalks; ++w) {
+                    float Tr = 1.0f, t = mint;
+                    for (;;) {
+                        t -= logf(1 - rng.next1D()) * P.inv_max_density;
+                        if (t >= maxt) break;
+                        const float sigma = lookup_float(P.density, ps + dvec * t) * S.density_scale; C.tentative++;
+                        if (S.tr_estimator == MER_TR_RATIO) { Tr *= 1.0f - sigma * P.inv_max_density; if (Tr == 0.0f) break; }
+                        else if (sigma * P.inv_max_density > rng.next1D()) { Tr = 0.0f; break; }
+                    }
+                    result += Tr;
+                }
+                const float tv = result / (float) nwalks; tr = f3(tv, tv, tv);
+            }
+        }
+        value = value * tr;
+        if (is_zero(value)) return f3(0, 0, 0);
+        return value * phase_eval(S.phase, S.g, wi, dvec);
+    } else {
+        Connector<RIF> K(P);
+        float w = 1.0f, od = 0, dist = 0; f3 dir(0, 0, 1), rev(0, 0, 1);
+        if (!K.connect(ps, pp, normalize(pp - ps), rng, w, dir, rev, od, dist)) return f3(0, 0, 0);
+        f3 tr;
+        if (SIGMA == MER_SIGMA_HOMOGENEOUS) tr = f3(expf(P.sigT.x * (-dist)), expf(P.sigT.y * (-dist)), expf(P.sigT.z * (-dist)));
+        else {
+            float result = 0.0f;
+            for (int wk = 0; wk < nwalks; ++wk) {
+                f3 p = ps, v = dir; float left = dist, Tr = 1.0f, opt = 0; CellCache cc; cc.reset();
+                for (;;) {
+                    const float s = -logf(1 - rng.next1D()) * P.inv_max_density;
+                    if (s >= left) break;
+                    // trace(p, v, s): int(s/h) full steps + remainder, insideShape after each, one step back on exit (:671-691)
+                    const float h = S.stepsize; int steps = (int) (s / h); const float rem = s - steps * h; bool inside = true;
+                    for (int q = 0; q <= steps && inside; ++q) {
+                        const float hq = q < steps ? h : rem;
+                        er_step<RIF, STEPPER>(P.rif, cc, p, v, hq, opt); C.steps++;
+                        if (!inside_shape(S, p)) { er_step<RIF, STEPPER>(P.rif, cc, p, v, -hq, opt); C.steps++; inside = false; }
+                    }
+                    if (!inside) break;
+                    left -= s;
+                    const float sigma = lookup_float(P.density, p) * S.density_scale; C.tentative++;
+                    if (S.tr_estimator == MER_TR_RATIO) { Tr *= 1.0f - sigma * P.inv_max_density; if (Tr == 0.0f) break; }
+                    else if (sigma * P.inv_max_density > rng.next1D()) { Tr = 0.0f; break; }
+                }
+                result += Tr;
+            }
+            const float tv = result / (float) nwalks; tr = f3(tv, tv, tv);
+        }
+        if (is_zero(tr)) return f3(0, 0, 0);
+        const float invDist = 1.0f / dist;
+        const f3 value = I * (invDist * invDist) * tr * w;
+        return value * phase_eval(S.phase, S.g, wi, normalize(dir));
+    }
+}
+
 // leaf kernel: out stride 12: ok, weight, dirToP2[3], revDirToP1[3], dist, opticalDist, 0, 0; RNG stream (seed, i, 0)
 template <int RIF>
 __global__ void __launch_bounds__(64) connect_kernel(const Params P, const float *p1, const float *p2, int64_t n, float *out) {

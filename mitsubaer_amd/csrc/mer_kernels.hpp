@@ -33,7 +33,6 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 }  // namespace mer
 #include "mer_wavefront.hpp"
-#include "mer_connect.hpp"
 namespace mer {
 
 // ---------------------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@
 // lanes that have an event.  Slot traffic is ~160 B per lane per pass against ksteps x 128 B of field fetches.
 #pragma once
 #include "mer_walk.hpp"
+#include "mer_connect.hpp"
 
 namespace mer {
 
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
 // index-matched shape + interior medium + constant environment emitter, with the refractive hooks of
 // src/libbidir/edge.cpp:45-60,91-93 and src/libbidir/vertex.cpp:251-255, plus pixel regeneration
 // (src/librender/integrator.cpp:162-187) and ImageBlock::put (include/mitsuba/render/imageblock.h:124-205).
-template <bool CURVED, int RIF, int STEPPER, int SIGMA>
+template <bool CURVED, int RIF, int STEPPER, int SIGMA, bool POINT>
 __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32_t pass) {
     typedef Walk<CURVED, RIF, STEPPER, SIGMA> WalkT;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
@@ -411,6 +412,8 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                 ev = EV_AFTER_LOOKUP;
             }
         } else if (ev == EV_PHASE) {
+            // ---- luminaire sampling of the point emitter, if any (after the environment NEE, as in the oracle's draw order)
+            if (POINT) L = L + T * point_nee<CURVED, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth);
             // ---- phase function sampling: volpath.cpp:149-160
             const float p2x = rng.next1D(), p2y = rng.next1D();
             f3 wo;

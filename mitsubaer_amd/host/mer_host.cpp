@@ -353,9 +353,16 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
         o->sampleCount = props.getInteger("sampleCount", 4);
         out = o;
     } else if (tag == "emitter") {
-        if (type != "constant") Log_EError("emitter \"" + type + "\" is not supported on the GPU path (constant)");
         auto o = std::make_shared<Emitter>();
-        o->radiance = props.getSpectrum("radiance", Spectrum{{1, 1, 1}});
+        if (type == "constant") o->radiance = props.getSpectrum("radiance", Spectrum{{1, 1, 1}});
+        else if (type == "point") {                                      // src/emitters/point.cpp:57-69
+            o->kind = Emitter::EPoint;
+            if (props.hasProperty("position")) {
+                if (props.hasProperty("toWorld")) Log_EError("Only one of the parameters 'position' and 'toWorld' can be used!'");
+                o->position = props.getPoint("position");
+            } else { float m[16]; props.getTransform("toWorld", m); o->position = Vec3{m[3], m[7], m[11]}; }
+            o->radiance = props.getSpectrum("intensity", Spectrum{{1, 1, 1}});
+        } else Log_EError("emitter \"" + type + "\" is not supported on the GPU path (constant, point)");
         out = o;
     } else Log_EError("Unsupported scene element <" + tag + ">");
     return out;
@@ -596,8 +603,18 @@ void Integrator::flatten(const Scene &scene, mer_scene_desc &d) const {
     d.stepper = m.stepper; d.stepsize = m.stepsize;
     d.phase = m.phase->kind; d.g = m.phase->g;
     d.tr_estimator = m.trEstimator;
-    if (scene.emitters.size() > 1) Log_EError("Only one emitter is supported on the GPU path");
-    for (int i = 0; i < 3; i++) { d.env_radiance[i] = scene.emitters.empty() ? 0.0f : scene.emitters[0]->radiance.c[i]; d.emission[i] = m.emission.c[i]; }
+    int nconst = 0, npoint = 0;
+    for (int i = 0; i < 3; i++) { d.env_radiance[i] = 0; d.point_intensity[i] = 0; d.point_position[i] = 0; d.emission[i] = m.emission.c[i]; }
+    for (auto &e : scene.emitters) {
+        if (e->kind == Emitter::EPoint) {
+            if (++npoint > 1) Log_EError("Only one point emitter is supported on the GPU path");
+            d.point_position[0] = e->position.x; d.point_position[1] = e->position.y; d.point_position[2] = e->position.z;
+            for (int i = 0; i < 3; i++) d.point_intensity[i] = e->radiance.c[i];
+        } else {
+            if (++nconst > 1) Log_EError("Only one constant emitter is supported on the GPU path");
+            for (int i = 0; i < 3; i++) d.env_radiance[i] = e->radiance.c[i];
+        }
+    }
 }
 
 std::vector<float> Integrator::render(const Scene &scene, int device, int spp, unsigned long long seed, int layout) const {

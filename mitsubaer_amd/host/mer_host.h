@@ -158,7 +158,9 @@ public:
 class Emitter : public ConfigurableObject {
 public:
     const char *getClassName() const override { return "Emitter"; }
-    Spectrum radiance{};
+    enum Kind { EConstant, EPoint } kind = EConstant;
+    Spectrum radiance{};                        // constant: radiance ; point: intensity
+    Vec3 position{0, 0, 0};                     // point (src/emitters/point.cpp:60-68)
 };
 
 class Scene;

@@ -66,6 +66,7 @@ class SceneParams:
         self.tr_estimator = TR_RATIO
         self.env_radiance = [1.0, 1.0, 1.0]
         self.emission = [0.0, 0.0, 0.0]
+        self.point_position = [0.0, 0.0, 0.0]; self.point_intensity = [0.0, 0.0, 0.0]     # emitter `point`
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("unknown scene parameter '%s'" % k)

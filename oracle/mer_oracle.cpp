@@ -1156,6 +1156,32 @@ struct Walker {
         return Spec(result / nWalks);
     }
 
+    /* transmittance along the connecting ray of arc length `dist` starting at o with optical momentum v0
+       (Medium::eval's transmittance, heterogeneousrefractive.cpp:617 for homogeneous sigma; delta tracking otherwise) */
+    template <typename FLOAT> Spec connectionTransmittance(const Vec &o, const V3<FLOAT> &v0, FLOAT dist) {
+        if (S.s.sigma_mode == ORC_SIGMA_HOMOGENEOUS) {
+            Spec tr; for (int i = 0; i < 3; ++i) tr[i] = std::exp(S.sigmaT[i] * (Float) (-dist));
+            return tr;
+        }
+        Tracer<FLOAT> T(S, C);
+        const int nWalks = S.s.tr_estimator == ORC_TR_RATIO ? 1 : 2;
+        Float result = 0;
+        for (int w = 0; w < nWalks; ++w) {
+            V3<FLOAT> p(o), v = v0; FLOAT left = dist, ds = 0, opt = 0; Float Tr = 1.0f;
+            while (true) {
+                FLOAT s = (FLOAT) (-std::log(1 - rng.next1D()) * S.invMaxDensity);
+                if (s >= left) break;
+                if (!T.trace(p, v, s, ds, opt)) break;
+                left -= s;
+                Float density = sigmaTAt(Vec(p));
+                if (S.s.tr_estimator == ORC_TR_RATIO) { Tr *= 1.0f - density * S.invMaxDensity; if (Tr == 0.0f) break; }
+                else if (density * S.invMaxDensity > rng.next1D()) { Tr = 0.0f; break; }
+            }
+            result += Tr;
+        }
+        return Spec(result / nWalks);
+    }
+
     bool sampleDistance(const Vec &o, const Vec &d, Float maxt, MediumRec &mRec) {
         C.c[ORC_C_SEGMENTS]++;
         if (!S.curved) {
@@ -1190,6 +1216,9 @@ struct Walker {
         const Spec env(P.env_radiance[0], P.env_radiance[1], P.env_radiance[2]);
         const bool hasEnv = !env.isZero();
         const bool hasEmission = P.emission[0] != 0 || P.emission[1] != 0 || P.emission[2] != 0;
+        const Spec pointI(P.point_intensity[0], P.point_intensity[1], P.point_intensity[2]);
+        const bool hasPoint = !pointI.isZero();
+        const Vec pointP(P.point_position[0], P.point_position[1], P.point_position[2]);
         Spec Li(0.0f), throughput(1.0f);
         Float eta = 1.0f;
         bool scattered = false, medium = false, emitted = true;   /* rRec.type & EEmittedRadiance */
@@ -1235,6 +1264,43 @@ struct Walker {
                             Float phasePdf = phaseVal;       /* env emitter isOnSurface: constant.cpp:47 */
                             Float weight = miWeight(dpdf, phasePdf);
                             Li += throughput * value * phaseVal * weight;
+                        }
+                    }
+                }
+                /* ---- luminaire sampling of a point emitter: src/emitters/point.cpp sampleDirect (pdf 1, EDiscrete => no MIS) */
+                if (hasPoint) {
+                    C.c[ORC_C_NEE]++;
+                    const int interactions = maxDepth - depth - 1;
+                    if (!S.curved) {
+                        Vec dvec = pointP - mRec.p;
+                        const Float dist = std::sqrt(dot(dvec, dvec)), invDist = 1.0f / dist;
+                        dvec *= invDist;
+                        Spec value = pointI * (invDist * invDist);
+                        const Float tExit = S.intersectShape(mRec.p, dvec, 0.0f, std::numeric_limits<Float>::infinity());
+                        const bool crosses = tExit >= 0 && tExit < dist;          /* emitter outside the shape: one null crossing */
+                        Spec tr(1.0f);
+                        if (crosses && interactions == 0) tr = Spec(0.0f);
+                        else tr = evalTransmittance(mRec.p, dvec, crosses ? tExit : dist);
+                        value *= tr;
+                        if (!value.isZero()) Li += throughput * value * phaseEval(P.phase, P.g, wi, dvec);
+                    } else {
+                        /* connection through the RIF: Medium::eval (heterogeneousrefractive.cpp:571-640) */
+                        bool ok; Float w = 1, dist = 0; Vec dir; Spec tr(0.0f);
+                        if (S.s.rif_double) {
+                            Connector<double> K(S, C, rng); V3<double> d2, rev; double ww = 1, od = 0, di = 0;
+                            V3<double> a(mRec.p), b(pointP);
+                            ok = K.makeDirectConnections(a, b, normalize(b - a), ww, d2, rev, od, di);
+                            if (ok) { w = (Float) ww; dist = (Float) di; dir = Vec(d2); tr = connectionTransmittance<double>(mRec.p, d2, di); }
+                        } else {
+                            Connector<float> K(S, C, rng); V3<float> d2, rev; float ww = 1, od = 0, di = 0;
+                            V3<float> a(mRec.p), b(pointP);
+                            ok = K.makeDirectConnections(a, b, normalize(b - a), ww, d2, rev, od, di);
+                            if (ok) { w = ww; dist = di; dir = d2; tr = connectionTransmittance<float>(mRec.p, d2, di); }
+                        }
+                        if (ok && !tr.isZero()) {
+                            const Float invDist = 1.0f / dist;
+                            Spec value = pointI * (invDist * invDist) * tr * w;
+                            Li += throughput * value * phaseEval(P.phase, P.g, wi, normalize(dir));
                         }
                     }
                 }

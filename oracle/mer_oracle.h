@@ -73,6 +73,7 @@ typedef struct {
     /* emitters */
     float   env_radiance[3];
     float   emission[3];            /* medium emission coefficient per unit density (0 => none) */
+    float   point_position[3], point_intensity[3];   /* emitter `point` (src/emitters/point.cpp); intensity 0 => none */
 } orc_scene;
 
 enum {

@@ -275,3 +275,62 @@ def test_rng_stream_properties(orc):
     assert np.all((a * 2 ** 23) == np.floor(a * 2 ** 23))               # 23-bit granularity (random.cpp:630-639)
     assert not np.array_equal(a[:8], orc.rng_floats(0, 1, 0, 8))
     assert not np.array_equal(a[:8], orc.rng_floats(0, 0, 1, 8))
+
+
+# ----------------------------------------------------------------------------- A12 + point-emitter luminaire sampling
+def test_connect_constant_index_is_the_chord(orc):
+    """A12 known answer: in a constant-index field the eikonal ray is a straight line, so the connection p1 -> p2 is the
+    chord: arc length |p2-p1|, optical length n|p2-p1|, direction (p2-p1)/|p2-p1|, exactly one solution (weight 1)."""
+    N = 12
+    p = scenes.curved_scene(N=N, rif="linear")
+    p.rif = np.full((N, N, N), 1.3, np.float32)
+    rng = np.random.RandomState(5)
+    p1 = rng.uniform(-0.8, 0.8, (64, 3)).astype(np.float32); p2 = rng.uniform(-0.8, 0.8, (64, 3)).astype(np.float32)
+    out = orc.connect(p, p1, p2, 9)
+    chord = p2 - p1; L = np.linalg.norm(chord, axis=1)
+    ok = out[:, 0] == 1
+    # the initial momentum is drawn in the hemisphere about the chord (uniformSample, :1078-1084); a draw whose ray leaves the
+    # shape before its closest approach needs the boundary branch (not built) and is lost to Russian roulette
+    assert ok.mean() > 0.85
+    out, chord, L = out[ok], chord[ok], L[ok]
+    np.testing.assert_allclose(out[:, 1], 1.0, atol=0)
+    np.testing.assert_allclose(out[:, 8], L, rtol=2e-3)                      # arc length, quantised by the step size
+    np.testing.assert_allclose(out[:, 9], 1.3 * L, rtol=2e-3)
+    d = out[:, 2:5] / np.linalg.norm(out[:, 2:5], axis=1, keepdims=True)
+    np.testing.assert_allclose(d, chord / L[:, None], atol=2e-4)
+
+
+def test_point_emitter_single_scatter_matches_quadrature(orc):
+    """Point-emitter luminaire sampling (src/emitters/point.cpp sampleDirect + Scene::evalTransmittance) in a homogeneous,
+    isotropic medium with exactly one scattering event (max_depth = 3: the null boundary crossing counts as a depth,
+    volpath.cpp:259-262): the radiance along the central camera ray has the closed form
+      L = int_0^2 sigma_s exp(-sigma_t t) (1/4pi) I exp(-sigma_t d(t)) / d(t)^2 dt ."""
+    sig_a, sig_s = 0.3, 0.9
+    pp = np.array([0.1, 0.6, -0.2]); I = np.array([1.0, 0.8, 0.5])
+    p = scenes.homogeneous_scene(w=2, h=2, fov_x_deg=0.02, sigma_a=[sig_a] * 3, sigma_s=[sig_s] * 3, env_radiance=[0, 0, 0],
+                                 point_position=list(pp), point_intensity=list(I), max_depth=3,
+                                 rfilter=P.FILTER_BOX, rfilter_param=0.5)
+    film, _ = orc.render(p, 0, 60000, 11)
+    got = film[..., :3].sum((0, 1)) / film[..., 4].sum()
+    st = sig_a + sig_s
+    t = (np.arange(200000) + 0.5) / 200000 * 2.0
+    x = np.stack([-1 + t, 0 * t, 0 * t], 1)                                    # camera at (-3,0,0) looking along +x
+    d = np.linalg.norm(pp[None] - x, axis=1)
+    ref = (sig_s * np.exp(-st * t) / (4 * np.pi) * np.exp(-st * d) / d ** 2).mean() * 2.0
+    np.testing.assert_allclose(got, ref * I, rtol=0.03)
+
+
+def test_point_emitter_curved_equals_straight_in_constant_index(orc):
+    """The curved branch (connection solver + transmittance along the connecting ray) must reproduce the straight branch
+    when the index field is constant 1 (same expectation; different sampler stream, so compared as film means)."""
+    N = 12
+    kw = dict(w=4, h=4, env_radiance=[0, 0, 0], point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5], max_depth=3,
+              rfilter=P.FILTER_BOX, rfilter_param=0.5)
+    ps = scenes.straight_scene(N=N, **kw)
+    pc = scenes.curved_scene(N=N, **kw)
+    pc.rif = np.ones((N, N, N), np.float32)
+    fs, _ = orc.render(ps, 0, 3000, 2)
+    fc, _ = orc.render(pc, 0, 3000, 2)
+    a = fs[..., :3].sum((0, 1)) / fs[..., 4].sum(); b = fc[..., :3].sum((0, 1)) / fc[..., 4].sum()
+    assert a.min() > 0
+    np.testing.assert_allclose(b, a, rtol=0.08)
