@@ -39,6 +39,16 @@ def build_workload(name, res, size, spp):
         p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.radial_rif(res), stepper=P.STEP_RK4,
                           stepsize=0.5 * 2.0 / (res - 1), **common)
         desc = "%d^3 sigma_t grid + %d^3 radial RIF, RK4 eikonal curved rays, HG g=0.8, %d^2 x %d spp" % (res, res, size, spp)
+    elif name == "cfg5":
+        # emissive heterogeneous medium + RGB albedo grid + curved-ray luminaire sampling of a point emitter (A12)
+        g = np.linspace(0.0, 1.0, res, dtype=np.float32)
+        alb = np.empty((res, res, res, 3), np.float32)
+        alb[..., 0] = 0.55 + 0.4 * g[None, None, :]; alb[..., 1] = 0.55 + 0.4 * g[None, :, None]; alb[..., 2] = 0.55 + 0.4 * g[:, None, None]
+        common.pop("albedo")
+        p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.linear_rif(res), stepper=P.STEP_RK4,
+                          stepsize=0.5 * 2.0 / (res - 1), albedo_mode=P.ALBEDO_GRID, albedo_grid=alb, env_radiance=[0, 0, 0],
+                          emission=[0.2, 0.12, 0.06], point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5], **common)
+        desc = "%d^3 sigma_t + RGB albedo grids, emissive medium, %d^3 linear RIF, RK4 curved rays + curved-ray point-emitter NEE, %d^2 x %d spp" % (res, res, size, spp)
     else:
         raise SystemExit("unknown workload %s" % name)
     return p, desc
@@ -180,7 +190,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: " + desc, "grid": args.res, "film": [p.width, p.height], "spp_per_gpu": args.spp,
+            "config": {"workload": {"cfg2": "configs[1]: ", "cfg3": "configs[2]: ", "cfg4": "configs[3]: ", "cfg5": "configs[4]: "}[args.workload] + desc, "grid": args.res, "film": [p.width, p.height], "spp_per_gpu": args.spp,
                        "stepper": "rk4", "rif_interp": "trilinear", "layout": args.layout, "shard": args.shard,
                        "stepsize": p.stepsize, "estimator": "volpath + delta tracking on eikonal rays, ratio-tracking NEE",
                        "device": name, "cus": cus},

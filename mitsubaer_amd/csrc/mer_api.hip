@@ -39,7 +39,7 @@ struct mer_context {
     hipDeviceProp_t prop;
     // wavefront path-state slots
     uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
-    SegQueue eq{}, mq[2]{}, sq[2]{};
+    SegQueue eq{}, mq[2]{}, sq[2]{}, cq{};
     unsigned long long *hitq = nullptr, *hitq_ctr = nullptr; unsigned long long hitq_cap = 0;
     int last_passes = 0;
     float last_march_ms = 0, last_event_ms = 0;
@@ -297,7 +297,7 @@ void mer_context_destroy(mer_context *ctx) {
     if (ctx->counters) (void) hipFree(ctx->counters);
     if (ctx->slots) (void) hipFree(ctx->slots);
     if (ctx->live) (void) hipFree(ctx->live);
-    for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1]}) { if (q->items) (void) hipFree(q->items); if (q->counts) (void) hipFree(q->counts); }
+    for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1], &ctx->cq}) { if (q->items) (void) hipFree(q->items); if (q->counts) (void) hipFree(q->counts); }
     if (ctx->hitq) (void) hipFree(ctx->hitq);
     if (ctx->hitq_ctr) (void) hipFree(ctx->hitq_ctr);
     if (ctx->host_live) (void) hipHostFree(ctx->host_live);
@@ -488,7 +488,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         if (ctx->hitq) (void) hipFree(ctx->hitq);
         ctx->slots = nullptr; ctx->hitq = nullptr; ctx->nslots = 0;
         HIP_CHECK(ctx, hipMalloc((void **) &ctx->slots, (size_t) want * MER_SLOT_WORDS * sizeof(uint32_t)));
-        for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1]}) {
+        for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1], &ctx->cq}) {
             if (q->items) (void) hipFree(q->items);
             q->items = nullptr;
             q->segcap = 2u * (want / MER_NSEG) + 256u;          // two producer kernels may feed one segment
@@ -507,13 +507,13 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     uint32_t nslots = ctx->nslots;
     const uint64_t need_slots = (P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
     if (need_slots < nslots) nslots = (uint32_t) need_slots;
-    P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.eq = ctx->eq; P.mq[0] = ctx->mq[0]; P.mq[1] = ctx->mq[1]; P.sq[0] = ctx->sq[0]; P.sq[1] = ctx->sq[1];
+    P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.eq = ctx->eq; P.mq[0] = ctx->mq[0]; P.mq[1] = ctx->mq[1]; P.sq[0] = ctx->sq[0]; P.sq[1] = ctx->sq[1]; P.cq = ctx->cq;
     P.hitq = ctx->hitq; P.hitq_cap = ctx->hitq_cap; P.hitq_ctr = ctx->hitq_ctr; P.gen_iters = 8; P.gen_all = getenv("MER_GEN_ALL") ? 1 : 0;
     P.ksteps = 64;
     { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) P.ksteps = atoi(e); }
     HIP_CHECK(ctx, hipMemsetAsync(ctx->slots, 0, (size_t) nslots * MER_SLOT_WORDS * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
-    for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1]})
+    for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1], &ctx->cq})
         HIP_CHECK(ctx, hipMemsetAsync(q->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->hitq_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
     return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
@@ -521,6 +521,8 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         auto kev = has_point ? event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, true>
                              : event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, false>;
         auto kma = march_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
+        auto kco = connect_stage_kernel<decltype(curved)::value ? decltype(rif)::value : MER_RIF_TRILINEAR, decltype(stepper)::value, decltype(sigma)::value>;
+        const bool connect_stage = has_point && decltype(curved)::value;
         auto kge = gen_kernel<decltype(curved)::value>;
         const unsigned gen_blocks = std::max(1u, std::min(nslots / MER_BLOCK, 1024u));      // 4096 waves x 512 ids per launch
         bool work_left = true;
@@ -536,6 +538,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
             HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 0], ctx->stream));
             for (int g = 0; work_left && g < (pass == 0 ? 6 : 1); g++) hipLaunchKernelGGL(kge, dim3(gen_blocks), dim3(MER_BLOCK), 0, ctx->stream, P);
             hipLaunchKernelGGL(kev, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
+            if (connect_stage) hipLaunchKernelGGL(kco, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
             HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 1], ctx->stream));
             hipLaunchKernelGGL(kma, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
             HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 2], ctx->stream));

@@ -64,7 +64,7 @@ __device__ __forceinline__ void bspline_weights2(float t, float d2[4]) {
 
 // Spline<3>::valueGradientAndHessian (basisspline.h:539-606) / Hessian of the trilinear interpolant (mixed terms only)
 template <int RIF>
-__device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, f3 p, float &val, f3 &grad, m33 &H) {
+__device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, CellCache &cc, f3 p, float &val, f3 &grad, m33 &H) {
     if (RIF == MER_RIF_BSPLINE3) {
         const float px = (p.x - g.bmin[0]) * g.s[0], py = (p.y - g.bmin[1]) * g.s[1], pz = (p.z - g.bmin[2]) * g.s[2];
         const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
@@ -92,7 +92,6 @@ __device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, f3 p, float 
         H.m[0][0] = hxx * g.s[0] * g.s[0]; H.m[1][1] = hyy * g.s[1] * g.s[1]; H.m[2][2] = hzz * g.s[2] * g.s[2];
         H.m[0][1] = H.m[1][0] = hxy * g.s[0] * g.s[1]; H.m[1][2] = H.m[2][1] = hyz * g.s[1] * g.s[2]; H.m[0][2] = H.m[2][0] = hzx * g.s[2] * g.s[0];
     } else {
-        CellCache cc; cc.reset();
         trilinear_value_grad<RIF>(g, cc, p, val, grad);
         const float fx = __builtin_fmaf(g.s[0], p.x, g.t[0]) - cc.cx, fy = __builtin_fmaf(g.s[1], p.y, g.t[1]) - cc.cy,
                     fz = __builtin_fmaf(g.s[2], p.z, g.t[2]) - cc.cz;
@@ -107,23 +106,25 @@ __device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, f3 p, float 
 template <int RIF> struct Connector {
     const Params &P;
     float tol, rrweight; int precision, maxIter, maxSteps;
+    mutable CellCache cc;                       // the 8 corners of the cell the ray is in (trilinear RIF): reused across evaluations
     __device__ Connector(const Params &p) : P(p) {
+        cc.reset();
         tol = 1e-6f; rrweight = 1e-2f; precision = 3; maxIter = 20;                 // :209-213, :217
         float diag = 0;
         for (int i = 0; i < 3; i++) diag += (p.sc.bmax[i] - p.sc.bmin[i]) * (p.sc.bmax[i] - p.sc.bmin[i]);
         if (p.sc.boundary == MER_BOUNDARY_SPHERE) diag = 4 * p.sc.sph_radius * p.sc.sph_radius;
         maxSteps = min(100000, (int) (4 * sqrtf(diag) / p.sc.stepsize) + 16);        // the reference allows 1e5 (:829)
     }
-    __device__ float rif_value(f3 p) const { float n; f3 g; CellCache cc; cc.reset(); rif_value_grad<RIF>(P.rif, cc, p, n, g); return n; }
+    __device__ float rif_value(f3 p) const { float n; f3 g; rif_value_grad<RIF>(P.rif, cc, p, n, g); return n; }
 
     // er_derivativestep (:798-814)
     __device__ void dstep(f3 &p, f3 &v, m33 &dp, m33 &dv, float h) const {
         float n; f3 G; m33 H;
-        rif_value_grad_hess<RIF>(P.rif, p, n, G, H);
+        rif_value_grad_hess<RIF>(P.rif, cc, p, n, G, H);
         v = v + 0.5f * h * G;
         dv = add(dv, scale(mul(H, dp), 0.5f * h));
         p = p + h * v / n;
-        rif_value_grad_hess<RIF>(P.rif, p, n, G, H);
+        rif_value_grad_hess<RIF>(P.rif, cc, p, n, G, H);
         const float invn = 1.0f / n;
         dp = add(dp, scale(add(scale(mul(outer(v, G), dp), -invn * invn), scale(dv, invn)), h));
         v = v + 0.5f * h * G;
@@ -163,7 +164,7 @@ template <int RIF> struct Connector {
             } else if (!inside_shape(P.sc, p)) return false;
         }
         if (!found) return false;
-        float rr; f3 dvdt; CellCache cc; cc.reset();
+        float rr; f3 dvdt;
         rif_value_grad<RIF>(P.rif, cc, p, rr, dvdt);
         const f3 dpdt = v / rr;
         const f3 dtstar = -(premult(dp, v) + premult(dv, p - p2)) / (dot(v, dpdt) + dot(p - p2, dvdt));
@@ -203,7 +204,7 @@ template <int RIF> struct Connector {
     }
     // the reference's own Verlet step (:662-669)
     __device__ void verlet(f3 &p, f3 &v, float h) const {
-        float n, n2; f3 G, G2; CellCache cc; cc.reset();
+        float n, n2; f3 G, G2;
         rif_value_grad<RIF>(P.rif, cc, p, n, G);
         v = v + 0.5f * h * G;
         p = p + h * v / n;

@@ -414,6 +414,7 @@ struct Params {
     uint32_t *slots; uint32_t nslots; int32_t ksteps;
     uint32_t *live;                     // live[0]: number of finished slots
     SegQueue eq, mq[2], sq[2];          // event queue, march lists (by pass parity), starved lists (by pass parity)
+    SegQueue cq;                        // connection requests of this pass (curved-ray point-emitter NEE, K_connect)
     unsigned long long *hitq; unsigned long long hitq_cap;     // ring of work ids that will march (power-of-two capacity)
     unsigned long long *hitq_ctr;       // [0] produced (tail), [1] consumed (head)
     int32_t gen_iters, gen_all;

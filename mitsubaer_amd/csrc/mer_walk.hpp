@@ -14,7 +14,7 @@ namespace mer {
 enum { ST_NEW = 0, ST_MARCH = 1, ST_DONE = 2 };
 enum { K_FREE = 0, K_NEE = 1, K_LOOKUP = 2 };
 enum { EV_NONE = 0, EV_ARRIVED, EV_EXITED, EV_REAL, EV_FAIL, EV_WALK_END, EV_TR_DONE, EV_PHASE, EV_AFTER_LOOKUP,
-       EV_PATH_DONE, EV_GATE_FAIL };
+       EV_PATH_DONE, EV_GATE_FAIL, EV_PHASE2 /* phase sampling after K_connect's luminaire sample */ };
 
 struct LaneCounters {
     uint32_t steps, rif_evals, tentative, real, segments, nee, paths, marched;

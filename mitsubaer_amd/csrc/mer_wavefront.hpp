@@ -249,8 +249,9 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     const uint32_t count = nq + ns;
     // ring hygiene: the rows K_march / K_event of pass+1 will add to
     queue_clear_row(P.eq, pass + 2, j); queue_clear_row(P.mq[pass & 1u], pass + 2, j); queue_clear_row(P.sq[pass & 1u], pass + 2, j);
+    if (POINT && CURVED) queue_clear_row(P.cq, pass + 2, j);
     LaneCounters C; C.clear();
-    bool marching = false, starved_out = false; uint32_t i = 0;
+    bool marching = false, starved_out = false, connecting = false; uint32_t i = 0;
     if (j < count) {
     i = pass == 0 ? j : (j < nq ? queue_item(P.eq, pass, j) : queue_item(P.sq[pass & 1u], pass, j - nq));
     const uint32_t fl = SLOT(H_FLAGS);
@@ -411,9 +412,14 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                 }
                 ev = EV_AFTER_LOOKUP;
             }
-        } else if (ev == EV_PHASE) {
-            // ---- luminaire sampling of the point emitter, if any (after the environment NEE, as in the oracle's draw order)
-            if (POINT) L = L + T * point_nee<CURVED, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth);
+        } else if (ev == EV_PHASE || ev == EV_PHASE2) {
+            // ---- luminaire sampling of the point emitter, if any (after the environment NEE, as in the oracle's draw order).
+            // Curved rays: the connection is a shooting problem of hundreds of sensitivity steps -- it gets a kernel of its
+            // own (K_connect) in which every lane solves one; the path resumes at EV_PHASE2 in the next pass.
+            if (POINT && ev == EV_PHASE) {
+                if (CURVED) { connecting = true; break; }
+                L = L + T * point_nee<false, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth);
+            }
             // ---- phase function sampling: volpath.cpp:149-160
             const float p2x = rng.next1D(), p2y = rng.next1D();
             f3 wo;
@@ -477,7 +483,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     if (st == ST_DONE) { SLOT(H_FLAGS) = ST_DONE; atomicAdd(P.live, 1u); }      // live[0] counts finished slots
     else if (starved) { SLOT(H_FLAGS) = ST_NEW; starved_out = true; }
     else {
-        store_hot(P, i, ST_MARCH, EV_NONE, W, rng, pixel, sample, 0.0f);
+        store_hot(P, i, ST_MARCH, connecting ? EV_PHASE2 : EV_NONE, W, rng, pixel, sample, 0.0f);
         SLOT(CO_PXF) = __float_as_uint(px); SLOT(CO_PYF) = __float_as_uint(py);
         SLOT(CO_LX) = __float_as_uint(L.x); SLOT(CO_LY) = __float_as_uint(L.y); SLOT(CO_LZ) = __float_as_uint(L.z);
         SLOT(CO_TX) = __float_as_uint(T.x); SLOT(CO_TY) = __float_as_uint(T.y); SLOT(CO_TZ) = __float_as_uint(T.z);
@@ -489,11 +495,40 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
         SLOT(CO_PHASEPDF) = __float_as_uint(phasePdf); SLOT(CO_ITST) = __float_as_uint(itsT);
         SLOT(CO_N0) = __float_as_uint(W.n0); SLOT(CO_TRSUM) = __float_as_uint(W.trsum);
         SLOT(CO_SDENS) = __float_as_uint(W.sdens); SLOT(CO_TMIN) = __float_as_uint(W.tmin);
-        marching = true;
+        marching = !connecting;
     }
     }   // j < count
+    if (POINT && CURVED) queue_push(P.cq, pass, connecting, i);
     queue_push(P.mq[pass & 1u], pass, marching, i);
     queue_push(P.sq[(pass + 1) & 1u], pass + 1, starved_out, i);
+    flush_counters(P, C, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K_connect: curved-ray luminaire sampling of the point emitter for the slots K_event parked on a scattering event
+// (Medium::eval -> makeDirectConnections, src/medium/heterogeneousrefractive.cpp:571-640,1087-1163).  One lane per
+// connection; the sampler stream continues where K_event left it, so the draw order is the oracle's.
+template <int RIF, int STEPPER, int SIGMA>
+__global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P, uint32_t pass) {
+    const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
+    if (j >= P.nslots) return;
+    const uint32_t count = queue_total(P.cq, pass);
+    LaneCounters C; C.clear();
+    uint32_t i = 0;
+    const bool mine = j < count;
+    if (mine) {
+        i = queue_item(P.cq, pass, j);
+        Rng rng;
+        const uint32_t pixel = SLOT(H_PIXEL), sample = SLOT(H_SAMPLE);
+        rng.state = (uint64_t) SLOT(H_RNG_LO) | ((uint64_t) SLOT(H_RNG_HI) << 32);
+        rng.inc = (((((uint64_t) sample) << 32) | (uint64_t) pixel) << 1) | 1ULL;
+        const f3 T(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ)), ps(SLOTF(CO_PSX), SLOTF(CO_PSY), SLOTF(CO_PSZ)), wi(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
+        const int depth = (int) SLOT(CO_DEPTH);
+        const f3 c = T * point_nee<true, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth);
+        SLOT(CO_LX) = __float_as_uint(SLOTF(CO_LX) + c.x); SLOT(CO_LY) = __float_as_uint(SLOTF(CO_LY) + c.y); SLOT(CO_LZ) = __float_as_uint(SLOTF(CO_LZ) + c.z);
+        SLOT(H_RNG_LO) = (uint32_t) rng.state; SLOT(H_RNG_HI) = (uint32_t) (rng.state >> 32);
+    }
+    queue_push(P.eq, pass + 1, mine, i);            // resumes at EV_PHASE2 in K_event of the next pass
     flush_counters(P, C, 0);
 }
 

@@ -36,6 +36,12 @@ def homogeneous_scene(w=48, h=40, **kw):
     return P.SceneParams(**base)
 
 
+def rgb_albedo(N, seed=4):
+    """RGB albedo grid (gridvolume, 3 channels: src/volume/gridvolume.cpp:390-421), values in [0.5, 0.95]"""
+    rng = np.random.RandomState(seed)
+    return (0.5 + 0.45 * rng.rand(N, N, N, 3)).astype(np.float32)
+
+
 def rand_points(n, lo=-1.05, hi=1.05, seed=1):
     rng = np.random.RandomState(seed)
     return rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)

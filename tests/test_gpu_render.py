@@ -35,6 +35,9 @@ CASES = {
     "point_curved_trilinear": lambda: scenes.curved_scene(N=24, w=32, h=24, env_radiance=[0, 0, 0], point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5]),
     "point_curved_bspline": lambda: scenes.bspline_scene(N=24, w=32, h=24, env_radiance=[0, 0, 0], point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5]),
     "point_curved_homogeneous_sigma": lambda: scenes.curved_scene(N=24, w=32, h=24, sigma_mode=P.SIGMA_HOMOGENEOUS, stepper=P.STEP_VERLET, point_position=[-0.3, 0.1, 0.4], point_intensity=[1.0, 0.8, 0.5]),
+    "cfg5_rgb_albedo_grid_emissive": lambda: scenes.curved_scene(N=24, albedo_mode=P.ALBEDO_GRID, albedo_grid=scenes.rgb_albedo(24), emission=[0.2, 0.12, 0.06]),
+    "point_curved_cfg5_rgb_albedo_emissive": lambda: scenes.curved_scene(N=24, w=32, h=24, albedo_mode=P.ALBEDO_GRID, albedo_grid=scenes.rgb_albedo(24), emission=[0.2, 0.12, 0.06],
+                                                                         env_radiance=[0, 0, 0], point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5]),
     "emissive_rgb": lambda: scenes.curved_scene(N=24, env_radiance=[0, 0, 0], emission=[1.0, 0.6, 0.3], albedo=[0.95, 0.9, 0.8]),
 }
 
