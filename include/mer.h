@@ -78,7 +78,14 @@ typedef struct {
     /* emitter `point` (src/emitters/point.cpp): position + radiant intensity; all-zero intensity = none.  With curved rays the
        emitter must lie inside the medium shape and is reached by mer_connect's shooting solver. */
     float   point_position[3], point_intensity[3];
+    /* film decomposition (src/librender/film.cpp:56-84): 0 = none, 1 = transient.  Transient: every radiance
+       contribution is binned by its optical path length (sum of h*n along curved segments, length*n otherwise:
+       src/integrators/bdpt/bdpt_proc.cpp:151-176,449-470) into frames = ceil((max_bound-min_bound)/bin_width) RGB slices.
+       The film then is float[height][width][frames*3 + 2]: RGB per frame, alpha, weight (bdpt_proc.cpp:230-245,484-485).
+       calibrated_transient != 0 leaves the camera edge out of the path length (bdpt_proc.cpp:163-170). */
+    int32_t decomposition; float min_bound, max_bound, bin_width; int32_t calibrated_transient;
 } mer_scene_desc;
+enum { MER_DECOMPOSITION_NONE = 0, MER_DECOMPOSITION_TRANSIENT = 1 };
 
 /* which part of the image-sample space this call renders (multi-GPU sharding):
    sample indices spp_begin + k*spp_stride, k in [0, spp_count); 32x32 image tiles t with
@@ -115,7 +122,13 @@ int  mer_volume_build_spline(mer_context *ctx, mer_volume v);
 int  mer_volume_download_spline(mer_context *ctx, mer_volume v, float *coeff_host);
 int  mer_volume_destroy(mer_context *ctx, mer_volume v);
 
-/* ---- film (ImageBlock, include/mitsuba/render/imageblock.h:124-205): float[height][width][5] ------ */
+/* ---- film (ImageBlock, include/mitsuba/render/imageblock.h:124-205): float[height][width][channels], channels = 5
+        (R,G,B,alpha,weight) in steady state; mer_film_channels() for a scene with a transient decomposition; the *_n
+        variants take the channel count ------ */
+int  mer_film_channels(mer_context *ctx, const mer_scene_desc *scene, int32_t *channels);
+int  mer_film_alloc_n(mer_context *ctx, int32_t width, int32_t height, int32_t channels, float **film_dev);
+int  mer_film_zero_n(mer_context *ctx, float *film_dev, int32_t width, int32_t height, int32_t channels);
+int  mer_film_download_n(mer_context *ctx, const float *film_dev, int32_t width, int32_t height, int32_t channels, float *film_host);
 int  mer_film_alloc(mer_context *ctx, int32_t width, int32_t height, float **film_dev);
 int  mer_film_zero(mer_context *ctx, float *film_dev, int32_t width, int32_t height);
 int  mer_film_download(mer_context *ctx, const float *film_dev, int32_t width, int32_t height, float *film_host);

@@ -17,7 +17,8 @@ LAYOUT_DENSE, LAYOUT_CELL8 = 0, 1
 SYMBOLS = [
     "mer_abi_version", "mer_context_create", "mer_context_destroy", "mer_last_error", "mer_context_set_stream",
     "mer_device_info", "mer_volume_upload", "mer_volume_upload_dev", "mer_volume_build_spline",
-    "mer_volume_download_spline", "mer_volume_destroy", "mer_film_alloc", "mer_film_zero", "mer_film_download",
+    "mer_volume_download_spline", "mer_volume_destroy", "mer_film_channels", "mer_film_alloc_n", "mer_film_zero_n",
+    "mer_film_download_n", "mer_film_alloc", "mer_film_zero", "mer_film_download",
     "mer_film_free", "mer_render", "mer_synchronize", "mer_last_kernel_ms", "mer_last_render_stats", "mer_counters_read",
     "mer_counters_reset", "mer_lookup_trilinear", "mer_lookup_trilinear_rgb", "mer_rif_value_grad", "mer_er_trace",
     "mer_sample_distance", "mer_connect", "mer_eval_transmittance", "mer_phase_sample", "mer_phase_eval", "mer_camera_rays",
@@ -50,6 +51,8 @@ class SceneDesc(C.Structure):
         ("tr_estimator", C.c_int32),
         ("env_radiance", C.c_float * 3), ("emission", C.c_float * 3),
         ("point_position", C.c_float * 3), ("point_intensity", C.c_float * 3),
+        ("decomposition", C.c_int32), ("min_bound", C.c_float), ("max_bound", C.c_float), ("bin_width", C.c_float),
+        ("calibrated_transient", C.c_int32),
     ]
 
 
@@ -202,6 +205,8 @@ class Context:
         s.env_radiance[:] = p.env_radiance
         s.emission[:] = p.emission
         s.point_position[:] = p.point_position; s.point_intensity[:] = p.point_intensity
+        s.decomposition = p.decomposition; s.min_bound = p.min_bound; s.max_bound = p.max_bound; s.bin_width = p.bin_width
+        s.calibrated_transient = int(p.calibrated_transient)
         return s
 
     def upload_scene(self, p, layout=LAYOUT_DENSE, rif_layout=None):
@@ -223,17 +228,23 @@ class Context:
         return self.scene_desc(p, dens, alb, rif), vols
 
     # ---- film + render -------------------------------------------------------------------------
-    def film_alloc(self, w, h):
+    def film_channels(self, scene):
+        """frames*3 + 2: RGB per frame, alpha, weight (5 in steady state)"""
+        ch = C.c_int32()
+        self._check(lib().mer_film_channels(self.h, C.byref(scene), C.byref(ch)))
+        return ch.value
+
+    def film_alloc(self, w, h, channels=5):
         ptr = C.c_void_p()
-        self._check(lib().mer_film_alloc(self.h, C.c_int32(w), C.c_int32(h), C.byref(ptr)))
+        self._check(lib().mer_film_alloc_n(self.h, C.c_int32(w), C.c_int32(h), C.c_int32(channels), C.byref(ptr)))
         return ptr
 
-    def film_zero(self, ptr, w, h):
-        self._check(lib().mer_film_zero(self.h, ptr, C.c_int32(w), C.c_int32(h)))
+    def film_zero(self, ptr, w, h, channels=5):
+        self._check(lib().mer_film_zero_n(self.h, ptr, C.c_int32(w), C.c_int32(h), C.c_int32(channels)))
 
-    def film_download(self, ptr, w, h):
-        out = np.empty((h, w, 5), np.float32)
-        self._check(lib().mer_film_download(self.h, ptr, C.c_int32(w), C.c_int32(h), _fp(out)))
+    def film_download(self, ptr, w, h, channels=5):
+        out = np.empty((h, w, channels), np.float32)
+        self._check(lib().mer_film_download_n(self.h, ptr, C.c_int32(w), C.c_int32(h), C.c_int32(channels), _fp(out)))
         return out
 
     def film_free(self, ptr):
@@ -246,10 +257,11 @@ class Context:
         self._check(lib().mer_render(self.h, C.byref(scene), C.byref(sh), C.c_uint64(seed), fp))
 
     def render_to_host(self, scene, spp_begin, spp_count, seed=0, **kw):
-        f = self.film_alloc(scene.width, scene.height)
+        ch = self.film_channels(scene)
+        f = self.film_alloc(scene.width, scene.height, ch)
         try:
             self.render(scene, f, spp_begin, spp_count, seed, **kw)
-            return self.film_download(f, scene.width, scene.height)
+            return self.film_download(f, scene.width, scene.height, ch)
         finally:
             self.film_free(f)
 

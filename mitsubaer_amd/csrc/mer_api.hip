@@ -105,6 +105,16 @@ static void filter_table(int kind, float param, float *values, float &radius, fl
 }
 
 // Validate the scene the way the reference plugins' constructors / configure() do, and flatten it.
+static int film_frames(mer_context *ctx, const mer_scene_desc *sc, int &frames) {
+    frames = 1;
+    if (sc->decomposition == MER_DECOMPOSITION_NONE) return 0;
+    if (sc->decomposition != MER_DECOMPOSITION_TRANSIENT)
+        return fail(ctx, "The \"decomposition\" parameter must be equal toeither \"none\", \"transient\", or \"bounce\"!");   // film.cpp:66-68 (bounce: not built)
+    const float f = std::ceil((sc->max_bound - sc->min_bound) / sc->bin_width);                                               // film.cpp:74
+    if (!(f >= 1.0f) || f > 4096.0f) return fail(ctx, "film: transient decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames");
+    frames = (int) f;
+    return 0;
+}
 static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P) {
     std::memset(&P, 0, sizeof(P));
     P.sc = *sc;
@@ -182,6 +192,8 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P) {
     if (!(sc->rfilter_param > 0)) return fail(ctx, "reconstruction filter radius/stddev must be positive");
     filter_table(sc->rfilter, sc->rfilter_param, P.fvalues, P.fradius, P.fscale);
     if (P.fradius > 7.0f) return fail(ctx, "reconstruction filter radius too large");
+    if (film_frames(ctx, sc, P.frames)) return 1;
+    P.film_ch = P.frames * 3 + 2;
     if (sc->boundary == MER_BOUNDARY_AABB) {
         for (int i = 0; i < 3; i++) if (!(sc->bmin[i] < sc->bmax[i])) return fail(ctx, "medium shape: empty bounding box");
     } else if (sc->boundary == MER_BOUNDARY_SPHERE) {
@@ -423,19 +435,31 @@ int mer_volume_destroy(mer_context *ctx, mer_volume h) {
     return 0;
 }
 
-int mer_film_alloc(mer_context *ctx, int32_t width, int32_t height, float **film_dev) {
-    HIP_CHECK(ctx, hipMalloc((void **) film_dev, (size_t) width * height * 5 * sizeof(float)));
-    HIP_CHECK(ctx, hipMemsetAsync(*film_dev, 0, (size_t) width * height * 5 * sizeof(float), ctx->stream));
+int mer_film_channels(mer_context *ctx, const mer_scene_desc *scene, int32_t *channels) {
+    int frames;
+    if (!scene || !channels) return 1;
+    if (film_frames(ctx, scene, frames)) return 1;
+    *channels = frames * 3 + 2;
     return 0;
 }
-int mer_film_zero(mer_context *ctx, float *film_dev, int32_t width, int32_t height) {
-    HIP_CHECK(ctx, hipMemsetAsync(film_dev, 0, (size_t) width * height * 5 * sizeof(float), ctx->stream));
+int mer_film_alloc_n(mer_context *ctx, int32_t width, int32_t height, int32_t channels, float **film_dev) {
+    HIP_CHECK(ctx, hipMalloc((void **) film_dev, (size_t) width * height * channels * sizeof(float)));
+    HIP_CHECK(ctx, hipMemsetAsync(*film_dev, 0, (size_t) width * height * channels * sizeof(float), ctx->stream));
     return 0;
 }
-int mer_film_download(mer_context *ctx, const float *film_dev, int32_t width, int32_t height, float *film_host) {
-    HIP_CHECK(ctx, hipMemcpyAsync(film_host, film_dev, (size_t) width * height * 5 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+int mer_film_zero_n(mer_context *ctx, float *film_dev, int32_t width, int32_t height, int32_t channels) {
+    HIP_CHECK(ctx, hipMemsetAsync(film_dev, 0, (size_t) width * height * channels * sizeof(float), ctx->stream));
+    return 0;
+}
+int mer_film_download_n(mer_context *ctx, const float *film_dev, int32_t width, int32_t height, int32_t channels, float *film_host) {
+    HIP_CHECK(ctx, hipMemcpyAsync(film_host, film_dev, (size_t) width * height * channels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+int mer_film_alloc(mer_context *ctx, int32_t width, int32_t height, float **film_dev) { return mer_film_alloc_n(ctx, width, height, 5, film_dev); }
+int mer_film_zero(mer_context *ctx, float *film_dev, int32_t width, int32_t height) { return mer_film_zero_n(ctx, film_dev, width, height, 5); }
+int mer_film_download(mer_context *ctx, const float *film_dev, int32_t width, int32_t height, float *film_host) {
+    return mer_film_download_n(ctx, film_dev, width, height, 5, film_host);
 }
 int mer_film_free(mer_context *ctx, float *film_dev) { HIP_CHECK(ctx, hipFree(film_dev)); return 0; }
 int mer_device_free(mer_context *ctx, void *p) { HIP_CHECK(ctx, hipFree(p)); return 0; }
@@ -461,6 +485,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     if (P.total_work == 0) return 0;
     const char *mode = getenv("MER_MODE");
     if (mode && std::strcmp(mode, "mega") == 0) {
+        if (scene->decomposition != MER_DECOMPOSITION_NONE) return fail(ctx, "MER_MODE=mega renders steady-state films only; use the default wavefront mode");
         if (scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0)
             return fail(ctx, "MER_MODE=mega does not sample point emitters; use the default wavefront mode");
         return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {

@@ -276,7 +276,8 @@ template <int RIF> struct Connector {
 // Medium::eval through the RIF (curved rays, heterogeneousrefractive.cpp:571-640).  Returns value * phase (to be
 // multiplied by the path throughput).  Synchronous: it runs inside K_event.
 template <bool CURVED, int RIF, int STEPPER, int SIGMA>
-__device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi, int depth) {
+__device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi, int depth, float &optLen) {
+    optLen = 0.0f;
     const mer_scene_desc &S = P.sc;
     const f3 I(S.point_intensity[0], S.point_intensity[1], S.point_intensity[2]);
     const f3 pp(S.point_position[0], S.point_position[1], S.point_position[2]);
@@ -288,6 +289,7 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
         const float dist = sqrtf(dot(dvec, dvec)), invDist = 1.0f / dist;
         dvec = dvec * invDist;
         f3 value = I * (invDist * invDist);
+        optLen = dist * S.rif_const;
         const float tExit = intersect_shape(S, ps, dvec, 0.0f, MER_INF);
         const bool crosses = tExit >= 0 && tExit < dist;
         const float L = crosses ? tExit : dist;
@@ -320,6 +322,7 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
         Connector<RIF> K(P);
         float w = 1.0f, od = 0, dist = 0; f3 dir(0, 0, 1), rev(0, 0, 1);
         if (!K.connect(ps, pp, normalize(pp - ps), rng, w, dir, rev, od, dist)) return f3(0, 0, 0);
+        optLen = od;
         f3 tr;
         if (SIGMA == MER_SIGMA_HOMOGENEOUS) tr = f3(expf(P.sigT.x * (-dist)), expf(P.sigT.y * (-dist)), expf(P.sigT.z * (-dist)));
         else {

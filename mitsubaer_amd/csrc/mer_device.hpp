@@ -178,10 +178,14 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
     // fast path: the point is still in the cached cell  <=>  0 <= q - corner < 1 on every axis (the subtraction is
     // exact, so this is the same decision as floor(q) == corner); the four RK4 stages of a half-voxel step mostly are
     float fx = px - cc.cx, fy = py - cc.cy, fz = pz - cc.cz;
-    if (!(fminf(fx, fminf(fy, fz)) >= 0.0f && fmaxf(fx, fmaxf(fy, fz)) < 1.0f)) {
-        int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
-        x1 = min(max(x1, 0), g.res[0] - 2); y1 = min(max(y1, 0), g.res[1] - 2); z1 = min(max(z1, 0), g.res[2] - 2);
-        cc.cx = (float) x1; cc.cy = (float) y1; cc.cz = (float) z1;
+    // all three in [0,1)  <=>  the largest of the three bit patterns, compared as unsigned, is below that of 1.0f (a negative
+    // value has the sign bit set; NaN and -0.0f take the slow path, which is always correct)
+    if (max(__float_as_uint(fx), max(__float_as_uint(fy), __float_as_uint(fz))) >= 0x3F800000u) {
+        // clamp in the float domain (exact: the operands are small integers), one v_med3_f32 per axis
+        cc.cx = __builtin_amdgcn_fmed3f(floorf(px), 0.0f, (float) (g.res[0] - 2));
+        cc.cy = __builtin_amdgcn_fmed3f(floorf(py), 0.0f, (float) (g.res[1] - 2));
+        cc.cz = __builtin_amdgcn_fmed3f(floorf(pz), 0.0f, (float) (g.res[2] - 2));
+        const int x1 = (int) cc.cx, y1 = (int) cc.cy, z1 = (int) cc.cz;
         fx = px - cc.cx; fy = py - cc.cy; fz = pz - cc.cz;
         const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);
         if (base != cc.cell) {
@@ -405,7 +409,8 @@ struct Params {
     int32_t spp_begin, spp_count, spp_stride, tile_rank, tile_count;
     int32_t tiles_x, tiles_y, ntiles_mine;
     uint64_t total_work;
-    float *film;
+    float *film;                        // float[H][W][film_ch]: RGB per frame, alpha, weight
+    int32_t frames, film_ch;            // frames = 1 and film_ch = 5 in steady state
     float *path_out;                    // per-path radiance (mer_render_paths) or NULL
     unsigned long long *counters;       // MER_C_COUNT
     unsigned long long *work_counter;
@@ -478,7 +483,8 @@ __device__ __forceinline__ float mi_weight(float a, float b) { a *= a; b *= b; r
 
 // ImageBlock::put (include/mitsuba/render/imageblock.h:124-205) with one block = the whole image;
 // accumulation by float atomics (replaces film->put under a mutex, renderproc.cpp:142-149)
-__device__ __forceinline__ void film_put(const Params &P, float px, float py, f3 L, float alpha) {
+// what = 1: RGB into frame `bin`; what = 2: alpha + weight; what = 3: both (steady state: bin 0)
+__device__ __forceinline__ void film_splat(const Params &P, float px, float py, f3 L, float alpha, int bin, int what) {
     const float temp[5] = {L.x, L.y, L.z, alpha, 1.0f};
 #pragma unroll
     for (int i = 0; i < 5; ++i) if (!isfinite(temp[i])) return;          // imageblock.h:148-152
@@ -491,11 +497,24 @@ __device__ __forceinline__ void film_put(const Params &P, float px, float py, f3
         for (int x = minx; x <= maxx; ++x) {
             const float wx = P.fvalues[min((int) fabsf(((float) x - posx) * P.fscale), 31)];
             const float weight = wx * wy;
-            float *dest = P.film + ((size_t) y * W + x) * 5;
+            float *dest = P.film + ((size_t) y * W + x) * P.film_ch;
+            if (what & 1) {
 #pragma unroll
-            for (int k = 0; k < 5; ++k) atomicAdd(dest + k, weight * temp[k]);
+                for (int k = 0; k < 3; ++k) atomicAdd(dest + bin * 3 + k, weight * temp[k]);
+            }
+            if (what & 2) { atomicAdd(dest + P.film_ch - 2, weight * temp[3]); atomicAdd(dest + P.film_ch - 1, weight * temp[4]); }
         }
     }
+}
+__device__ __forceinline__ void film_put(const Params &P, float px, float py, f3 L, float alpha) {
+    film_splat(P, px, py, L, alpha, 0, P.sc.decomposition ? 2 : 3);     // transient: the RGB went out per contribution
+}
+// Transient film: one radiance contribution binned by its optical path length (bdpt_proc.cpp:449-470)
+__device__ __forceinline__ void film_contribute(const Params &P, float px, float py, f3 value, float pathLength) {
+    if (!P.sc.decomposition || P.path_out || is_zero(value)) return;
+    const float b = floorf((pathLength - P.sc.min_bound) / P.sc.bin_width);
+    if (!(b >= 0.0f) || !(b < (float) P.frames)) return;
+    film_splat(P, px, py, value, 0.0f, (int) b, 1);
 }
 
 }  // namespace mer

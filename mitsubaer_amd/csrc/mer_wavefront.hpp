@@ -20,7 +20,7 @@ enum { H_PX = 0, H_PY, H_PZ, H_VX, H_VY, H_VZ, H_OPT, H_DIST, H_REM, H_HPREV, H_
 // cold words (K_event only)
 enum { CO_PXF = H_COUNT, CO_PYF, CO_LX, CO_LY, CO_LZ, CO_TX, CO_TY, CO_TZ, CO_DEPTH, CO_PFLAGS, CO_PSX, CO_PSY, CO_PSZ,
        CO_DSX, CO_DSY, CO_DSZ, CO_DDX, CO_DDY, CO_DDZ, CO_WIX, CO_WIY, CO_WIZ, CO_PHASEPDF, CO_ITST, CO_N0, CO_TRSUM,
-       CO_SDENS, CO_TMIN, CO_WNEXT_LO, CO_WNEXT_HI, CO_WLEFT, SLOT_WORDS };
+       CO_SDENS, CO_TMIN, CO_WNEXT_LO, CO_WNEXT_HI, CO_WLEFT, CO_PLEN, CO_TROPT, SLOT_WORDS };
 
 // H_FLAGS: st[1:0] ev[5:2] kind[7:6] seg_inf[8] backstep[9] walk[11:10]
 __device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg_inf, int backstep, int walk) {
@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
                 f3 o, d; float mint, maxt;
                 sample_ray(P, px, py, o, d, mint, maxt);
                 f3 L(0, 0, 0);
+                float plen = 0.0f;                                   // transient film: optical path length so far
                 const float itsT = intersect_shape(S, o, d, mint, maxt);
                 if (itsT < 0) { if (!S.hide_emitters) L = env; }
                 else if (1 >= maxDepth && maxDepth != -1) { }
@@ -127,13 +128,13 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
                     bool medium = true;
                     if (!CURVED) { const f3 ro = o + d * itsT; medium = intersect_shape(S, ro, d, MER_EPSILON, MER_INF) >= 0; }
                     if (!(2 <= maxDepth || maxDepth < 0)) { }
-                    else if (!medium) { if (!S.hide_emitters) L = env; }
+                    else if (!medium) { if (!S.hide_emitters) L = env; if (!S.calibrated_transient) plen = itsT; }
                     else hit = true;
                 }
                 if (!hit) {
                     C.paths++;
                     if (P.path_out) { float *q = P.path_out + ((size_t) y * S.width + x) * 3; q[0] = L.x; q[1] = L.y; q[2] = L.z; }
-                    else film_put(P, px, py, L, 1.0f);
+                    else { film_contribute(P, px, py, L, plen); film_put(P, px, py, L, 1.0f); }
                 }
             }
         }
@@ -272,6 +273,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     WalkT W; Rng rng; uint32_t pixel = 0, sample = 0;
     W.cc.reset();
     float px = 0, py = 0, sigma = 0, phasePdf = 0, itsT = 0;
+    float plen = 0, trOpt = 0;                 // transient film: optical path length sensor -> vertex; length of the last NEE / look-up walk
     f3 L(0, 0, 0), T(1, 1, 1), ps(0, 0, 0), dsave(0, 0, 1), dd(0, 0, 1), wi(0, 0, 1), trv(1, 1, 1);
     int depth = 1, flags = F_EMITTED, px_i = 0, py_i = 0;
     bool starved = false;
@@ -285,6 +287,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
         dd = f3(SLOTF(CO_DDX), SLOTF(CO_DDY), SLOTF(CO_DDZ)); wi = f3(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
         phasePdf = SLOTF(CO_PHASEPDF); itsT = SLOTF(CO_ITST); W.n0 = SLOTF(CO_N0); W.trsum = SLOTF(CO_TRSUM);
         W.sdens = SLOTF(CO_SDENS); W.tmin = SLOTF(CO_TMIN);
+        plen = SLOTF(CO_PLEN); trOpt = SLOTF(CO_TROPT);
         px_i = (int) (pixel % (uint32_t) S.width); py_i = (int) (pixel / (uint32_t) S.width);
     } else {
         W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = 0; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.dist = 0;
@@ -316,22 +319,24 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             f3 o, d; float mint, maxt;
             sample_ray(P, px, py, o, d, mint, maxt);
             L = f3(0, 0, 0); T = f3(1, 1, 1); depth = 1; flags = F_EMITTED;
+            plen = 0.0f; trOpt = 0.0f;
             C.paths++;
             ev = EV_NONE;
             itsT = intersect_shape(S, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
             if (itsT < 0) {
-                if (!S.hide_emitters) L = L + T * env;                         // volpath.cpp:194-201
+                if (!S.hide_emitters) { L = L + T * env; film_contribute(P, px, py, T * env, plen); }   // volpath.cpp:194-201
                 ev = EV_PATH_DONE;
             } else if (depth >= maxDepth && maxDepth != -1) ev = EV_PATH_DONE;
             else {
                 (void) rng.next1D(); (void) rng.next1D();                      // null bsdf->sample(..., nextSample2D())
+                if (!S.calibrated_transient) plen += itsT;                     // the camera edge (bdpt_proc.cpp:163-176)
                 const f3 ro = o + d * itsT;
                 bool medium = true;
                 if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
                 else { itsT = intersect_shape(S, ro, d, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); if (!itsValid) medium = false; }
                 depth++;
                 if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
-                else if (!medium) { if (!S.hide_emitters) L = L + T * env; ev = EV_PATH_DONE; }
+                else if (!medium) { if (!S.hide_emitters) { L = L + T * env; film_contribute(P, px, py, T * env, plen); } ev = EV_PATH_DONE; }
                 else { C.segments++; ps = ro; dsave = d; ev = W.begin(P, rng, C, K_FREE, ro, d, itsT); }
             }
             st = ST_MARCH;
@@ -342,6 +347,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
         if (ev == EV_ARRIVED) {
             ev = W.on_arrived(P, rng, C, sigma);
         } else if (ev == EV_EXITED) {
+            if (CURVED && W.kind != K_FREE) trOpt = W.opt;     // this transmittance walk reached the boundary
             ev = (W.kind == K_FREE) ? EV_FAIL : EV_WALK_END;
         } else if (ev == EV_GATE_FAIL) {
             if (W.kind == K_FREE) ev = EV_PATH_DONE;          // transmittance 0 => nothing further contributes
@@ -364,9 +370,12 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             }
             if (!success) { ev = EV_FAIL; continue; }
             C.real++;
+            plen += CURVED ? m.opticalLength : m.t * S.rif_const;                     // bdpt_proc.cpp:158-176
             if (depth >= maxDepth && maxDepth != -1) { ev = EV_PATH_DONE; continue; }
-            if (hasEmission && SIGMA == MER_SIGMA_GRID)
+            if (hasEmission && SIGMA == MER_SIGMA_GRID) {
                 L = L + T * f3(S.emission[0], S.emission[1], S.emission[2]) * m.refRatioSq;
+                film_contribute(P, px, py, T * f3(S.emission[0], S.emission[1], S.emission[2]) * m.refRatioSq, plen);
+            }
             T = T * (m.sigmaS * m.transmittance / m.pdfSuccess);
             if (CURVED) T = T * m.refRatioSq;                                         // edge.cpp:91-93
             wi = CURVED ? normalize(-m.d) : -W.v;                                     // vertex.cpp:251-255
@@ -378,11 +387,13 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                 const float s2x = rng.next1D(), s2y = rng.next1D();
                 dd = square_to_uniform_sphere(s2x, s2y);
                 W.kind = K_NEE;
+                trOpt = 0.0f;
                 if (interactions != 0) {                                              // scene.cpp:619-678: one null crossing
                     float tExit = 0.0f;
                     if (!CURVED) tExit = intersect_shape(S, ps, dd, 0.0f, MER_INF);
                     if (tExit >= 0) {
                         itsT = tExit;
+                        if (!CURVED) trOpt = tExit * S.rif_const;
                         ev = W.begin(P, rng, C, K_NEE, ps, dd, tExit);
                         if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - tExit);
                     } else { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
@@ -399,6 +410,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                     if (phaseVal != 0) {
                         const float weight = mi_weight(dpdf, phaseVal);              // env emitter is "on surface": constant.cpp:47
                         L = L + T * value * phaseVal * weight;
+                        film_contribute(P, px, py, T * value * phaseVal * weight, plen + trOpt);
                     }
                 }
                 ev = EV_PHASE;
@@ -409,6 +421,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                 if (!blocked && !is_zero(tr)) {
                     const f3 value = tr * env;
                     L = L + T * value * mi_weight(phasePdf, MER_INV_FOURPI);
+                    film_contribute(P, px, py, T * value * mi_weight(phasePdf, MER_INV_FOURPI), plen + trOpt);
                 }
                 ev = EV_AFTER_LOOKUP;
             }
@@ -418,7 +431,10 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             // own (K_connect) in which every lane solves one; the path resumes at EV_PHASE2 in the next pass.
             if (POINT && ev == EV_PHASE) {
                 if (CURVED) { connecting = true; break; }
-                L = L + T * point_nee<false, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth);
+                float optLen = 0.0f;
+                const f3 c = T * point_nee<false, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth, optLen);
+                L = L + c;
+                film_contribute(P, px, py, c, plen + optLen);
             }
             // ---- phase function sampling: volpath.cpp:149-160
             const float p2x = rng.next1D(), p2y = rng.next1D();
@@ -429,6 +445,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             else { itsT = intersect_shape(S, ps, wo, 0.0f, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
             if (hasEnv) {
                 W.kind = K_LOOKUP;
+                trOpt = (!CURVED && itsValid) ? itsT * S.rif_const : 0.0f;
                 if (!CURVED && !itsValid) { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
                 else {
                     ev = W.begin(P, rng, C, K_LOOKUP, ps, wo, itsT);
@@ -453,17 +470,18 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             // ---- no medium interaction: volpath.cpp:183-201,289-301
             MRec m;
             finish_free_flight(P, C, W, false, 0.0f, m);
+            plen += CURVED ? m.opticalLength : itsT * S.rif_const;
             T = T * (m.transmittance / m.pdfFailure);
             if (CURVED) { T = T * m.refRatioSq; SET_FLAG(F_ITSVALID, true); }         // edge.cpp:45-60
             ev = EV_PATH_DONE;
             if (!itsValid) {
-                if (emitted && (!S.hide_emitters || scattered)) L = L + T * env;
+                if (emitted && (!S.hide_emitters || scattered)) { L = L + T * env; film_contribute(P, px, py, T * env, plen); }
             } else if (!(depth >= maxDepth && maxDepth != -1)) {
                 (void) rng.next1D(); (void) rng.next1D();                             // null BSDF sample
                 SET_FLAG(F_EMITTED, !scattered);
                 depth++;
                 if (depth <= maxDepth || maxDepth < 0)
-                    if (emitted && (!S.hide_emitters || scattered)) L = L + T * env;
+                    if (emitted && (!S.hide_emitters || scattered)) { L = L + T * env; film_contribute(P, px, py, T * env, plen); }
             }
         } else {  // EV_PATH_DONE: ImageBlock::put (imageblock.h:124-205)
             if (P.path_out) {
@@ -495,6 +513,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
         SLOT(CO_PHASEPDF) = __float_as_uint(phasePdf); SLOT(CO_ITST) = __float_as_uint(itsT);
         SLOT(CO_N0) = __float_as_uint(W.n0); SLOT(CO_TRSUM) = __float_as_uint(W.trsum);
         SLOT(CO_SDENS) = __float_as_uint(W.sdens); SLOT(CO_TMIN) = __float_as_uint(W.tmin);
+        SLOT(CO_PLEN) = __float_as_uint(plen); SLOT(CO_TROPT) = __float_as_uint(trOpt);
         marching = !connecting;
     }
     }   // j < count
@@ -524,7 +543,9 @@ __global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P
         rng.inc = (((((uint64_t) sample) << 32) | (uint64_t) pixel) << 1) | 1ULL;
         const f3 T(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ)), ps(SLOTF(CO_PSX), SLOTF(CO_PSY), SLOTF(CO_PSZ)), wi(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
         const int depth = (int) SLOT(CO_DEPTH);
-        const f3 c = T * point_nee<true, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth);
+        float optLen = 0.0f;
+        const f3 c = T * point_nee<true, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth, optLen);
+        film_contribute(P, SLOTF(CO_PXF), SLOTF(CO_PYF), c, SLOTF(CO_PLEN) + optLen);
         SLOT(CO_LX) = __float_as_uint(SLOTF(CO_LX) + c.x); SLOT(CO_LY) = __float_as_uint(SLOTF(CO_LY) + c.y); SLOT(CO_LZ) = __float_as_uint(SLOTF(CO_LZ) + c.z);
         SLOT(H_RNG_LO) = (uint32_t) rng.state; SLOT(H_RNG_HI) = (uint32_t) (rng.state >> 32);
     }

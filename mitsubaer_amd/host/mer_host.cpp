@@ -338,8 +338,18 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
         auto o = std::make_shared<Film>();
         o->width = props.getInteger("width", 768); o->height = props.getInteger("height", 576);          // film.cpp
         (void) props.getBoolean("banner", true);
-        const std::string dec = lower(props.getString("decomposition", "none"));
-        if (dec != "none") Log_EError("film: decomposition \"" + dec + "\" (transient / bounce films) is a 'next' row and not built yet");
+        const std::string dec = lower(props.getString("decomposition", "none"));                         // film.cpp:56-84
+        if (dec == "none") o->decomposition = MER_DECOMPOSITION_NONE;
+        else if (dec == "transient") o->decomposition = MER_DECOMPOSITION_TRANSIENT;
+        else if (dec == "bounce") Log_EError("film: decomposition \"bounce\" is not built on the GPU path");
+        else Log_EError("The \"decomposition\" parameter must be equal toeither \"none\", \"transient\", or \"bounce\"!");
+        o->minBound = props.getFloat("minBound", 0.0f); o->maxBound = props.getFloat("maxBound", 0.0f);
+        o->binWidth = props.getFloat("binWidth", 1.0f);
+        o->calibratedTransient = props.getBoolean("calibratedTransient", false);
+        if (lower(props.getString("modulationType", "none")) != "none")
+            Log_EError("film: path-length modulation (CW-ToF, src/librender/pathlengthsampler.cpp) is not built on the GPU path");
+        if (o->decomposition == MER_DECOMPOSITION_TRANSIENT && !(o->frames() >= 1 && o->frames() <= 4096))
+            Log_EError("film: transient decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames");
         out = o;
     } else if (tag == "rfilter") {
         auto o = std::make_shared<ReconstructionFilter>();
@@ -570,6 +580,8 @@ void Integrator::flatten(const Scene &scene, mer_scene_desc &d) const {
     std::memset(&d, 0, sizeof(d));
     const Sensor &se = *scene.sensor; const Film &fi = *se.film;
     d.width = fi.width; d.height = fi.height;
+    d.decomposition = fi.decomposition; d.min_bound = fi.minBound; d.max_bound = fi.maxBound; d.bin_width = fi.binWidth;
+    d.calibrated_transient = fi.calibratedTransient ? 1 : 0;
     const float aspect = (float) fi.width / (float) fi.height;
     std::string axis = se.fovAxis;                                        // sensor.cpp:246-260
     if (axis == "smaller") axis = aspect > 1 ? "y" : "x"; else if (axis == "larger") axis = aspect > 1 ? "x" : "y";
@@ -622,7 +634,7 @@ std::vector<float> Integrator::render(const Scene &scene, int device, int spp, u
     if (spp <= 0) spp = scene.sensor->sampler->sampleCount;
     mer_context *ctx = NULL;
     if (mer_context_create(device, &ctx)) Log_EError(mer_last_error(NULL));
-    std::vector<float> film((size_t) d.width * d.height * 5, 0.0f);
+    int32_t channels = 5;
     auto fail = [&](void) { std::string msg = mer_last_error(ctx); mer_context_destroy(ctx); Log_EError(msg); };
     const Medium &m = *([&]() -> const Shape * { for (auto &s : scene.shapes) if (s->interior) return s.get(); return (const Shape *) NULL; }())->interior;
     auto upload = [&](const VolumeDataSource &v, int lay) -> mer_volume {
@@ -639,20 +651,24 @@ std::vector<float> Integrator::render(const Scene &scene, int device, int spp, u
         if (m.rif->isSpline() && mer_volume_build_spline(ctx, d.rif)) fail();
     }
     float *film_dev = NULL;
-    if (mer_film_alloc(ctx, d.width, d.height, &film_dev)) fail();
+    if (mer_film_channels(ctx, &d, &channels)) fail();
+    std::vector<float> film((size_t) d.width * d.height * channels, 0.0f);
+    if (mer_film_alloc_n(ctx, d.width, d.height, channels, &film_dev)) fail();
     mer_shard sh = {0, spp, 1, 0, 1};
     if (mer_render(ctx, &d, &sh, seed, film_dev)) fail();
-    if (mer_film_download(ctx, film_dev, d.width, d.height, film.data())) fail();
+    if (mer_film_download_n(ctx, film_dev, d.width, d.height, channels, film.data())) fail();
     mer_film_free(ctx, film_dev);
     mer_context_destroy(ctx);
     return film;
 }
 
-std::vector<float> develop(const std::vector<float> &film, int w, int h) {
-    std::vector<float> rgb((size_t) w * h * 3);
+std::vector<float> develop(const std::vector<float> &film, int w, int h, int frames) {
+    const int ch = frames * 3 + 2;
+    std::vector<float> rgb((size_t) frames * w * h * 3);
     for (size_t p = 0; p < (size_t) w * h; p++) {
-        const float wgt = film[p * 5 + 4], inv = wgt > 0 ? 1.0f / wgt : 0.0f;          // HDRFilm::develop
-        for (int c = 0; c < 3; c++) rgb[p * 3 + c] = film[p * 5 + c] * inv;
+        const float wgt = film[p * ch + ch - 1], inv = wgt > 0 ? 1.0f / wgt : 0.0f;     // HDRFilm::develop
+        for (int f = 0; f < frames; f++)
+            for (int c = 0; c < 3; c++) rgb[((size_t) f * w * h + p) * 3 + c] = film[p * ch + f * 3 + c] * inv;
     }
     return rgb;
 }

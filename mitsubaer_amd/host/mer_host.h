@@ -15,6 +15,7 @@
 //
 // Errors: like Log(EError) in the reference (src/libcore/logger.cpp:100-147) every failure throws std::runtime_error.
 #pragma once
+#include <cmath>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -145,6 +146,10 @@ public:
     const char *getClassName() const override { return "Film"; }
     void addChild(const std::string &name, ObjRef child) override;
     int width = 768, height = 576;
+    /// src/librender/film.cpp:56-84
+    int decomposition = MER_DECOMPOSITION_NONE; float minBound = 0.0f, maxBound = 0.0f, binWidth = 1.0f; bool calibratedTransient = false;
+    int frames() const { return decomposition == MER_DECOMPOSITION_TRANSIENT ? (int) std::ceil((maxBound - minBound) / binWidth) : 1; }
+    int channels() const { return frames() * 3 + 2; }
     std::shared_ptr<ReconstructionFilter> rfilter;
 };
 class Sensor : public ConfigurableObject {
@@ -192,8 +197,8 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
 std::shared_ptr<Scene> loadScene(const std::string &path, const std::map<std::string, std::string> &defines);
 std::shared_ptr<Scene> loadSceneFromString(const std::string &xml, const std::map<std::string, std::string> &defines, const std::string &baseDir);
 
-/// film [h][w][5] -> developed RGB [h][w][3] (HDRFilm::develop: divide by the weight channel)
-std::vector<float> develop(const std::vector<float> &film, int w, int h);
+/// film [h][w][frames*3+2] -> developed RGB [frames][h][w][3] (HDRFilm::develop: divide by the weight channel)
+std::vector<float> develop(const std::vector<float> &film, int w, int h, int frames = 1);
 void writeNpy(const std::string &path, const float *data, int h, int w, int c);
 void writePfm(const std::string &path, const float *rgb, int h, int w);
 

@@ -27,11 +27,18 @@ int main(int argc, char **argv) {
         auto scene = merhost::loadScene(scenePath, defines);
         const int w = scene->sensor->film->width, h = scene->sensor->film->height;
         std::vector<float> film = scene->integrator->render(*scene, device, spp, seed, layout);
-        if (raw) merhost::writeNpy(out, film.data(), h, w, 5);
+        const int frames = scene->sensor->film->frames();
+        if (raw) merhost::writeNpy(out, film.data(), h, w, frames * 3 + 2);
         else {
-            std::vector<float> rgb = merhost::develop(film, w, h);
-            if (out.size() > 4 && out.substr(out.size() - 4) == ".pfm") merhost::writePfm(out, rgb.data(), h, w);
-            else merhost::writeNpy(out, rgb.data(), h, w, 3);
+            std::vector<float> rgb = merhost::develop(film, w, h, frames);
+            const bool pfm = out.size() > 4 && out.substr(out.size() - 4) == ".pfm";
+            if (frames == 1) { if (pfm) merhost::writePfm(out, rgb.data(), h, w); else merhost::writeNpy(out, rgb.data(), h, w, 3); }
+            else if (pfm) {                       // one file per frame, as the reference's hdrfilm writes <name>_<frame>
+                for (int f = 0; f < frames; f++) {
+                    char suffix[32]; std::snprintf(suffix, sizeof(suffix), "_%04d.pfm", f);
+                    merhost::writePfm(out.substr(0, out.size() - 4) + suffix, rgb.data() + (size_t) f * w * h * 3, h, w);
+                }
+            } else merhost::writeNpy(out, rgb.data(), frames * h, w, 3);     // [frames*h][w][3]
         }
         std::printf("wrote %s (%dx%d)\n", out.c_str(), w, h);
     } catch (const std::exception &e) {

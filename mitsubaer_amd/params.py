@@ -18,6 +18,7 @@ TR_WOODCOCK2, TR_RATIO = 0, 1
 STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL = 0, 1, 2
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 ALBEDO_CONST, ALBEDO_GRID = 0, 1
+DECOMPOSITION_NONE, DECOMPOSITION_TRANSIENT = 0, 1
 
 
 def look_at(origin, target, up):
@@ -67,6 +68,9 @@ class SceneParams:
         self.env_radiance = [1.0, 1.0, 1.0]
         self.emission = [0.0, 0.0, 0.0]
         self.point_position = [0.0, 0.0, 0.0]; self.point_intensity = [0.0, 0.0, 0.0]     # emitter `point`
+        # film decomposition (src/librender/film.cpp:56-84): 0 none | 1 transient; frames = ceil((max-min)/binWidth)
+        self.decomposition = DECOMPOSITION_NONE; self.min_bound = 0.0; self.max_bound = 0.0; self.bin_width = 1.0
+        self.calibrated_transient = False
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("unknown scene parameter '%s'" % k)

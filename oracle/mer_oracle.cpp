@@ -505,6 +505,7 @@ struct Scene {
     Float mediumSamplingWeight, samplingDensity;
     Float maxDensity, invMaxDensity;
     bool curved;
+    int frames = 1;                /* film.cpp:71-78 */
 
     bool configure(const orc_scene &in) {
         s = in;
@@ -517,6 +518,11 @@ struct Scene {
         }
         if (s.albedo_mode == ORC_ALBEDO_GRID) albedoGrid.configure(s.albedo_grid);
         curved = s.rif_mode != ORC_RIF_CONST;
+        frames = 1;
+        if (s.decomposition == 1) {
+            frames = (int) std::ceil((s.max_bound - s.min_bound) / s.bin_width);      /* film.cpp:71-74 */
+            if (!(frames >= 1) || frames > 4096) { g_err = "film: transient decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames"; return false; }
+        } else if (s.decomposition != 0) { g_err = "The \"decomposition\" parameter must be equal toeither \"none\", \"transient\", or \"bounce\"!"; return false; }
         if (s.rif_double) rifD.configure(s); else rifF.configure(s);
         if (!s.rif_double && s.rif_mode == ORC_RIF_CONST) rifF.cst = s.rif_const;
         /* homogeneous coefficients: src/librender/medium.cpp:26-36 */
@@ -947,6 +953,17 @@ template <typename FLOAT> struct Connector {
 struct Walker {
     const Scene &S; Pcg32 &rng; Counters &C;
     Walker(const Scene &s, Pcg32 &r, Counters &c) : S(s), rng(r), C(c) {}
+    /* transient film (N1): optical length of the last transmittance walk that reached the boundary, and the per-sample
+       decomposition values (frames x RGB) the contributions are binned into (bdpt_proc.cpp:449-470 restated for volpath) */
+    Float lastTrOpt = 0;
+    Float *decomp = nullptr;
+    inline void contribute(const Spec &value, Float pathLength) {
+        if (!decomp || value.isZero()) return;
+        const Float b = std::floor((pathLength - S.s.min_bound) / S.s.bin_width);
+        if (!(b >= 0) || !(b < (Float) S.frames)) return;      /* size_t binIndex >= 0 && binIndex < m_frames */
+        const int bin = (int) b;
+        for (int k = 0; k < 3; ++k) decomp[bin * 3 + k] += value[k];
+    }
 
     inline Float sigmaTAt(const Vec &p) const {     /* heterogeneous.cpp:707-717 (isotropic medium) * m_scale */
         C.c[ORC_C_TENTATIVE]++;
@@ -1133,6 +1150,7 @@ struct Walker {
             v *= T.R.value(p, C);
             FLOAT distSurf = 0, opt = 0;
             T.traceTillBoundary(p, v, distSurf, opt);
+            lastTrOpt = (Float) opt;
             Spec tr;                                           /* heterogeneousrefractive.cpp:393-400 */
             for (int i = 0; i < 3; ++i) tr[i] = S.sigmaT[i] != 0 ? std::exp(S.sigmaT[i] * (Float) (-distSurf)) : 1.0f;
             return tr;
@@ -1146,7 +1164,7 @@ struct Walker {
             Float Tr = 1.0f;
             while (true) {
                 FLOAT s = (FLOAT) (-std::log(1 - rng.next1D()) * S.invMaxDensity);
-                if (!T.trace(p, v, s, distSurf, opt)) break;
+                if (!T.trace(p, v, s, distSurf, opt)) { lastTrOpt = (Float) opt; break; }
                 Float density = sigmaTAt(Vec(p));
                 if (S.s.tr_estimator == ORC_TR_RATIO) { Tr *= 1.0f - density * S.invMaxDensity; if (Tr == 0.0f) break; }
                 else if (density * S.invMaxDensity > rng.next1D()) { Tr = 0.0f; break; }
@@ -1196,6 +1214,7 @@ struct Walker {
     /* Medium::evalTransmittance over [0,maxt] (straight) or to the boundary (curved) */
     Spec evalTransmittance(const Vec &o, const Vec &d, Float maxt) {
         if (!S.curved) {
+            lastTrOpt = maxt * S.s.rif_const;
             if (S.s.sigma_mode == ORC_SIGMA_GRID) return evalTransmittanceHet(o, d, maxt);
             Spec tr;                                           /* homogeneous.cpp:264-273 */
             Float negLength = 0.0f - maxt;
@@ -1220,6 +1239,7 @@ struct Walker {
         const bool hasPoint = !pointI.isZero();
         const Vec pointP(P.point_position[0], P.point_position[1], P.point_position[2]);
         Spec Li(0.0f), throughput(1.0f);
+        Float plen = 0;                                            /* optical path length sensor -> current vertex (transient film) */
         Float eta = 1.0f;
         bool scattered = false, medium = false, emitted = true;   /* rRec.type & EEmittedRadiance */
         int depth = 1;
@@ -1230,11 +1250,13 @@ struct Walker {
 
         while (depth <= maxDepth || maxDepth < 0) {
             if (medium && sampleDistance(ro, rd, itsT, mRec)) {
+                plen += S.curved ? mRec.opticalLength : mRec.t * P.rif_const;           /* bdpt_proc.cpp:158-176 */
                 if (depth >= maxDepth && maxDepth != -1) break;
                 if (hasEmission && P.sigma_mode == ORC_SIGMA_GRID) {
                     /* collision estimator for volumetric emission (new, config 5): eps(p)/sigma_t(p),
                        eps = emission * density(p) * scale ; sigma_t = density(p)*scale  => ratio = emission */
                     Li += throughput * Spec(P.emission[0], P.emission[1], P.emission[2]) * mRec.refRatioSq;
+                    contribute(throughput * Spec(P.emission[0], P.emission[1], P.emission[2]) * mRec.refRatioSq, plen);
                 }
                 throughput *= mRec.sigmaS * mRec.transmittance / mRec.pdfSuccess;       /* volpath.cpp:113 */
                 if (S.curved) throughput *= mRec.refRatioSq;                              /* edge.cpp:91-93 */
@@ -1249,6 +1271,7 @@ struct Walker {
                     Float dpdf = INV_FOURPI_F;
                     Spec value = env / dpdf;
                     Spec tr(0.0f);
+                    lastTrOpt = 0;
                     if (interactions != 0) {                 /* scene.cpp:619-678: one null crossing is needed */
                         Float tExit = 0;
                         if (!S.curved) {
@@ -1264,6 +1287,7 @@ struct Walker {
                             Float phasePdf = phaseVal;       /* env emitter isOnSurface: constant.cpp:47 */
                             Float weight = miWeight(dpdf, phasePdf);
                             Li += throughput * value * phaseVal * weight;
+                            contribute(throughput * value * phaseVal * weight, plen + lastTrOpt);
                         }
                     }
                 }
@@ -1282,25 +1306,29 @@ struct Walker {
                         if (crosses && interactions == 0) tr = Spec(0.0f);
                         else tr = evalTransmittance(mRec.p, dvec, crosses ? tExit : dist);
                         value *= tr;
-                        if (!value.isZero()) Li += throughput * value * phaseEval(P.phase, P.g, wi, dvec);
+                        if (!value.isZero()) {
+                            Li += throughput * value * phaseEval(P.phase, P.g, wi, dvec);
+                            contribute(throughput * value * phaseEval(P.phase, P.g, wi, dvec), plen + dist * P.rif_const);
+                        }
                     } else {
                         /* connection through the RIF: Medium::eval (heterogeneousrefractive.cpp:571-640) */
-                        bool ok; Float w = 1, dist = 0; Vec dir; Spec tr(0.0f);
+                        bool ok; Float w = 1, dist = 0, optD = 0; Vec dir; Spec tr(0.0f);
                         if (S.s.rif_double) {
                             Connector<double> K(S, C, rng); V3<double> d2, rev; double ww = 1, od = 0, di = 0;
                             V3<double> a(mRec.p), b(pointP);
                             ok = K.makeDirectConnections(a, b, normalize(b - a), ww, d2, rev, od, di);
-                            if (ok) { w = (Float) ww; dist = (Float) di; dir = Vec(d2); tr = connectionTransmittance<double>(mRec.p, d2, di); }
+                            if (ok) { w = (Float) ww; dist = (Float) di; optD = (Float) od; dir = Vec(d2); tr = connectionTransmittance<double>(mRec.p, d2, di); }
                         } else {
                             Connector<float> K(S, C, rng); V3<float> d2, rev; float ww = 1, od = 0, di = 0;
                             V3<float> a(mRec.p), b(pointP);
                             ok = K.makeDirectConnections(a, b, normalize(b - a), ww, d2, rev, od, di);
-                            if (ok) { w = ww; dist = di; dir = d2; tr = connectionTransmittance<float>(mRec.p, d2, di); }
+                            if (ok) { w = ww; dist = di; optD = od; dir = d2; tr = connectionTransmittance<float>(mRec.p, d2, di); }
                         }
                         if (ok && !tr.isZero()) {
                             const Float invDist = 1.0f / dist;
                             Spec value = pointI * (invDist * invDist) * tr * w;
                             Li += throughput * value * phaseEval(P.phase, P.g, wi, normalize(dir));
+                            contribute(throughput * value * phaseEval(P.phase, P.g, wi, normalize(dir)), plen + optD);
                         }
                     }
                 }
@@ -1316,6 +1344,7 @@ struct Walker {
                 else { itsT = S.intersectShape(ro, rd, 0.0f, std::numeric_limits<Float>::infinity()); itsValid = itsT >= 0; }
                 if (hasEnv) {
                     Spec tr(1.0f);
+                    lastTrOpt = 0;
                     int maxInteractions = maxDepth - depth - 1;
                     bool blocked = false;
                     if (!S.curved) {
@@ -1329,11 +1358,13 @@ struct Walker {
                         Spec value = tr * env;
                         Float emitterPdf = INV_FOURPI_F;
                         Li += throughput * value * miWeight(phasePdf, emitterPdf);
+                        contribute(throughput * value * miWeight(phasePdf, emitterPdf), plen + lastTrOpt);
                     }
                 }
                 emitted = false;                              /* ERadianceNoEmission */
             } else {
                 if (medium) {
+                    plen += S.curved ? mRec.opticalLength : itsT * P.rif_const;
                     throughput *= mRec.transmittance / mRec.pdfFailure;                  /* volpath.cpp:188-189 */
                     if (S.curved) {
                         throughput *= mRec.refRatioSq;
@@ -1342,12 +1373,13 @@ struct Walker {
                     }
                 }
                 if (!itsValid) {
-                    if (emitted && (!P.hide_emitters || scattered)) Li += throughput * env;   /* volpath.cpp:194-201 */
+                    if (emitted && (!P.hide_emitters || scattered)) { Li += throughput * env; contribute(throughput * env, plen); }   /* volpath.cpp:194-201 */
                     break;
                 }
                 if (depth >= maxDepth && maxDepth != -1) break;
                 /* null BSDF (shape.cpp:48-70): no NEE (not smooth), pass-through sample */
                 (void) rng.next1D(); (void) rng.next1D();     /* bsdf->sample(bRec, pdf, rRec.nextSample2D()) */
+                if (!medium && !P.calibrated_transient) plen += itsT;      /* the camera edge (bdpt_proc.cpp:163-176: startIndex 2 | 3) */
                 ro = ro + rd * itsT;
                 medium = !medium;
                 emitted = !scattered;                         /* volpath.cpp:293-301 */
@@ -1372,9 +1404,9 @@ struct Walker {
 
 /* ------------------------------------------------------------------ A11 pixel loop + film */
 /* include/mitsuba/render/imageblock.h:124-205 with block = whole image (borders cropped) */
-inline bool filmPut(const Scene &S, float *film, Float px, Float py, const Spec &spec, Float alpha) {
-    Float temp[5] = {spec[0], spec[1], spec[2], alpha, 1.0f};
-    for (int i = 0; i < 5; ++i) if (!std::isfinite(temp[i])) return false;
+inline bool filmPut(const Scene &S, float *film, Float px, Float py, const Float *temp) {
+    const int ch = S.frames * 3 + 2;                  /* RGB per frame, alpha, weight (bdpt_proc.cpp:230-245, :484-485) */
+    for (int i = 0; i < ch; ++i) if (!std::isfinite(temp[i])) return false;
     const int W = S.s.width, H = S.s.height;
     const Float posx = px - 0.5f, posy = py - 0.5f, r = S.fradius;
     const int minx = std::max((int) std::ceil(posx - r), 0), miny = std::max((int) std::ceil(posy - r), 0),
@@ -1384,10 +1416,10 @@ inline bool filmPut(const Scene &S, float *film, Float px, Float py, const Spec 
     for (int y = miny, idx = 0; y <= maxy; ++y) wy[idx++] = S.evalDiscretized(y - posy);
     for (int y = miny, yr = 0; y <= maxy; ++y, ++yr) {
         const Float weightY = wy[yr];
-        float *dest = film + ((size_t) y * W + minx) * 5;
+        float *dest = film + ((size_t) y * W + minx) * ch;
         for (int x = minx, xr = 0; x <= maxx; ++x, ++xr) {
             const Float weight = wx[xr] * weightY;
-            for (int k = 0; k < 5; ++k) *dest++ += weight * temp[k];
+            for (int k = 0; k < ch; ++k) *dest++ += weight * temp[k];
         }
     }
     return true;
@@ -1419,6 +1451,7 @@ template <typename FLOAT> static void bsplineEval(const FLOAT *coeff, const int3
 /* =========================================================================== C exports */
 extern "C" {
 
+int32_t orc_film_channels(const orc_scene *s) { SceneHolder H(s); return H.ok ? H.S.frames * 3 + 2 : -1; }
 const char *orc_last_error(void) { return g_err.c_str(); }
 
 void orc_lookup_trilinear(const orc_grid *g, const float *pts, int64_t n, float *out_val, int32_t *out_idx) {
@@ -1557,6 +1590,8 @@ void orc_rng_floats(uint64_t seed, uint32_t pixel, uint32_t sample, int32_t n, f
 static void renderRows(const Scene &S, int spp_begin, int spp_count, uint64_t seed, std::atomic<int> &nextRow, int y0, int y1,
                        float *film, Counters &C, float *pathOut) {
     const int W = S.s.width;
+    const int ch = S.frames * 3 + 2;
+    std::vector<Float> temp((size_t) ch, 0.0f);
     while (true) {
         int y = nextRow.fetch_add(1);
         if (y >= y1) break;
@@ -1571,10 +1606,16 @@ static void renderRows(const Scene &S, int spp_begin, int spp_count, uint64_t se
                 Float px = (Float) x + sx, py = (Float) y + sy;
                 Vec o, d; Float mint, maxt;
                 S.sampleRay(px, py, o, d, mint, maxt);
+                std::fill(temp.begin(), temp.end(), 0.0f);
+                if (S.s.decomposition == 1) Wk.decomp = temp.data();
                 Spec L = Wk.Li(o, d, mint, maxt);
                 C.c[ORC_C_PATHS]++;
                 if (pathOut) { float *q = pathOut + ((size_t) y * W + x) * 3; q[0] = L[0]; q[1] = L[1]; q[2] = L[2]; }
-                else filmPut(S, film, px, py, L, 1.0f);
+                else {
+                    if (S.s.decomposition != 1) { temp[0] = L[0]; temp[1] = L[1]; temp[2] = L[2]; }
+                    temp[ch - 2] = 1.0f; temp[ch - 1] = 1.0f;
+                    filmPut(S, film, px, py, temp.data());
+                }
             }
         }
     }
@@ -1592,13 +1633,13 @@ static int renderImpl(const orc_scene *s, int spp_begin, int spp_count, uint64_t
     std::vector<std::vector<float>> films(nthreads);
     std::vector<std::thread> th;
     for (int t = 0; t < nthreads; t++) {
-        if (!pathOut) films[t].assign((size_t) W * Hh * 5, 0.0f);
+        if (!pathOut) films[t].assign((size_t) W * Hh * (H.S.frames * 3 + 2), 0.0f);
         th.emplace_back([&, t]() { renderRows(H.S, spp_begin, spp_count, seed, nextRow, y0, y1, pathOut ? NULL : films[t].data(), Cs[t], pathOut); });
     }
     for (auto &t : th) t.join();
     if (!pathOut)
         for (int t = 0; t < nthreads; t++)
-            for (size_t i = 0; i < (size_t) W * Hh * 5; i++) film[i] += films[t][i];
+            for (size_t i = 0; i < (size_t) W * Hh * (H.S.frames * 3 + 2); i++) film[i] += films[t][i];
     if (counters) {
         for (int k = 0; k < ORC_C_COUNT; k++) { counters[k] = 0; for (int t = 0; t < nthreads; t++) counters[k] += Cs[t].c[k]; }
     }

@@ -74,6 +74,10 @@ typedef struct {
     float   env_radiance[3];
     float   emission[3];            /* medium emission coefficient per unit density (0 => none) */
     float   point_position[3], point_intensity[3];   /* emitter `point` (src/emitters/point.cpp); intensity 0 => none */
+    /* film decomposition (src/librender/film.cpp:56-84): 0 = none (steady state), 1 = transient: every radiance contribution is
+       binned by its optical path length into frames = ceil((max_bound - min_bound) / bin_width) RGB slices; the film is
+       float[H][W][frames*3 + 2] (RGB per frame, then alpha, weight), the reference's channel order (bdpt_proc.cpp:230-245) */
+    int32_t decomposition; float min_bound, max_bound, bin_width; int32_t calibrated_transient;
 } orc_scene;
 
 enum {
@@ -118,13 +122,15 @@ void orc_filter_table(int32_t rfilter, float param, float *values33, float *radi
 void orc_rng_floats(uint64_t seed, uint32_t pixel, uint32_t sample, int32_t n, float *out);
 
 /* ---- full render (A10 + A11) ------------------------------------------------ */
-/* film: float[height][width][5] accumulated (R,G,B,alpha,weight).  counters: uint64[ORC_C_COUNT].
+/* film: float[height][width][frames*3+2] accumulated (R,G,B per frame, alpha, weight); frames = 1 in steady state.  counters: uint64[ORC_C_COUNT].
    Renders sample indices [spp_begin, spp_begin+spp_count) of pixels in rows [y0,y1). */
 int orc_render(const orc_scene *s, int32_t spp_begin, int32_t spp_count, uint64_t seed,
                int32_t y0, int32_t y1, int32_t nthreads, float *film, uint64_t *counters);
 /* per-path radiance for debugging parity: out[(y*w+x)*3] for one sample index */
 int orc_render_paths(const orc_scene *s, int32_t sample_index, uint64_t seed, int32_t nthreads, float *out_rgb);
 
+/* channels of the film for this scene (frames*3 + 2) */
+int32_t orc_film_channels(const orc_scene *s);
 const char *orc_last_error(void);
 #ifdef __cplusplus
 }

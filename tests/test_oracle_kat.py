@@ -334,3 +334,62 @@ def test_point_emitter_curved_equals_straight_in_constant_index(orc):
     a = fs[..., :3].sum((0, 1)) / fs[..., 4].sum(); b = fc[..., :3].sum((0, 1)) / fc[..., 4].sum()
     assert a.min() > 0
     np.testing.assert_allclose(b, a, rtol=0.08)
+
+
+# ----------------------------------------------------------------------------- N1 transient film
+def _transient(p, **kw):
+    base = dict(decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=0.0, max_bound=24.0, bin_width=0.25)
+    base.update(kw)
+    return p.copy(**base)
+
+
+@pytest.mark.parametrize("kind", ["straight", "curved", "homogeneous"])
+def test_transient_frames_sum_to_the_steady_state_film(orc, kind):
+    """Binning by path length only redistributes radiance: with bounds that hold every path, the frames add up to the
+    steady-state film, and alpha / weight are those of the steady state (film.cpp:71-78, bdpt_proc.cpp:449-485)."""
+    mk = {"straight": lambda: scenes.straight_scene(N=16, w=8, h=8), "curved": lambda: scenes.curved_scene(N=16, w=8, h=8),
+          "homogeneous": lambda: scenes.homogeneous_scene(w=8, h=8)}[kind]
+    ps = mk().copy(rfilter=P.FILTER_BOX, rfilter_param=0.5, max_depth=12)
+    pt = _transient(ps, max_bound=60.0, bin_width=0.5)
+    fs, _ = orc.render(ps, 0, 32, 5)
+    ft, _ = orc.render(pt, 0, 32, 5)
+    assert ft.shape == (8, 8, 120 * 3 + 2)
+    np.testing.assert_array_equal(ft[..., -2:], fs[..., 3:])
+    tot = ft[..., :-2].reshape(8, 8, 120, 3).sum(2)
+    np.testing.assert_allclose(tot, fs[..., :3], rtol=2e-5, atol=1e-5)
+
+
+def test_transient_single_scatter_profile_matches_quadrature(orc):
+    """Time-resolved known answer: homogeneous isotropic medium, point emitter, exactly one scattering event.  A path that
+    scatters at depth t along the central camera ray has optical length 2 + t + d(t) (camera edge 2, n = 1), so frame k holds
+    the single-scatter integrand integrated over {t : 2 + t + d(t) in bin k}."""
+    sig_a, sig_s = 0.3, 0.9
+    pp = np.array([0.1, 0.6, -0.2]); I = np.array([1.0, 0.8, 0.5])
+    p = scenes.homogeneous_scene(w=2, h=2, fov_x_deg=0.02, sigma_a=[sig_a] * 3, sigma_s=[sig_s] * 3, env_radiance=[0, 0, 0],
+                                 point_position=list(pp), point_intensity=list(I), max_depth=3, rfilter=P.FILTER_BOX, rfilter_param=0.5,
+                                 decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=2.0, max_bound=6.0, bin_width=0.25)
+    film, _ = orc.render(p, 0, 120000, 11)
+    frames = 16
+    got = film[..., :-2].reshape(2, 2, frames, 3).sum((0, 1)) / film[..., -1].sum()
+    st = sig_a + sig_s
+    n = 400000
+    t = (np.arange(n) + 0.5) / n * 2.0
+    x = np.stack([-1 + t, 0 * t, 0 * t], 1)
+    d = np.linalg.norm(pp[None] - x, axis=1)
+    f = sig_s * np.exp(-st * t) / (4 * np.pi) * np.exp(-st * d) / d ** 2 * (2.0 / n)
+    bins = np.floor((2.0 + t + d - 2.0) / 0.25).astype(int)
+    ref = np.bincount(bins[(bins >= 0) & (bins < frames)], weights=f[(bins >= 0) & (bins < frames)], minlength=frames)
+    assert ref[:2].sum() == 0 and got[:2].sum() == 0                        # nothing can arrive before 2 + |pp - entry| ~ 2.6
+    big = ref > 0.02 * ref.max()
+    np.testing.assert_allclose(got[big, 0], ref[big] * I[0], rtol=0.06)
+    np.testing.assert_allclose(got.sum(0), ref.sum() * I, rtol=0.03)
+    # calibrated transients leave the camera edge (length 2) out: the same profile, 8 bins earlier
+    pc = p.copy(calibrated_transient=True, min_bound=0.0, max_bound=4.0)
+    fc, _ = orc.render(pc, 0, 120000, 11)
+    np.testing.assert_allclose(fc[..., :-2], film[..., :-2], rtol=1e-4, atol=1e-7)
+
+
+def test_transient_rejects_bad_bounds(orc):
+    p = scenes.homogeneous_scene(w=2, h=2, decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=1.0, max_bound=1.0, bin_width=0.5)
+    with pytest.raises(RuntimeError, match="frames"):
+        orc.render(p, 0, 1, 0)
