@@ -103,3 +103,35 @@ def test_xml_render_equals_direct_c_abi_render(tmp_path, ctx):
     p1 = scenes.homogeneous_scene(w=128, h=128)
     ref1, _ = orc.render(p1, 0, 4, 1, nthreads=8)
     assert np.linalg.norm(film1 - ref1) / np.linalg.norm(ref1) < 2e-2
+
+
+def test_transient_film_and_point_emitter_flatten():
+    """film decomposition parameters (src/librender/film.cpp:56-84) and the `point` emitter (src/emitters/point.cpp:57-69)"""
+    d, spp = host.flatten_xml(os.path.join(SC, "cfg_transient_point.xml"), {"samples": 8, "tMin": 2, "tMax": 10, "tRes": 0.1})
+    assert d.decomposition == P.DECOMPOSITION_TRANSIENT and (d.min_bound, d.max_bound) == (2.0, 10.0) and abs(d.bin_width - 0.1) < 1e-7
+    assert d.calibrated_transient == 0 and spp == 8
+    assert np.allclose(list(d.point_position), [0.2, 0.3, -0.1]) and np.allclose(list(d.point_intensity), [1, 0.8, 0.5])
+    assert list(d.env_radiance) == [0, 0, 0]
+
+
+@pytest.mark.parametrize("film,msg", [
+    ('<string name="decomposition" value="temporal"/>', "decomposition"),
+    ('<string name="decomposition" value="bounce"/>', "bounce"),
+    ('<string name="decomposition" value="transient"/><float name="minBound" value="3"/><float name="maxBound" value="1"/>', "frames"),
+    ('<string name="decomposition" value="transient"/><float name="maxBound" value="4"/><string name="modulationType" value="sine"/>', "modulation"),
+])
+def test_film_decomposition_errors(tmp_path, film, msg):
+    cam = '<sensor type="perspective"><film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/>' + film + '</film></sensor>'
+    f = _scene(tmp_path, '<integrator type="volpath"/>' + cam + '<medium type="homogeneous" id="m"/><shape type="cube"><ref name="interior" id="m"/></shape>')
+    with pytest.raises(host.HostError, match=msg):
+        host.flatten_xml(f)
+
+
+def test_point_emitter_position_and_toworld_are_exclusive(tmp_path):
+    body = ('<integrator type="volpath"/>' + CAM + '<medium type="homogeneous" id="m"><spectrum name="sigmaS" value="1"/><spectrum name="sigmaA" value="0.1"/></medium><shape type="cube"><ref name="interior" id="m"/></shape>'
+            '<emitter type="point"><point name="position" x="0" y="0" z="0"/><transform name="toWorld"><translate x="1"/></transform></emitter>')
+    with pytest.raises(host.HostError, match="Only one of the parameters 'position'"):
+        host.flatten_xml(_scene(tmp_path, body))
+    body = body.replace('<point name="position" x="0" y="0" z="0"/>', '')
+    d, _ = host.flatten_xml(_scene(tmp_path, body))
+    assert np.allclose(list(d.point_position), [1, 0, 0]) and np.allclose(list(d.point_intensity), [1, 1, 1])
