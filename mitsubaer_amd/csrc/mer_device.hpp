@@ -172,6 +172,12 @@ struct CellCache {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// MER_ALWAYS_LOAD (experiment): no cell cache, every evaluation gathers its cell -- straight-line code, no exec-mask regions
+#ifdef MER_ALWAYS_LOAD
+#define MER_CELL_TEST(cond) true
+#else
+#define MER_CELL_TEST(cond) (cond)
+#endif
 template <int RIFK>
 __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &cc, f3 p, float &val, f3 &grad) {
     const float px = __builtin_fmaf(g.s[0], p.x, g.t[0]), py = __builtin_fmaf(g.s[1], p.y, g.t[1]), pz = __builtin_fmaf(g.s[2], p.z, g.t[2]);
@@ -180,7 +186,7 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
     float fx = px - cc.cx, fy = py - cc.cy, fz = pz - cc.cz;
     // all three in [0,1)  <=>  the largest of the three bit patterns, compared as unsigned, is below that of 1.0f (a negative
     // value has the sign bit set; NaN and -0.0f take the slow path, which is always correct)
-    if (max(__float_as_uint(fx), max(__float_as_uint(fy), __float_as_uint(fz))) >= 0x3F800000u) {
+    if (MER_CELL_TEST(max(__float_as_uint(fx), max(__float_as_uint(fy), __float_as_uint(fz))) >= 0x3F800000u)) {
         // clamp in the float domain (exact: the operands are small integers), one v_med3_f32 per axis
         cc.cx = __builtin_amdgcn_fmed3f(floorf(px), 0.0f, (float) (g.res[0] - 2));
         cc.cy = __builtin_amdgcn_fmed3f(floorf(py), 0.0f, (float) (g.res[1] - 2));
@@ -188,7 +194,7 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
         const int x1 = (int) cc.cx, y1 = (int) cc.cy, z1 = (int) cc.cz;
         fx = px - cc.cx; fy = py - cc.cy; fz = pz - cc.cz;
         const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);
-        if (base != cc.cell) {
+        if (MER_CELL_TEST(base != cc.cell)) {
             cc.cell = base;
             if (RIFK == RIFK_CELL8 || RIFK == RIFK_CELL8_BUF) {
                 const int cell = (int) (__umul24(__umul24(z1, g.res[1] - 1) + y1, g.res[0] - 1) + x1);
