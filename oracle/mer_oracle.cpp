@@ -1565,6 +1565,7 @@ void orc_connect(const orc_scene *s, const float *p1, const float *p2, int64_t n
         Pcg32 rng; rng.seed(seed, (uint32_t) i, 0);
         float *o = out + 12 * i;
         for (int k = 0; k < 12; k++) o[k] = 0;
+        const uint64_t steps0 = C.c[ORC_C_STEPS];
         const Vec a(p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]), b(p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]);
         if (s->rif_double) {
             Connector<double> K(H.S, C, rng);
@@ -1579,6 +1580,7 @@ void orc_connect(const orc_scene *s, const float *p1, const float *p2, int64_t n
             o[0] = ok; o[1] = w; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z;
             if (ok) { o[5] = rev.x; o[6] = rev.y; o[7] = rev.z; o[8] = di; o[9] = od; }
         }
+        o[10] = (float) (C.c[ORC_C_STEPS] - steps0);           /* eikonal / sensitivity steps this connection cost */
     }
 }
 

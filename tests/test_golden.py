@@ -1,0 +1,109 @@
+"""Committed golden fixtures (tests/golden/):
+  reference_known_answers.json -- data that comes from the reference itself (its B-spline core's probe values recorded in SURVEY.md
+                                   section 8c, its phase-function fixture, its VOL recipe);
+  oracle_vectors.npz           -- seeded regression vectors of the CPU oracle (generator: tests/golden/make_golden.py).
+CPU tests pin the oracle on both; GPU tests (`-m gpu`) compare the HIP path, through the C-ABI, with the same vectors."""
+import importlib.util
+import json
+import os
+import numpy as np
+import pytest
+from mitsubaer_amd import params as P, volio
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KA = json.load(open(os.path.join(HERE, "reference_known_answers.json")))
+G = np.load(os.path.join(HERE, "oracle_vectors.npz"))
+_spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "make_golden.py"))
+make_golden = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(make_golden)
+SCENES = make_golden.scene_set()
+
+
+def _probe():
+    b = KA["bspline_probe"]
+    f = np.float32
+    nz, ny, nx = b["grid_shape_zyx"]
+    k, j, i = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    data = ((f(1.3) + f(0.05) * i.astype(f)) + (f(0.01) * (j * j).astype(f))) - (f(0.02) * k.astype(f))
+    return b, data.astype(np.float32)
+
+
+@pytest.mark.parametrize("prec", ["fp64", "fp32"])
+def test_oracle_bspline_reproduces_the_reference_probe(orc, prec):
+    b, data = _probe()
+    e = b[prec]
+    c = orc.bspline_build(data, double=(prec == "fp64"))
+    q = np.array([b["query"]], np.float64 if prec == "fp64" else np.float32)
+    v, g, h = orc.bspline_eval(c, b["aabb_min"], b["aabb_max"], q, hessian=True)
+    tv = e.get("tolerance", e.get("tolerance_value")); td = e.get("tolerance", e.get("tolerance_derivatives"))
+    assert abs(v[0] - e["value"]) < tv
+    assert np.abs(g[0] - e["gradient"]).max() < td
+    assert abs(h[0][0] - e["hessian_xx"]) < td
+
+
+def test_vol_recipe_round_trip(tmp_path):
+    r = KA["vol_recipe"]
+    nx, ny, nz = r["res_xyz"]
+    data = np.random.RandomState(0).rand(nz, ny, nx).astype(np.float32)
+    f = str(tmp_path / "t.vol")
+    volio.write_vol(f, data, r["aabb_min"], r["aabb_max"])
+    raw = open(f, "rb").read()
+    assert raw[:3] == r["magic"].encode() and raw[3] == r["version"] and len(raw) == r["header_bytes"] + data.nbytes
+    assert np.frombuffer(raw[4:8], "<i4")[0] == r["type_float32"] and list(np.frombuffer(raw[8:20], "<i4")) == r["res_xyz"]
+    back, mn, mx = volio.read_vol(f)[:3]
+    assert np.array_equal(back.reshape(data.shape), data) and list(mn) == r["aabb_min"] and list(mx) == r["aabb_max"]
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_oracle_reproduces_golden_paths(orc, name):
+    """per-path radiance of samples 0 and 1, seed 7 (the oracle is deterministic; tolerance covers a different libm build)"""
+    p = SCENES[name]
+    got = np.stack([orc.render_paths(p, s, 7, nthreads=2) for s in (0, 1)])
+    ref = G["paths/" + name]
+    close = np.abs(got - ref).max(-1) <= 1e-5 * np.maximum(1.0, np.abs(ref).max(-1))
+    assert close.mean() > 0.995, close.mean()
+
+
+def test_oracle_reproduces_golden_leafs_and_transient(orc):
+    pc = make_golden.scenes.curved_scene(N=16)
+    v, idx = orc.lookup_trilinear(pc.density, pc.density_aabb[0], pc.density_aabb[1], G["leaf/points"])
+    assert np.array_equal(idx, G["leaf/lookup_index"]) and np.array_equal(v, G["leaf/lookup_value"])           # integer / index work: bit-exact
+    assert np.array_equal(orc.rng_floats(42, 1234, 3, 16), G["leaf/rng"])
+    tr = orc.er_trace(pc, G["leaf/ray_o"], G["leaf/ray_d"], G["leaf/trace_dist"])
+    np.testing.assert_allclose(tr[0], G["leaf/trace_p"], atol=1e-6); np.testing.assert_allclose(tr[3], G["leaf/trace_opt"], rtol=1e-6)
+    assert np.array_equal(tr[4], G["leaf/trace_ok"])
+    sd = orc.sample_distance(pc, G["leaf/ray_o"], G["leaf/ray_d"], np.full(32, np.inf, np.float32), 5)
+    np.testing.assert_allclose(sd, G["leaf/sample_distance"], rtol=1e-5, atol=1e-6)
+    cn = orc.connect(pc, G["leaf/ray_o"], np.tile(np.array([[0.2, 0.3, -0.1]], np.float32), (32, 1)), 5)[:, :10]
+    np.testing.assert_allclose(cn, G["leaf/connect"], rtol=1e-4, atol=1e-5)
+    p = make_golden.scenes.curved_scene(N=16, w=8, h=6, rfilter=P.FILTER_BOX, rfilter_param=0.5, decomposition=P.DECOMPOSITION_TRANSIENT,
+                                        min_bound=0.0, max_bound=12.0, bin_width=0.5)
+    np.testing.assert_allclose(orc.render(p, 0, 4, 7, nthreads=2)[0], G["transient/curved_film"], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ GPU against the goldens
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_gpu_reproduces_golden_paths(ctx, name):
+    p = SCENES[name]
+    sc, vols = ctx.upload_scene(p)
+    got = np.stack([ctx.render_paths(sc, s, seed=7) for s in (0, 1)])
+    ref = G["paths/" + name]
+    close = np.abs(got - ref).max(-1) <= 1e-4 * np.maximum(1.0, np.abs(ref).max(-1))
+    # stated tolerance: >= 99 % of paths within 1e-4 (>= 95 % where a curved-ray connection solver runs per scattering event)
+    assert close.mean() > (0.95 if name.startswith("curved_point") else 0.99), close.mean()
+    for v in vols:
+        v.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_leafs(ctx):
+    pc = make_golden.scenes.curved_scene(N=16)
+    sc, vols = ctx.upload_scene(pc)
+    v, idx = ctx.lookup_trilinear(vols[0], G["leaf/points"])
+    assert np.array_equal(idx, G["leaf/lookup_index"]) and np.array_equal(v, G["leaf/lookup_value"])
+    assert np.array_equal(ctx.rng_floats(42, 1234, 3, 16), G["leaf/rng"])
+    tr = ctx.er_trace(sc, G["leaf/ray_o"], G["leaf/ray_d"], G["leaf/trace_dist"])
+    np.testing.assert_allclose(tr[0], G["leaf/trace_p"], atol=2e-5); np.testing.assert_allclose(tr[3], G["leaf/trace_opt"], rtol=2e-5)
+    assert np.array_equal(tr[4], G["leaf/trace_ok"])
+    for vv in vols:
+        vv.destroy()
