@@ -12,7 +12,7 @@ def straight_scene(N=32, w=48, h=40, **kw):
 
 def curved_scene(N=32, w=48, h=40, rif="linear", **kw):
     d = synth.density_field(N)
-    r = synth.linear_rif(N) if rif == "linear" else synth.radial_rif(N)
+    r = rif if isinstance(rif, np.ndarray) else (synth.linear_rif(N) if rif == "linear" else synth.radial_rif(N))
     base = dict(width=w, height=h, density=d, rif_mode=P.RIF_TRILINEAR, rif=r, stepsize=0.5 * 2.0 / (N - 1),
                 rfilter=P.FILTER_GAUSSIAN, rfilter_param=0.5)
     base.update(kw)
