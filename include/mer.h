@@ -84,7 +84,14 @@ typedef struct {
        The film then is float[height][width][frames*3 + 2]: RGB per frame, alpha, weight (bdpt_proc.cpp:230-245,484-485).
        calibrated_transient != 0 leaves the camera edge out of the path length (bdpt_proc.cpp:163-170). */
     int32_t decomposition; float min_bound, max_bound, bin_width; int32_t calibrated_transient;
+    /* path-length modulation of a transient film (continuous-wave time of flight; PathLengthSampler,
+       src/librender/pathlengthsampler.cpp:12-114): MER_MODULATION_*; lambda, phase in degrees, P, neighbors.  With a
+       modulation the film has one frame and every contribution is weighted by correlationFunction(pathLength)
+       (src/integrators/bdpt/bdpt_proc.cpp:446-447; src/librender/film.cpp:76-78). */
+    int32_t modulation; float mod_lambda, mod_phase_deg; int32_t mod_P, mod_neighbors;
 } mer_scene_desc;
+enum { MER_MODULATION_NONE = 0, MER_MODULATION_SINE, MER_MODULATION_SQUARE, MER_MODULATION_HAMILTONIAN, MER_MODULATION_MSEQ,
+       MER_MODULATION_DEPTHSELECTIVE };
 enum { MER_DECOMPOSITION_NONE = 0, MER_DECOMPOSITION_TRANSIENT = 1 };
 
 /* which part of the image-sample space this call renders (multi-GPU sharding):
@@ -177,6 +184,8 @@ int  mer_phase_sample(mer_context *ctx, int32_t phase, float g, const float *wi,
 int  mer_phase_eval(mer_context *ctx, int32_t phase, float g, const float *wi, const float *wo, int64_t n, float *val);
 /* PerspectiveCamera::sampleRay (src/sensors/perspective.cpp:247-269) */
 int  mer_camera_rays(mer_context *ctx, const mer_scene_desc *scene, const float *pos2, int64_t n, float *o, float *d);
+/* PathLengthSampler::correlationFunction for the scene's modulation (src/librender/pathlengthsampler.cpp:68-114) */
+int  mer_correlation(mer_context *ctx, const mer_scene_desc *scene, const float *path_length, int64_t n, float *out);
 /* per-path radiance Li of sample `sample_index` for every pixel: out[(y*w+x)*3] (no filter) */
 int  mer_render_paths(mer_context *ctx, const mer_scene_desc *scene, int32_t sample_index, uint64_t seed, float *out_rgb);
 /* sampler stream known answers */

@@ -22,7 +22,7 @@ SYMBOLS = [
     "mer_film_free", "mer_render", "mer_synchronize", "mer_last_kernel_ms", "mer_last_render_stats", "mer_counters_read",
     "mer_counters_reset", "mer_lookup_trilinear", "mer_lookup_trilinear_rgb", "mer_rif_value_grad", "mer_er_trace",
     "mer_sample_distance", "mer_connect", "mer_eval_transmittance", "mer_phase_sample", "mer_phase_eval", "mer_camera_rays",
-    "mer_render_paths", "mer_rng_floats", "mer_synth_field_dev", "mer_device_free",
+    "mer_correlation", "mer_render_paths", "mer_rng_floats", "mer_synth_field_dev", "mer_device_free",
 ]
 
 
@@ -53,6 +53,7 @@ class SceneDesc(C.Structure):
         ("point_position", C.c_float * 3), ("point_intensity", C.c_float * 3),
         ("decomposition", C.c_int32), ("min_bound", C.c_float), ("max_bound", C.c_float), ("bin_width", C.c_float),
         ("calibrated_transient", C.c_int32),
+        ("modulation", C.c_int32), ("mod_lambda", C.c_float), ("mod_phase_deg", C.c_float), ("mod_P", C.c_int32), ("mod_neighbors", C.c_int32),
     ]
 
 
@@ -207,6 +208,7 @@ class Context:
         s.point_position[:] = p.point_position; s.point_intensity[:] = p.point_intensity
         s.decomposition = p.decomposition; s.min_bound = p.min_bound; s.max_bound = p.max_bound; s.bin_width = p.bin_width
         s.calibrated_transient = int(p.calibrated_transient)
+        s.modulation = p.modulation; s.mod_lambda = p.mod_lambda; s.mod_phase_deg = p.mod_phase_deg; s.mod_P = p.mod_P; s.mod_neighbors = p.mod_neighbors
         return s
 
     def upload_scene(self, p, layout=LAYOUT_DENSE, rif_layout=None):
@@ -348,6 +350,12 @@ class Context:
         o = np.empty((n, 3), np.float32); d = np.empty((n, 3), np.float32)
         self._check(lib().mer_camera_rays(self.h, C.byref(scene), _fp(pos2), C.c_int64(n), _fp(o), _fp(d)))
         return o, d
+
+    def correlation(self, scene, path_length):
+        t = _f32(path_length); n = t.shape[0]
+        out = np.empty(n, np.float32)
+        self._check(lib().mer_correlation(self.h, C.byref(scene), _fp(t), C.c_int64(n), _fp(out)))
+        return out
 
     def render_paths(self, scene, sample_index, seed=0):
         out = np.zeros((scene.height, scene.width, 3), np.float32)

@@ -107,7 +107,14 @@ static void filter_table(int kind, float param, float *values, float &radius, fl
 // Validate the scene the way the reference plugins' constructors / configure() do, and flatten it.
 static int film_frames(mer_context *ctx, const mer_scene_desc *sc, int &frames) {
     frames = 1;
+    if (sc->modulation < MER_MODULATION_NONE || sc->modulation > MER_MODULATION_DEPTHSELECTIVE)            // pathlengthsampler.cpp:33-35
+        return fail(ctx, "The \"modulation\" parameter must be equal toeither \"none\", \"square\", or \"hamiltonian\", or \"mseq\", or \"depthselective\"!");
+    if (sc->modulation != MER_MODULATION_NONE && sc->decomposition != MER_DECOMPOSITION_TRANSIENT)
+        return fail(ctx, "film: a path-length modulation needs decomposition = transient");
+    if (sc->modulation != MER_MODULATION_NONE && (!(sc->mod_lambda > 0) || sc->mod_P < 1 || sc->mod_neighbors < 0))
+        return fail(ctx, "film: modulation needs lambda > 0, P >= 1, neighbors >= 0");
     if (sc->decomposition == MER_DECOMPOSITION_NONE) return 0;
+    if (sc->decomposition == MER_DECOMPOSITION_TRANSIENT && sc->modulation != MER_MODULATION_NONE) return 0;  // film.cpp:76-78: one frame
     if (sc->decomposition != MER_DECOMPOSITION_TRANSIENT)
         return fail(ctx, "The \"decomposition\" parameter must be equal toeither \"none\", \"transient\", or \"bounce\"!");   // film.cpp:66-68 (bounce: not built)
     const float f = std::ceil((sc->max_bound - sc->min_bound) / sc->bin_width);                                               // film.cpp:74
@@ -194,6 +201,7 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P) {
     if (P.fradius > 7.0f) return fail(ctx, "reconstruction filter radius too large");
     if (film_frames(ctx, sc, P.frames)) return 1;
     P.film_ch = P.frames * 3 + 2;
+    P.mod_phase = (float) (sc->mod_phase_deg * M_PI / 180);                                                   // pathlengthsampler.cpp:15
     if (sc->boundary == MER_BOUNDARY_AABB) {
         for (int i = 0; i < 3; i++) if (!(sc->bmin[i] < sc->bmax[i])) return fail(ctx, "medium shape: empty bounding box");
     } else if (sc->boundary == MER_BOUNDARY_SPHERE) {
@@ -798,6 +806,17 @@ int mer_camera_rays(mer_context *ctx, const mer_scene_desc *scene, const float *
     HIP_CHECK(ctx, hipGetLastError());
     if (b.download(o, n * 12)) return 1;
     return c.download(d, n * 12);
+}
+int mer_correlation(mer_context *ctx, const mer_scene_desc *scene, const float *path_length, int64_t n, float *out) {
+    Params P;
+    mer_scene_desc sc = *scene; sc.sigma_mode = MER_SIGMA_HOMOGENEOUS; sc.rif_mode = MER_RIF_CONST; sc.albedo_mode = MER_ALBEDO_CONST;
+    if (make_params(ctx, &sc, P)) return 1;
+    if (sc.modulation == MER_MODULATION_NONE) return fail(ctx, "Cannot call correlation function when the modulation type is not defined");   // pathlengthsampler.cpp:71-73
+    DevBuf a(ctx), b(ctx);
+    if (a.upload(path_length, n * 4) || b.alloc(n * 4)) return 1;
+    hipLaunchKernelGGL(correlation_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, P, a.as<float>(), n, b.as<float>());
+    HIP_CHECK(ctx, hipGetLastError());
+    return b.download(out, n * 4);
 }
 int mer_rng_floats(mer_context *ctx, uint64_t seed, uint32_t pixel, uint32_t sample, int32_t n, float *out) {
     DevBuf a(ctx);

@@ -9,6 +9,7 @@
 #define MER_EPSILON 1e-4f                 // include/mitsuba/core/constants.h:25-31 (single precision)
 #define MER_PI 3.14159265358979323846f
 #define MER_INV_FOURPI 0.07957747154594766788f
+#define MER_INV_PI 0.31830988618379067154f
 #define MER_INF __builtin_huge_valf()
 
 namespace mer {
@@ -417,6 +418,7 @@ struct Params {
     uint64_t total_work;
     float *film;                        // float[H][W][film_ch]: RGB per frame, alpha, weight
     int32_t frames, film_ch;            // frames = 1 and film_ch = 5 in steady state
+    float mod_phase;                    // path-length modulation phase in radians
     float *path_out;                    // per-path radiance (mer_render_paths) or NULL
     unsigned long long *counters;       // MER_C_COUNT
     unsigned long long *work_counter;
@@ -513,11 +515,47 @@ __device__ __forceinline__ void film_splat(const Params &P, float px, float py, 
     }
 }
 __device__ __forceinline__ void film_put(const Params &P, float px, float py, f3 L, float alpha) {
-    film_splat(P, px, py, L, alpha, 0, P.sc.decomposition ? 2 : 3);     // transient: the RGB went out per contribution
+    film_splat(P, px, py, L, alpha, 0, (P.sc.decomposition && !P.sc.modulation) ? 2 : 3);     // transient: the RGB went out per contribution
+}
+// PathLengthSampler::mSeq / correlationFunction (include/mitsuba/render/pathlengthsampler.h:32-42,
+// src/librender/pathlengthsampler.cpp:68-114), float / double mix as written there
+__device__ __forceinline__ float mseq(const Params &P, float t, float phase) {
+    const float lambda = P.sc.mod_lambda; const int mP = P.sc.mod_P;
+    float pathLength = t;
+    pathLength = pathLength + phase * lambda * MER_INV_PI / 2;
+    pathLength = fmodf(pathLength, lambda);
+    if (pathLength < lambda / mP) return 1 - pathLength * (mP - 1) / lambda;
+    else if (pathLength > (1 - 1.0 / mP) * lambda) return 1 - (lambda - pathLength) * (mP - 1) / lambda;
+    else return (float) (1.0 / mP);
+}
+__device__ __noinline__ float correlation_function(const Params &P, float t) {
+    const float lambda = P.sc.mod_lambda, modPhase = P.mod_phase;
+    float pathLength = t;
+    switch (P.sc.modulation) {
+    case MER_MODULATION_SINE: pathLength = pathLength + modPhase * lambda * MER_INV_PI / 2; return (float) cos(pathLength * 2 * M_PI / lambda);
+    case MER_MODULATION_SQUARE: pathLength = pathLength + modPhase * lambda * MER_INV_PI / 2;
+        return 4 / lambda * (fabsf(fmodf(pathLength, lambda) - lambda / 2) - lambda / 4);
+    case MER_MODULATION_HAMILTONIAN: pathLength = pathLength + modPhase * lambda * MER_INV_PI / 2;
+        pathLength = fmodf(pathLength, lambda);
+        if (pathLength < lambda / 6) return 6 * pathLength / lambda;
+        else if (pathLength < lambda / 2 && pathLength >= lambda / 6) return 1.0f;
+        else if (pathLength < 2 * lambda / 3 && pathLength >= lambda / 2) return 1 - (pathLength - lambda / 2) * 6 / lambda;
+        else return 0;
+    case MER_MODULATION_MSEQ: return mseq(P, pathLength, modPhase);
+    case MER_MODULATION_DEPTHSELECTIVE: { float value = 0;
+        for (int i = 0; i < P.sc.mod_neighbors; i++) value += mseq(P, pathLength, (float) (modPhase - i * (2 * M_PI) / P.sc.mod_P));
+        value -= (float) (P.sc.mod_neighbors - 1) / P.sc.mod_P;
+        return value; }
+    }
+    return 1.0f;
+}
+// a radiance contribution as it enters the per-path sum: weighted by the correlation function under a modulation (bdpt_proc.cpp:446-447)
+__device__ __forceinline__ f3 mod_weight(const Params &P, f3 value, float pathLength) {
+    return P.sc.modulation ? value * correlation_function(P, pathLength) : value;
 }
 // Transient film: one radiance contribution binned by its optical path length (bdpt_proc.cpp:449-470)
 __device__ __forceinline__ void film_contribute(const Params &P, float px, float py, f3 value, float pathLength) {
-    if (!P.sc.decomposition || P.path_out || is_zero(value)) return;
+    if (!P.sc.decomposition || P.sc.modulation || P.path_out || is_zero(value)) return;
     const float b = floorf((pathLength - P.sc.min_bound) / P.sc.bin_width);
     if (!(b >= 0.0f) || !(b < (float) P.frames)) return;
     film_splat(P, px, py, value, 0.0f, (int) b, 1);

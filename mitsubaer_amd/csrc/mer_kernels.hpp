@@ -400,6 +400,11 @@ __global__ void camera_rays_kernel(const Params P, const float *pos2, int64_t n,
     sample_ray(P, pos2[2 * i], pos2[2 * i + 1], oo, dd, a, b);
     o[3 * i] = oo.x; o[3 * i + 1] = oo.y; o[3 * i + 2] = oo.z; d[3 * i] = dd.x; d[3 * i + 1] = dd.y; d[3 * i + 2] = dd.z;
 }
+__global__ void correlation_kernel(const Params P, const float *t, int64_t n, float *out) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = correlation_function(P, t[i]);
+}
 __global__ void rng_kernel(uint64_t seed, uint32_t pixel, uint32_t sample, int n, float *out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     Rng r; r.seed(seed, pixel, sample);

@@ -133,8 +133,8 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
                 }
                 if (!hit) {
                     C.paths++;
-                    if (P.path_out) { float *q = P.path_out + ((size_t) y * S.width + x) * 3; q[0] = L.x; q[1] = L.y; q[2] = L.z; }
-                    else { film_contribute(P, px, py, L, plen); film_put(P, px, py, L, 1.0f); }
+                    if (P.path_out) { const f3 Lm = mod_weight(P, L, plen); float *q = P.path_out + ((size_t) y * S.width + x) * 3; q[0] = Lm.x; q[1] = Lm.y; q[2] = Lm.z; }
+                    else { film_contribute(P, px, py, L, plen); film_put(P, px, py, mod_weight(P, L, plen), 1.0f); }
                 }
             }
         }
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             ev = EV_NONE;
             itsT = intersect_shape(S, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
             if (itsT < 0) {
-                if (!S.hide_emitters) { L = L + T * env; film_contribute(P, px, py, T * env, plen); }   // volpath.cpp:194-201
+                if (!S.hide_emitters) { L = L + mod_weight(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }   // volpath.cpp:194-201
                 ev = EV_PATH_DONE;
             } else if (depth >= maxDepth && maxDepth != -1) ev = EV_PATH_DONE;
             else {
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                 else { itsT = intersect_shape(S, ro, d, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); if (!itsValid) medium = false; }
                 depth++;
                 if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
-                else if (!medium) { if (!S.hide_emitters) { L = L + T * env; film_contribute(P, px, py, T * env, plen); } ev = EV_PATH_DONE; }
+                else if (!medium) { if (!S.hide_emitters) { L = L + mod_weight(P, T * env, plen); film_contribute(P, px, py, T * env, plen); } ev = EV_PATH_DONE; }
                 else { C.segments++; ps = ro; dsave = d; ev = W.begin(P, rng, C, K_FREE, ro, d, itsT); }
             }
             st = ST_MARCH;
@@ -373,8 +373,9 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             plen += CURVED ? m.opticalLength : m.t * S.rif_const;                     // bdpt_proc.cpp:158-176
             if (depth >= maxDepth && maxDepth != -1) { ev = EV_PATH_DONE; continue; }
             if (hasEmission && SIGMA == MER_SIGMA_GRID) {
-                L = L + T * f3(S.emission[0], S.emission[1], S.emission[2]) * m.refRatioSq;
-                film_contribute(P, px, py, T * f3(S.emission[0], S.emission[1], S.emission[2]) * m.refRatioSq, plen);
+                const f3 c = T * f3(S.emission[0], S.emission[1], S.emission[2]) * m.refRatioSq;
+                L = L + mod_weight(P, c, plen);
+                film_contribute(P, px, py, c, plen);
             }
             T = T * (m.sigmaS * m.transmittance / m.pdfSuccess);
             if (CURVED) T = T * m.refRatioSq;                                         // edge.cpp:91-93
@@ -409,8 +410,9 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                     const float phaseVal = phase_eval(S.phase, S.g, wi, dd);
                     if (phaseVal != 0) {
                         const float weight = mi_weight(dpdf, phaseVal);              // env emitter is "on surface": constant.cpp:47
-                        L = L + T * value * phaseVal * weight;
-                        film_contribute(P, px, py, T * value * phaseVal * weight, plen + trOpt);
+                        const f3 c = T * value * phaseVal * weight;
+                        L = L + mod_weight(P, c, plen + trOpt);
+                        film_contribute(P, px, py, c, plen + trOpt);
                     }
                 }
                 ev = EV_PHASE;
@@ -420,8 +422,9 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                 const bool blocked = (maxInteractions == 0) && (CURVED || itsValid);
                 if (!blocked && !is_zero(tr)) {
                     const f3 value = tr * env;
-                    L = L + T * value * mi_weight(phasePdf, MER_INV_FOURPI);
-                    film_contribute(P, px, py, T * value * mi_weight(phasePdf, MER_INV_FOURPI), plen + trOpt);
+                    const f3 c = T * value * mi_weight(phasePdf, MER_INV_FOURPI);
+                    L = L + mod_weight(P, c, plen + trOpt);
+                    film_contribute(P, px, py, c, plen + trOpt);
                 }
                 ev = EV_AFTER_LOOKUP;
             }
@@ -433,7 +436,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                 if (CURVED) { connecting = true; break; }
                 float optLen = 0.0f;
                 const f3 c = T * point_nee<false, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth, optLen);
-                L = L + c;
+                L = L + mod_weight(P, c, plen + optLen);
                 film_contribute(P, px, py, c, plen + optLen);
             }
             // ---- phase function sampling: volpath.cpp:149-160
@@ -475,13 +478,13 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             if (CURVED) { T = T * m.refRatioSq; SET_FLAG(F_ITSVALID, true); }         // edge.cpp:45-60
             ev = EV_PATH_DONE;
             if (!itsValid) {
-                if (emitted && (!S.hide_emitters || scattered)) { L = L + T * env; film_contribute(P, px, py, T * env, plen); }
+                if (emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
             } else if (!(depth >= maxDepth && maxDepth != -1)) {
                 (void) rng.next1D(); (void) rng.next1D();                             // null BSDF sample
                 SET_FLAG(F_EMITTED, !scattered);
                 depth++;
                 if (depth <= maxDepth || maxDepth < 0)
-                    if (emitted && (!S.hide_emitters || scattered)) { L = L + T * env; film_contribute(P, px, py, T * env, plen); }
+                    if (emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
             }
         } else {  // EV_PATH_DONE: ImageBlock::put (imageblock.h:124-205)
             if (P.path_out) {
@@ -544,8 +547,9 @@ __global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P
         const f3 T(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ)), ps(SLOTF(CO_PSX), SLOTF(CO_PSY), SLOTF(CO_PSZ)), wi(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
         const int depth = (int) SLOT(CO_DEPTH);
         float optLen = 0.0f;
-        const f3 c = T * point_nee<true, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth, optLen);
-        film_contribute(P, SLOTF(CO_PXF), SLOTF(CO_PYF), c, SLOTF(CO_PLEN) + optLen);
+        const f3 c0 = T * point_nee<true, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth, optLen);
+        film_contribute(P, SLOTF(CO_PXF), SLOTF(CO_PYF), c0, SLOTF(CO_PLEN) + optLen);
+        const f3 c = mod_weight(P, c0, SLOTF(CO_PLEN) + optLen);
         SLOT(CO_LX) = __float_as_uint(SLOTF(CO_LX) + c.x); SLOT(CO_LY) = __float_as_uint(SLOTF(CO_LY) + c.y); SLOT(CO_LZ) = __float_as_uint(SLOTF(CO_LZ) + c.z);
         SLOT(H_RNG_LO) = (uint32_t) rng.state; SLOT(H_RNG_HI) = (uint32_t) (rng.state >> 32);
     }

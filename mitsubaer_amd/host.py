@@ -39,7 +39,7 @@ def flatten_xml(path, defines=None):
 
 def render_xml(path, defines=None, device=0, spp=0, seed=0, layout=capi.LAYOUT_CELL8):
     d, _ = flatten_xml(path, defines)
-    frames = int(np.ceil((d.max_bound - d.min_bound) / d.bin_width)) if d.decomposition else 1
+    frames = int(np.ceil((d.max_bound - d.min_bound) / d.bin_width)) if (d.decomposition and not d.modulation) else 1
     film = np.zeros((d.height, d.width, frames * 3 + 2), np.float32)
     if lib().merhost_render_xml(path.encode(), _defs(defines), C.c_int32(device), C.c_int32(spp), C.c_uint64(seed),
                                 C.c_int32(layout), film.ctypes.data_as(C.c_void_p)) != 0:

@@ -346,8 +346,17 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
         o->minBound = props.getFloat("minBound", 0.0f); o->maxBound = props.getFloat("maxBound", 0.0f);
         o->binWidth = props.getFloat("binWidth", 1.0f);
         o->calibratedTransient = props.getBoolean("calibratedTransient", false);
-        if (lower(props.getString("modulationType", "none")) != "none")
-            Log_EError("film: path-length modulation (CW-ToF, src/librender/pathlengthsampler.cpp) is not built on the GPU path");
+        {   // PathLengthSampler(props): pathlengthsampler.cpp:12-38
+            const std::string mod = lower(props.getString("modulation", "none"));
+            static const char *names[] = {"none", "sine", "square", "hamiltonian", "mseq", "depthselective"};
+            o->modulation = -1;
+            for (int i = 0; i < 6; i++) if (mod == names[i]) o->modulation = i;
+            if (o->modulation < 0) Log_EError("The \"modulation\" parameter must be equal toeither \"none\", \"square\", or \"hamiltonian\", or \"mseq\", or \"depthselective\"!");
+            o->lambda = props.getFloat("lambda", 1.0f); o->phase = props.getFloat("phase", 0.0f);
+            o->P = props.getInteger("P", 32); o->neighbors = props.getInteger("neighbors", 3);
+            if (o->modulation != MER_MODULATION_NONE && o->decomposition != MER_DECOMPOSITION_TRANSIENT)
+                Log_EError("film: a path-length modulation needs decomposition = transient");
+        }
         if (o->decomposition == MER_DECOMPOSITION_TRANSIENT && !(o->frames() >= 1 && o->frames() <= 4096))
             Log_EError("film: transient decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames");
         out = o;
@@ -582,6 +591,7 @@ void Integrator::flatten(const Scene &scene, mer_scene_desc &d) const {
     d.width = fi.width; d.height = fi.height;
     d.decomposition = fi.decomposition; d.min_bound = fi.minBound; d.max_bound = fi.maxBound; d.bin_width = fi.binWidth;
     d.calibrated_transient = fi.calibratedTransient ? 1 : 0;
+    d.modulation = fi.modulation; d.mod_lambda = fi.lambda; d.mod_phase_deg = fi.phase; d.mod_P = fi.P; d.mod_neighbors = fi.neighbors;
     const float aspect = (float) fi.width / (float) fi.height;
     std::string axis = se.fovAxis;                                        // sensor.cpp:246-260
     if (axis == "smaller") axis = aspect > 1 ? "y" : "x"; else if (axis == "larger") axis = aspect > 1 ? "x" : "y";

@@ -19,6 +19,7 @@ STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL = 0, 1, 2
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 ALBEDO_CONST, ALBEDO_GRID = 0, 1
 DECOMPOSITION_NONE, DECOMPOSITION_TRANSIENT = 0, 1
+MODULATION_NONE, MODULATION_SINE, MODULATION_SQUARE, MODULATION_HAMILTONIAN, MODULATION_MSEQ, MODULATION_DEPTHSELECTIVE = 0, 1, 2, 3, 4, 5
 
 
 def look_at(origin, target, up):
@@ -71,6 +72,8 @@ class SceneParams:
         # film decomposition (src/librender/film.cpp:56-84): 0 none | 1 transient; frames = ceil((max-min)/binWidth)
         self.decomposition = DECOMPOSITION_NONE; self.min_bound = 0.0; self.max_bound = 0.0; self.bin_width = 1.0
         self.calibrated_transient = False
+        # path-length modulation (src/librender/pathlengthsampler.cpp:12-40): lambda, phase [deg], P, neighbors
+        self.modulation = MODULATION_NONE; self.mod_lambda = 1.0; self.mod_phase_deg = 0.0; self.mod_P = 32; self.mod_neighbors = 3
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise AttributeError("unknown scene parameter '%s'" % k)

@@ -35,6 +35,7 @@ typedef float Float;
 static const Float Epsilon = 1e-4f;            /* include/mitsuba/core/constants.h:25-31 */
 static const Float M_PI_F  = 3.14159265358979323846f;
 static const Float INV_FOURPI_F = 0.07957747154594766788f;
+static const Float INV_PI_F = 0.31830988618379067154f;      /* constants.h INV_PI (single precision build) */
 
 thread_local std::string g_err;
 
@@ -506,6 +507,39 @@ struct Scene {
     Float maxDensity, invMaxDensity;
     bool curved;
     int frames = 1;                /* film.cpp:71-78 */
+    Float modPhase = 0;            /* radians */
+    /* include/mitsuba/render/pathlengthsampler.h:32-42 */
+    inline Float mSeq(Float t, Float phase) const {
+        const Float lambda = s.mod_lambda; const int mP = s.mod_P;
+        Float pathLength = t;
+        pathLength = pathLength + phase * lambda * INV_PI_F / 2;
+        pathLength = std::fmod(pathLength, lambda);
+        if (pathLength < lambda / mP) return 1 - pathLength * (mP - 1) / lambda;
+        else if (pathLength > (1 - 1.0 / mP) * lambda) return 1 - (lambda - pathLength) * (mP - 1) / lambda;
+        else return (Float) (1.0 / mP);
+    }
+    /* PathLengthSampler::correlationFunction, src/librender/pathlengthsampler.cpp:68-114 (mixed float / double as written there) */
+    inline Float correlationFunction(Float t) const {
+        const Float lambda = s.mod_lambda;
+        Float pathLength = t;
+        switch (s.modulation) {
+        case 1: pathLength = pathLength + modPhase * lambda * INV_PI_F / 2; return (Float) std::cos(pathLength * 2 * M_PI / lambda);
+        case 2: pathLength = pathLength + modPhase * lambda * INV_PI_F / 2;
+                return 4 / lambda * (std::fabs(std::fmod(pathLength, lambda) - lambda / 2) - lambda / 4);
+        case 3: pathLength = pathLength + modPhase * lambda * INV_PI_F / 2;
+                pathLength = std::fmod(pathLength, lambda);
+                if (pathLength < lambda / 6) return 6 * pathLength / lambda;
+                else if (pathLength < lambda / 2 && pathLength >= lambda / 6) return 1.0f;
+                else if (pathLength < 2 * lambda / 3 && pathLength >= lambda / 2) return 1 - (pathLength - lambda / 2) * 6 / lambda;
+                else return 0;
+        case 4: return mSeq(pathLength, modPhase);
+        case 5: { Float value = 0;
+                  for (int i = 0; i < s.mod_neighbors; i++) value += mSeq(pathLength, (Float) (modPhase - i * (2 * M_PI) / s.mod_P));
+                  value -= (float) (s.mod_neighbors - 1) / s.mod_P;
+                  return value; }
+        }
+        return 1.0f;
+    }
 
     bool configure(const orc_scene &in) {
         s = in;
@@ -519,7 +553,11 @@ struct Scene {
         if (s.albedo_mode == ORC_ALBEDO_GRID) albedoGrid.configure(s.albedo_grid);
         curved = s.rif_mode != ORC_RIF_CONST;
         frames = 1;
-        if (s.decomposition == 1) {
+        modPhase = (Float) (s.mod_phase_deg * M_PI / 180);                            /* pathlengthsampler.cpp:15 */
+        if (s.modulation < 0 || s.modulation > 5) { g_err = "The \"modulation\" parameter must be equal toeither \"none\", \"square\", or \"hamiltonian\", or \"mseq\", or \"depthselective\"!"; return false; }
+        if (s.modulation != 0 && s.decomposition != 1) { g_err = "film: a path-length modulation needs decomposition = transient"; return false; }
+        if (s.decomposition == 1 && s.modulation != 0) frames = 1;                    /* film.cpp:76-78 */
+        else if (s.decomposition == 1) {
             frames = (int) std::ceil((s.max_bound - s.min_bound) / s.bin_width);      /* film.cpp:71-74 */
             if (!(frames >= 1) || frames > 4096) { g_err = "film: transient decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames"; return false; }
         } else if (s.decomposition != 0) { g_err = "The \"decomposition\" parameter must be equal toeither \"none\", \"transient\", or \"bounce\"!"; return false; }
@@ -957,7 +995,9 @@ struct Walker {
        decomposition values (frames x RGB) the contributions are binned into (bdpt_proc.cpp:449-470 restated for volpath) */
     Float lastTrOpt = 0;
     Float *decomp = nullptr;
+    Spec modL = Spec(0.0f);                      /* sum of contributions x correlationFunction(pathLength) (bdpt_proc.cpp:446-447) */
     inline void contribute(const Spec &value, Float pathLength) {
+        if (S.s.modulation != 0) { if (!value.isZero()) modL += value * S.correlationFunction(pathLength); return; }
         if (!decomp || value.isZero()) return;
         const Float b = std::floor((pathLength - S.s.min_bound) / S.s.bin_width);
         if (!(b >= 0) || !(b < (Float) S.frames)) return;      /* size_t binIndex >= 0 && binIndex < m_frames */
@@ -1398,7 +1438,7 @@ struct Walker {
             }
             scattered = true;
         }
-        return Li;
+        return S.s.modulation != 0 ? modL : Li;
     }
 };
 
@@ -1451,6 +1491,10 @@ template <typename FLOAT> static void bsplineEval(const FLOAT *coeff, const int3
 /* =========================================================================== C exports */
 extern "C" {
 
+void orc_correlation(const orc_scene *s, const float *path_length, int64_t n, float *out) {
+    SceneHolder H(s);
+    for (int64_t i = 0; i < n; i++) out[i] = H.ok ? H.S.correlationFunction(path_length[i]) : 0.0f;
+}
 int32_t orc_film_channels(const orc_scene *s) { SceneHolder H(s); return H.ok ? H.S.frames * 3 + 2 : -1; }
 const char *orc_last_error(void) { return g_err.c_str(); }
 
@@ -1609,12 +1653,12 @@ static void renderRows(const Scene &S, int spp_begin, int spp_count, uint64_t se
                 Vec o, d; Float mint, maxt;
                 S.sampleRay(px, py, o, d, mint, maxt);
                 std::fill(temp.begin(), temp.end(), 0.0f);
-                if (S.s.decomposition == 1) Wk.decomp = temp.data();
+                if (S.s.decomposition == 1 && S.s.modulation == 0) Wk.decomp = temp.data();
                 Spec L = Wk.Li(o, d, mint, maxt);
                 C.c[ORC_C_PATHS]++;
                 if (pathOut) { float *q = pathOut + ((size_t) y * W + x) * 3; q[0] = L[0]; q[1] = L[1]; q[2] = L[2]; }
                 else {
-                    if (S.s.decomposition != 1) { temp[0] = L[0]; temp[1] = L[1]; temp[2] = L[2]; }
+                    if (S.s.decomposition != 1 || S.s.modulation != 0) { temp[0] = L[0]; temp[1] = L[1]; temp[2] = L[2]; }
                     temp[ch - 2] = 1.0f; temp[ch - 1] = 1.0f;
                     filmPut(S, film, px, py, temp.data());
                 }

@@ -78,6 +78,10 @@ typedef struct {
        binned by its optical path length into frames = ceil((max_bound - min_bound) / bin_width) RGB slices; the film is
        float[H][W][frames*3 + 2] (RGB per frame, then alpha, weight), the reference's channel order (bdpt_proc.cpp:230-245) */
     int32_t decomposition; float min_bound, max_bound, bin_width; int32_t calibrated_transient;
+    /* path-length modulation (continuous-wave ToF, src/librender/pathlengthsampler.cpp:12-114): 0 none, 1 sine, 2 square,
+       3 hamiltonian, 4 mseq, 5 depthselective.  With a modulation the transient film has one frame and every contribution is
+       weighted by correlationFunction(pathLength) (bdpt_proc.cpp:446-447). */
+    int32_t modulation; float mod_lambda, mod_phase_deg; int32_t mod_P, mod_neighbors;
 } orc_scene;
 
 enum {
@@ -129,6 +133,8 @@ int orc_render(const orc_scene *s, int32_t spp_begin, int32_t spp_count, uint64_
 /* per-path radiance for debugging parity: out[(y*w+x)*3] for one sample index */
 int orc_render_paths(const orc_scene *s, int32_t sample_index, uint64_t seed, int32_t nthreads, float *out_rgb);
 
+/* PathLengthSampler::correlationFunction for the scene's modulation (batched) */
+void orc_correlation(const orc_scene *s, const float *path_length, int64_t n, float *out);
 /* channels of the film for this scene (frames*3 + 2) */
 int32_t orc_film_channels(const orc_scene *s);
 const char *orc_last_error(void);

@@ -52,6 +52,7 @@ class Scene(C.Structure):
         ("point_position", C.c_float * 3), ("point_intensity", C.c_float * 3),
         ("decomposition", C.c_int32), ("min_bound", C.c_float), ("max_bound", C.c_float), ("bin_width", C.c_float),
         ("calibrated_transient", C.c_int32),
+        ("modulation", C.c_int32), ("mod_lambda", C.c_float), ("mod_phase_deg", C.c_float), ("mod_P", C.c_int32), ("mod_neighbors", C.c_int32),
     ]
 
 
@@ -128,6 +129,7 @@ def make_scene(p):
     s.point_position[:] = p.point_position; s.point_intensity[:] = p.point_intensity
     s.decomposition = p.decomposition; s.min_bound = p.min_bound; s.max_bound = p.max_bound; s.bin_width = p.bin_width
     s.calibrated_transient = int(p.calibrated_transient)
+    s.modulation = p.modulation; s.mod_lambda = p.mod_lambda; s.mod_phase_deg = p.mod_phase_deg; s.mod_P = p.mod_P; s.mod_neighbors = p.mod_neighbors
     return s, keep
 
 
@@ -257,6 +259,14 @@ def filter_table(kind, param):
     r = C.c_float(); sc = C.c_float()
     lib().orc_filter_table(C.c_int32(kind), C.c_float(param), _fp(v), C.byref(r), C.byref(sc))
     return v, r.value, sc.value
+
+
+def correlation(p, path_length):
+    s, keep = make_scene(p)
+    t = np.ascontiguousarray(path_length, np.float32)
+    out = np.empty(t.shape[0], np.float32)
+    lib().orc_correlation(C.byref(s), _fp(t), C.c_int64(t.shape[0]), _fp(out))
+    return out
 
 
 def rng_floats(seed, pixel, sample, n):

@@ -74,3 +74,36 @@ def test_transient_errors_are_loud(ctx):
         ctx.film_channels(sc)
     for v in vols:
         v.destroy()
+
+
+# ------------------------------------------------------------------------------------------------ continuous-wave modulation
+MODS = [P.MODULATION_SINE, P.MODULATION_SQUARE, P.MODULATION_HAMILTONIAN, P.MODULATION_MSEQ, P.MODULATION_DEPTHSELECTIVE]
+
+
+@pytest.mark.parametrize("m", MODS)
+def test_correlation_function_matches_oracle(ctx, orc, m):
+    """PathLengthSampler::correlationFunction through mer_correlation; float / double mix as in the reference => a few ulp"""
+    p = scenes.homogeneous_scene(w=2, h=2, decomposition=P.DECOMPOSITION_TRANSIENT, max_bound=8.0, modulation=m, mod_lambda=1.7, mod_phase_deg=-40.0,
+                                 mod_P=8, mod_neighbors=3)
+    sc, vols = ctx.upload_scene(p)
+    t = np.random.RandomState(m).uniform(0, 30, 4096).astype(np.float32)
+    np.testing.assert_allclose(ctx.correlation(sc, t), orc.correlation(p, t), atol=5e-6)
+
+
+@pytest.mark.parametrize("name,m", [("straight_env_ratio", P.MODULATION_SINE), ("curved_env_rk4", P.MODULATION_SQUARE),
+                                    ("homogeneous_point", P.MODULATION_HAMILTONIAN), ("curved_point_emissive", P.MODULATION_MSEQ)])
+def test_modulated_paths_match_oracle(ctx, orc, name, m):
+    """per-path modulated radiance (sum of contributions x correlation): same tolerance as the steady-state per-path test"""
+    p = CASES[name]().copy(modulation=m, mod_lambda=2.3, mod_phase_deg=25.0, mod_P=8)
+    sc, vols = ctx.upload_scene(p)
+    assert ctx.film_channels(sc) == 5                                          # film.cpp:76-78: one frame under a modulation
+    for s in (0, 1):
+        a = ctx.render_paths(sc, s, seed=8); b = orc.render_paths(p, s, 8)
+        close = np.abs(a - b).max(2) <= 1e-4 * np.maximum(1.0, np.abs(b).max(2))
+        assert close.mean() > (0.95 if name.startswith("curved_point") else 0.99), close.mean()
+    film = ctx.render_to_host(sc, 0, 4, seed=8); ref, _ = orc.render(p, 0, 4, 8)
+    np.testing.assert_allclose(film[..., 3:], ref[..., 3:], rtol=1e-5, atol=1e-5)
+    if not name.startswith("curved_point"):
+        assert _rel_l2(film[..., :3], ref[..., :3]) < 2e-2
+    for v in vols:
+        v.destroy()

@@ -118,7 +118,8 @@ def test_transient_film_and_point_emitter_flatten():
     ('<string name="decomposition" value="temporal"/>', "decomposition"),
     ('<string name="decomposition" value="bounce"/>', "bounce"),
     ('<string name="decomposition" value="transient"/><float name="minBound" value="3"/><float name="maxBound" value="1"/>', "frames"),
-    ('<string name="decomposition" value="transient"/><float name="maxBound" value="4"/><string name="modulationType" value="sine"/>', "modulation"),
+    ('<string name="decomposition" value="transient"/><float name="maxBound" value="4"/><string name="modulation" value="triangle"/>', "modulation"),
+    ('<string name="modulation" value="sine"/>', "needs decomposition = transient"),
 ])
 def test_film_decomposition_errors(tmp_path, film, msg):
     cam = '<sensor type="perspective"><film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/>' + film + '</film></sensor>'
@@ -135,3 +136,13 @@ def test_point_emitter_position_and_toworld_are_exclusive(tmp_path):
     body = body.replace('<point name="position" x="0" y="0" z="0"/>', '')
     d, _ = host.flatten_xml(_scene(tmp_path, body))
     assert np.allclose(list(d.point_position), [1, 0, 0]) and np.allclose(list(d.point_intensity), [1, 1, 1])
+
+
+def test_modulated_film_flattens_to_one_frame(tmp_path):
+    film = ('<string name="decomposition" value="transient"/><float name="maxBound" value="8"/><float name="binWidth" value="0.5"/>'
+            '<string name="modulation" value="sine"/><float name="lambda" value="2.5"/><float name="phase" value="90"/>')
+    cam = '<sensor type="perspective"><film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/>' + film + '</film></sensor>'
+    body = '<integrator type="volpath"/>' + cam + '<medium type="homogeneous" id="m"><spectrum name="sigmaS" value="1"/><spectrum name="sigmaA" value="0.1"/></medium><shape type="cube"><ref name="interior" id="m"/></shape>'
+    d, _ = host.flatten_xml(_scene(tmp_path, body))
+    assert d.decomposition == P.DECOMPOSITION_TRANSIENT and d.modulation == P.MODULATION_SINE
+    assert abs(d.mod_lambda - 2.5) < 1e-7 and d.mod_phase_deg == 90 and (d.mod_P, d.mod_neighbors) == (32, 3)    # pathlengthsampler.cpp:14-17 defaults

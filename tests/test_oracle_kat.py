@@ -393,3 +393,53 @@ def test_transient_rejects_bad_bounds(orc):
     p = scenes.homogeneous_scene(w=2, h=2, decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=1.0, max_bound=1.0, bin_width=0.5)
     with pytest.raises(RuntimeError, match="frames"):
         orc.render(p, 0, 1, 0)
+
+
+# ----------------------------------------------------------------------------- N1: continuous-wave modulation (PathLengthSampler)
+def _mod_scene(m, **kw):
+    base = dict(w=2, h=2, decomposition=P.DECOMPOSITION_TRANSIENT, max_bound=8.0, modulation=m, mod_lambda=2.0, mod_phase_deg=30.0, mod_P=8, mod_neighbors=3)
+    base.update(kw)
+    return scenes.homogeneous_scene(**base)
+
+
+def test_correlation_functions_known_values(orc):
+    """PathLengthSampler::correlationFunction (src/librender/pathlengthsampler.cpp:68-114), closed forms at lambda = 2, phase = 30 deg:
+    the phase shifts the argument by phase*lambda/(2 pi) = 1/6."""
+    t = np.array([0.0, 0.25, 0.5, 1.0, 1.5, 2.0, 3.3], np.float32)
+    u = (t + 1.0 / 6.0).astype(np.float64)
+    np.testing.assert_allclose(orc.correlation(_mod_scene(P.MODULATION_SINE), t), np.cos(u * np.pi), atol=2e-6)
+    np.testing.assert_allclose(orc.correlation(_mod_scene(P.MODULATION_SQUARE), t), 2.0 * (np.abs(np.fmod(u, 2.0) - 1.0) - 0.5), atol=2e-6)
+    w = np.fmod(u, 2.0)
+    ham = np.where(w < 1 / 3, 3 * w, np.where(w < 1.0, 1.0, np.where(w < 4 / 3, 1 - (w - 1.0) * 3, 0.0)))
+    np.testing.assert_allclose(orc.correlation(_mod_scene(P.MODULATION_HAMILTONIAN), t), ham, atol=3e-6)
+    ms = np.where(w < 0.25, 1 - w * 3.5, np.where(w > 1.75, 1 - (2 - w) * 3.5, 0.125))          # P = 8
+    np.testing.assert_allclose(orc.correlation(_mod_scene(P.MODULATION_MSEQ), t), ms, atol=3e-6)
+    # periodic with period lambda
+    for m in (P.MODULATION_SINE, P.MODULATION_SQUARE, P.MODULATION_HAMILTONIAN, P.MODULATION_MSEQ, P.MODULATION_DEPTHSELECTIVE):
+        a = orc.correlation(_mod_scene(m), np.array([0.4, 1.1], np.float32)); b = orc.correlation(_mod_scene(m), np.array([2.4, 5.1], np.float32))
+        np.testing.assert_allclose(a, b, atol=5e-6)
+
+
+def test_modulated_film_is_the_transient_film_weighted_by_the_correlation(orc):
+    """bdpt_proc.cpp:446-447: with a modulation every contribution is multiplied by correlationFunction(pathLength).  With bins much
+    narrower than lambda, sum_k frame_k * corr(centre_k) of the unmodulated transient film reproduces the modulated film."""
+    kw = dict(w=4, h=4, fov_x_deg=20.0, sigma_a=[0.3] * 3, sigma_s=[0.9] * 3, env_radiance=[0, 0, 0], point_position=[0.1, 0.6, -0.2],
+              point_intensity=[1.0, 0.8, 0.5], max_depth=6, rfilter=P.FILTER_BOX, rfilter_param=0.5, decomposition=P.DECOMPOSITION_TRANSIENT,
+              min_bound=0.0, max_bound=16.0)
+    pm = scenes.homogeneous_scene(modulation=P.MODULATION_SINE, mod_lambda=3.0, mod_phase_deg=20.0, **kw)
+    pt = scenes.homogeneous_scene(bin_width=0.01, **kw)
+    fm, _ = orc.render(pm, 0, 400, 3)
+    ft, _ = orc.render(pt, 0, 400, 3)
+    assert fm.shape == (4, 4, 5)
+    centres = (np.arange(1600) + 0.5) * 0.01
+    corr = orc.correlation(pm, centres.astype(np.float32))
+    want = (ft[..., :-2].reshape(4, 4, 1600, 3) * corr[None, None, :, None]).sum(2)
+    np.testing.assert_allclose(fm[..., :3], want, rtol=2e-2, atol=3e-3 * np.abs(want).max())   # bin-centre quadrature: 0.01 / lambda
+    np.testing.assert_array_equal(fm[..., 3:], ft[..., -2:])
+    assert (fm[..., :3] < 0).any()                                   # a correlation is signed: so is the film
+
+
+def test_modulation_needs_a_transient_film(orc):
+    p = scenes.homogeneous_scene(w=2, h=2, modulation=P.MODULATION_SINE)
+    with pytest.raises(RuntimeError, match="needs decomposition = transient"):
+        orc.render(p, 0, 1, 0)
