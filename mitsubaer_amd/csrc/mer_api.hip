@@ -551,12 +551,13 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     HIP_CHECK(ctx, hipMemsetAsync(ctx->hitq_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
     return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
         const bool has_point = scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0;
-        auto kev = has_point ? event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, true>
-                             : event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, false>;
+        const bool extra = has_point || scene->modulation != MER_MODULATION_NONE;
+        auto kev = extra ? event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, true>
+                         : event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, false>;
         auto kma = march_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
         auto kco = connect_stage_kernel<decltype(curved)::value ? decltype(rif)::value : MER_RIF_TRILINEAR, decltype(stepper)::value, decltype(sigma)::value>;
         const bool connect_stage = has_point && decltype(curved)::value;
-        auto kge = gen_kernel<decltype(curved)::value>;
+        auto kge = extra ? gen_kernel<decltype(curved)::value, true> : gen_kernel<decltype(curved)::value, false>;
         const unsigned gen_blocks = std::max(1u, std::min(nslots / MER_BLOCK, 1024u));      // 4096 waves x 512 ids per launch
         bool work_left = true;
         const unsigned blocks = nslots / MER_BLOCK;

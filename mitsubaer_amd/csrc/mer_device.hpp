@@ -550,7 +550,11 @@ __device__ __noinline__ float correlation_function(const Params &P, float t) {
     return 1.0f;
 }
 // a radiance contribution as it enters the per-path sum: weighted by the correlation function under a modulation (bdpt_proc.cpp:446-447)
+// MOD is a compile-time switch: the out-of-line correlation function must not appear in the kernels of unmodulated renders (a call
+// site costs them their register allocation: K_event went from 50 to 296 ms per bench step with it)
+template <bool MOD>
 __device__ __forceinline__ f3 mod_weight(const Params &P, f3 value, float pathLength) {
+    if (!MOD) return value;
     return P.sc.modulation ? value * correlation_function(P, pathLength) : value;
 }
 // Transient film: one radiance contribution binned by its optical path length (bdpt_proc.cpp:449-470)

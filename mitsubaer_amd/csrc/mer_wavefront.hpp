@@ -88,7 +88,7 @@ __device__ __forceinline__ void flush_counters(const Params &P, const LaneCounte
 // forbids entering it -- is retired here (environment radiance + film splat); a sample that will march is handed to
 // K_event as a work id through the hit ring.  Without this, K_event's regeneration is a per-lane loop with a geometric
 // trip count (80% of the bench scene's camera rays miss) that leaves most lanes of every wave idle.
-template <bool CURVED>
+template <bool CURVED, bool EXTRA>
 __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
     const mer_scene_desc &S = P.sc;
     const f3 env(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
@@ -133,8 +133,8 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
                 }
                 if (!hit) {
                     C.paths++;
-                    if (P.path_out) { const f3 Lm = mod_weight(P, L, plen); float *q = P.path_out + ((size_t) y * S.width + x) * 3; q[0] = Lm.x; q[1] = Lm.y; q[2] = Lm.z; }
-                    else { film_contribute(P, px, py, L, plen); film_put(P, px, py, mod_weight(P, L, plen), 1.0f); }
+                    if (P.path_out) { const f3 Lm = mod_weight<EXTRA>(P, L, plen); float *q = P.path_out + ((size_t) y * S.width + x) * 3; q[0] = Lm.x; q[1] = Lm.y; q[2] = Lm.z; }
+                    else { film_contribute(P, px, py, L, plen); film_put(P, px, py, mod_weight<EXTRA>(P, L, plen), 1.0f); }
                 }
             }
         }
@@ -239,7 +239,8 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
 // index-matched shape + interior medium + constant environment emitter, with the refractive hooks of
 // src/libbidir/edge.cpp:45-60,91-93 and src/libbidir/vertex.cpp:251-255, plus pixel regeneration
 // (src/librender/integrator.cpp:162-187) and ImageBlock::put (include/mitsuba/render/imageblock.h:124-205).
-template <bool CURVED, int RIF, int STEPPER, int SIGMA, bool POINT>
+// EXTRA: the scene has a point emitter and / or a modulated film (the plain kernel carries neither)
+template <bool CURVED, int RIF, int STEPPER, int SIGMA, bool EXTRA>
 __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32_t pass) {
     typedef Walk<CURVED, RIF, STEPPER, SIGMA> WalkT;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
@@ -250,7 +251,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     const uint32_t count = nq + ns;
     // ring hygiene: the rows K_march / K_event of pass+1 will add to
     queue_clear_row(P.eq, pass + 2, j); queue_clear_row(P.mq[pass & 1u], pass + 2, j); queue_clear_row(P.sq[pass & 1u], pass + 2, j);
-    if (POINT && CURVED) queue_clear_row(P.cq, pass + 2, j);
+    if (EXTRA && CURVED) queue_clear_row(P.cq, pass + 2, j);
     LaneCounters C; C.clear();
     bool marching = false, starved_out = false, connecting = false; uint32_t i = 0;
     if (j < count) {
@@ -262,6 +263,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     const f3 env(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
     const bool hasEnv = !is_zero(env);
     const bool hasEmission = S.emission[0] != 0 || S.emission[1] != 0 || S.emission[2] != 0;
+    const bool hasPoint = EXTRA && (S.point_intensity[0] != 0 || S.point_intensity[1] != 0 || S.point_intensity[2] != 0);
     const int maxDepth = S.max_depth;
     const int nwalks = (SIGMA == MER_SIGMA_GRID && S.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
     enum { F_SCATTERED = 1, F_EMITTED = 2, F_ITSVALID = 4 };
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             ev = EV_NONE;
             itsT = intersect_shape(S, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
             if (itsT < 0) {
-                if (!S.hide_emitters) { L = L + mod_weight(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }   // volpath.cpp:194-201
+                if (!S.hide_emitters) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }   // volpath.cpp:194-201
                 ev = EV_PATH_DONE;
             } else if (depth >= maxDepth && maxDepth != -1) ev = EV_PATH_DONE;
             else {
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                 else { itsT = intersect_shape(S, ro, d, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); if (!itsValid) medium = false; }
                 depth++;
                 if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
-                else if (!medium) { if (!S.hide_emitters) { L = L + mod_weight(P, T * env, plen); film_contribute(P, px, py, T * env, plen); } ev = EV_PATH_DONE; }
+                else if (!medium) { if (!S.hide_emitters) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); } ev = EV_PATH_DONE; }
                 else { C.segments++; ps = ro; dsave = d; ev = W.begin(P, rng, C, K_FREE, ro, d, itsT); }
             }
             st = ST_MARCH;
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             if (depth >= maxDepth && maxDepth != -1) { ev = EV_PATH_DONE; continue; }
             if (hasEmission && SIGMA == MER_SIGMA_GRID) {
                 const f3 c = T * f3(S.emission[0], S.emission[1], S.emission[2]) * m.refRatioSq;
-                L = L + mod_weight(P, c, plen);
+                L = L + mod_weight<EXTRA>(P, c, plen);
                 film_contribute(P, px, py, c, plen);
             }
             T = T * (m.sigmaS * m.transmittance / m.pdfSuccess);
@@ -411,7 +413,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                     if (phaseVal != 0) {
                         const float weight = mi_weight(dpdf, phaseVal);              // env emitter is "on surface": constant.cpp:47
                         const f3 c = T * value * phaseVal * weight;
-                        L = L + mod_weight(P, c, plen + trOpt);
+                        L = L + mod_weight<EXTRA>(P, c, plen + trOpt);
                         film_contribute(P, px, py, c, plen + trOpt);
                     }
                 }
@@ -423,7 +425,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                 if (!blocked && !is_zero(tr)) {
                     const f3 value = tr * env;
                     const f3 c = T * value * mi_weight(phasePdf, MER_INV_FOURPI);
-                    L = L + mod_weight(P, c, plen + trOpt);
+                    L = L + mod_weight<EXTRA>(P, c, plen + trOpt);
                     film_contribute(P, px, py, c, plen + trOpt);
                 }
                 ev = EV_AFTER_LOOKUP;
@@ -432,11 +434,11 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             // ---- luminaire sampling of the point emitter, if any (after the environment NEE, as in the oracle's draw order).
             // Curved rays: the connection is a shooting problem of hundreds of sensitivity steps -- it gets a kernel of its
             // own (K_connect) in which every lane solves one; the path resumes at EV_PHASE2 in the next pass.
-            if (POINT && ev == EV_PHASE) {
+            if (EXTRA && hasPoint && ev == EV_PHASE) {
                 if (CURVED) { connecting = true; break; }
                 float optLen = 0.0f;
                 const f3 c = T * point_nee<false, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth, optLen);
-                L = L + mod_weight(P, c, plen + optLen);
+                L = L + mod_weight<EXTRA>(P, c, plen + optLen);
                 film_contribute(P, px, py, c, plen + optLen);
             }
             // ---- phase function sampling: volpath.cpp:149-160
@@ -478,13 +480,13 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             if (CURVED) { T = T * m.refRatioSq; SET_FLAG(F_ITSVALID, true); }         // edge.cpp:45-60
             ev = EV_PATH_DONE;
             if (!itsValid) {
-                if (emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
+                if (emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
             } else if (!(depth >= maxDepth && maxDepth != -1)) {
                 (void) rng.next1D(); (void) rng.next1D();                             // null BSDF sample
                 SET_FLAG(F_EMITTED, !scattered);
                 depth++;
                 if (depth <= maxDepth || maxDepth < 0)
-                    if (emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
+                    if (emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
             }
         } else {  // EV_PATH_DONE: ImageBlock::put (imageblock.h:124-205)
             if (P.path_out) {
@@ -520,7 +522,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
         marching = !connecting;
     }
     }   // j < count
-    if (POINT && CURVED) queue_push(P.cq, pass, connecting, i);
+    if (EXTRA && CURVED) queue_push(P.cq, pass, connecting, i);
     queue_push(P.mq[pass & 1u], pass, marching, i);
     queue_push(P.sq[(pass + 1) & 1u], pass + 1, starved_out, i);
     flush_counters(P, C, 0);
@@ -532,6 +534,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
 // connection; the sampler stream continues where K_event left it, so the draw order is the oracle's.
 template <int RIF, int STEPPER, int SIGMA>
 __global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P, uint32_t pass) {
+    constexpr bool EXTRA = true;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
     const uint32_t count = queue_total(P.cq, pass);
@@ -549,7 +552,7 @@ __global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P
         float optLen = 0.0f;
         const f3 c0 = T * point_nee<true, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth, optLen);
         film_contribute(P, SLOTF(CO_PXF), SLOTF(CO_PYF), c0, SLOTF(CO_PLEN) + optLen);
-        const f3 c = mod_weight(P, c0, SLOTF(CO_PLEN) + optLen);
+        const f3 c = mod_weight<EXTRA>(P, c0, SLOTF(CO_PLEN) + optLen);
         SLOT(CO_LX) = __float_as_uint(SLOTF(CO_LX) + c.x); SLOT(CO_LY) = __float_as_uint(SLOTF(CO_LY) + c.y); SLOT(CO_LZ) = __float_as_uint(SLOTF(CO_LZ) + c.z);
         SLOT(H_RNG_LO) = (uint32_t) rng.state; SLOT(H_RNG_HI) = (uint32_t) (rng.state >> 32);
     }
