@@ -89,7 +89,11 @@ typedef struct {
        modulation the film has one frame and every contribution is weighted by correlationFunction(pathLength)
        (src/integrators/bdpt/bdpt_proc.cpp:446-447; src/librender/film.cpp:76-78). */
     int32_t modulation; float mod_lambda, mod_phase_deg; int32_t mod_P, mod_neighbors;
+    /* BSDF of the medium's boundary shape: MER_BSDF_NULL (index-matched, src/librender/shape.cpp:48-70) or MER_BSDF_HDIELECTRIC
+       (src/bsdfs/hdielectric.cpp: smooth dielectric whose eta is the RIF at the hit point, exterior index 1) */
+    int32_t boundary_bsdf;
 } mer_scene_desc;
+enum { MER_BSDF_NULL = 0, MER_BSDF_HDIELECTRIC = 1 };
 enum { MER_MODULATION_NONE = 0, MER_MODULATION_SINE, MER_MODULATION_SQUARE, MER_MODULATION_HAMILTONIAN, MER_MODULATION_MSEQ,
        MER_MODULATION_DEPTHSELECTIVE };
 enum { MER_DECOMPOSITION_NONE = 0, MER_DECOMPOSITION_TRANSIENT = 1 };

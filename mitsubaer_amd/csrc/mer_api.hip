@@ -199,6 +199,7 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P) {
     if (!(sc->rfilter_param > 0)) return fail(ctx, "reconstruction filter radius/stddev must be positive");
     filter_table(sc->rfilter, sc->rfilter_param, P.fvalues, P.fradius, P.fscale);
     if (P.fradius > 7.0f) return fail(ctx, "reconstruction filter radius too large");
+    if (sc->boundary_bsdf != MER_BSDF_NULL && sc->boundary_bsdf != MER_BSDF_HDIELECTRIC) return fail(ctx, "boundary BSDF must be null or hdielectric");
     if (film_frames(ctx, sc, P.frames)) return 1;
     P.film_ch = P.frames * 3 + 2;
     P.mod_phase = (float) (sc->mod_phase_deg * M_PI / 180);                                                   // pathlengthsampler.cpp:15
@@ -494,6 +495,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     const char *mode = getenv("MER_MODE");
     if (mode && std::strcmp(mode, "mega") == 0) {
         if (scene->decomposition != MER_DECOMPOSITION_NONE) return fail(ctx, "MER_MODE=mega renders steady-state films only; use the default wavefront mode");
+        if (scene->boundary_bsdf != MER_BSDF_NULL) return fail(ctx, "MER_MODE=mega knows the index-matched boundary only; use the default wavefront mode");
         if (scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0)
             return fail(ctx, "MER_MODE=mega does not sample point emitters; use the default wavefront mode");
         return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
@@ -551,7 +553,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     HIP_CHECK(ctx, hipMemsetAsync(ctx->hitq_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
     return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
         const bool has_point = scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0;
-        const bool extra = has_point || scene->modulation != MER_MODULATION_NONE;
+        const bool extra = has_point || scene->modulation != MER_MODULATION_NONE || scene->boundary_bsdf != MER_BSDF_NULL;
         auto kev = extra ? event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, true>
                          : event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, false>;
         auto kma = march_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;

@@ -489,6 +489,59 @@ __device__ __forceinline__ f3 albedo_at(const Params &P, f3 p) {
 
 __device__ __forceinline__ float mi_weight(float a, float b) { a *= a; b *= b; return a / (a + b); }   // volpath.cpp:430-433
 
+// outward geometric normal of the boundary shape at a surface point (cube: the face whose plane the point is closest to)
+__device__ __forceinline__ f3 shape_normal(const mer_scene_desc &s, f3 x) {
+    if (s.boundary == MER_BOUNDARY_SPHERE) return normalize(f3(x.x - s.sph_center[0], x.y - s.sph_center[1], x.z - s.sph_center[2]));
+    float best = -1.0f, sign = 1.0f; int axis = 0;
+    const float xx[3] = {x.x, x.y, x.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float c = 0.5f * (s.bmin[i] + s.bmax[i]), hsz = 0.5f * (s.bmax[i] - s.bmin[i]);
+        const float r = fabsf(xx[i] - c) / hsz;
+        if (r > best) { best = r; axis = i; sign = xx[i] >= c ? 1.0f : -1.0f; }
+    }
+    return f3(axis == 0 ? sign : 0.0f, axis == 1 ? sign : 0.0f, axis == 2 ? sign : 0.0f);
+}
+// fresnelDielectricExt (src/libcore/util.cpp:665-695)
+__device__ __forceinline__ float fresnel_dielectric_ext(float cosThetaI_, float &cosThetaT_, float eta) {
+    if (eta == 1.0f) { cosThetaT_ = -cosThetaI_; return 0.0f; }
+    const float scale = (cosThetaI_ > 0) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
+    const float cosThetaI = fabsf(cosThetaI_), cosThetaT = sqrtf(cosThetaTSqr);
+    const float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    const float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+// HDielectric::sample (src/bsdfs/hdielectric.cpp:183-242, ERadiance) at the boundary point ro + rd*t of the medium shape; eta is the
+// RIF there (:115-118).  Returns true when the sampled direction wo stays in / enters the medium.
+template <bool CURVED, int RIF>
+__device__ __forceinline__ bool dielectric_event(const Params &P, Rng &rng, f3 ro, f3 rd, float t, bool from_inside, f3 &T, float &etaPath,
+                                                 f3 &x, f3 &wo) {
+    const mer_scene_desc &S = P.sc;
+    const float u1 = rng.next1D(); (void) rng.next1D();          // only sample.x is used (:196)
+    x = ro + rd * t;
+    const f3 n = shape_normal(S, x);
+    const float cosI = dot(-rd, n);                              // Frame::cosTheta(wi), wi = -ray.d
+    float etaB = S.rif_const;
+    if (CURVED) {
+        f3 q = x; f3 g; CellCache cc; cc.reset();
+        q.x = fminf(fmaxf(q.x, P.rif.bmin[0]), P.rif.bmax[0]); q.y = fminf(fmaxf(q.y, P.rif.bmin[1]), P.rif.bmax[1]);
+        q.z = fminf(fmaxf(q.z, P.rif.bmin[2]), P.rif.bmax[2]);
+        rif_value_grad<RIF>(P.rif, cc, q, etaB, g);
+    }
+    const float invEtaB = 1 / etaB;
+    float cosT; const float F = fresnel_dielectric_ext(cosI, cosT, etaB);
+    if (u1 <= F) { wo = rd + n * (2 * cosI); return from_inside; }                   // reflect(wi): 2 (wi.n) n - wi
+    const float scale = -(cosT < 0 ? invEtaB : etaB);                                // refract (:121-126)
+    const f3 wi = -rd;
+    wo = (wi - n * cosI) * scale + n * cosT;
+    const float factor = cosT < 0 ? invEtaB : etaB;                                  // solid-angle compression (:213-216)
+    T = T * (factor * factor);
+    etaPath *= (cosT < 0 ? etaB : invEtaB);                                          // bRec.eta (:208)
+    return cosT < 0;
+}
+
 // ImageBlock::put (include/mitsuba/render/imageblock.h:124-205) with one block = the whole image;
 // accumulation by float atomics (replaces film->put under a mutex, renderproc.cpp:142-149)
 // what = 1: RGB into frame `bin`; what = 2: alpha + weight; what = 3: both (steady state: bin 0)

@@ -20,7 +20,7 @@ enum { H_PX = 0, H_PY, H_PZ, H_VX, H_VY, H_VZ, H_OPT, H_DIST, H_REM, H_HPREV, H_
 // cold words (K_event only)
 enum { CO_PXF = H_COUNT, CO_PYF, CO_LX, CO_LY, CO_LZ, CO_TX, CO_TY, CO_TZ, CO_DEPTH, CO_PFLAGS, CO_PSX, CO_PSY, CO_PSZ,
        CO_DSX, CO_DSY, CO_DSZ, CO_DDX, CO_DDY, CO_DDZ, CO_WIX, CO_WIY, CO_WIZ, CO_PHASEPDF, CO_ITST, CO_N0, CO_TRSUM,
-       CO_SDENS, CO_TMIN, CO_WNEXT_LO, CO_WNEXT_HI, CO_WLEFT, CO_PLEN, CO_TROPT, SLOT_WORDS };
+       CO_SDENS, CO_TMIN, CO_WNEXT_LO, CO_WNEXT_HI, CO_WLEFT, CO_PLEN, CO_TROPT, CO_ETA, SLOT_WORDS };
 
 // H_FLAGS: st[1:0] ev[5:2] kind[7:6] seg_inf[8] backstep[9] walk[11:10]
 __device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg_inf, int backstep, int walk) {
@@ -124,6 +124,7 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
                 const float itsT = intersect_shape(S, o, d, mint, maxt);
                 if (itsT < 0) { if (!S.hide_emitters) L = env; }
                 else if (1 >= maxDepth && maxDepth != -1) { }
+                else if (EXTRA && S.boundary_bsdf == MER_BSDF_HDIELECTRIC) hit = true;      // Fresnel sampling at the surface: K_event
                 else {
                     bool medium = true;
                     if (!CURVED) { const f3 ro = o + d * itsT; medium = intersect_shape(S, ro, d, MER_EPSILON, MER_INF) >= 0; }
@@ -261,7 +262,9 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
 
     const mer_scene_desc &S = P.sc;
     const f3 env(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
-    const bool hasEnv = !is_zero(env);
+    const bool dielectric = EXTRA && S.boundary_bsdf == MER_BSDF_HDIELECTRIC;
+    // a dielectric boundary blocks emitter sampling and look-ups from inside: the environment is reached by refracting out
+    const bool hasEnv = !is_zero(env) && !dielectric;
     const bool hasEmission = S.emission[0] != 0 || S.emission[1] != 0 || S.emission[2] != 0;
     const bool hasPoint = EXTRA && (S.point_intensity[0] != 0 || S.point_intensity[1] != 0 || S.point_intensity[2] != 0);
     const int maxDepth = S.max_depth;
@@ -275,6 +278,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
     WalkT W; Rng rng; uint32_t pixel = 0, sample = 0;
     W.cc.reset();
     float px = 0, py = 0, sigma = 0, phasePdf = 0, itsT = 0;
+    float etaPath = 1.0f;                      // relative index along the path (volpath.cpp:276; Russian roulette)
     float plen = 0, trOpt = 0;                 // transient film: optical path length sensor -> vertex; length of the last NEE / look-up walk
     f3 L(0, 0, 0), T(1, 1, 1), ps(0, 0, 0), dsave(0, 0, 1), dd(0, 0, 1), wi(0, 0, 1), trv(1, 1, 1);
     int depth = 1, flags = F_EMITTED, px_i = 0, py_i = 0;
@@ -289,7 +293,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
         dd = f3(SLOTF(CO_DDX), SLOTF(CO_DDY), SLOTF(CO_DDZ)); wi = f3(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
         phasePdf = SLOTF(CO_PHASEPDF); itsT = SLOTF(CO_ITST); W.n0 = SLOTF(CO_N0); W.trsum = SLOTF(CO_TRSUM);
         W.sdens = SLOTF(CO_SDENS); W.tmin = SLOTF(CO_TMIN);
-        plen = SLOTF(CO_PLEN); trOpt = SLOTF(CO_TROPT);
+        plen = SLOTF(CO_PLEN); trOpt = SLOTF(CO_TROPT); if (EXTRA) etaPath = SLOTF(CO_ETA);
         px_i = (int) (pixel % (uint32_t) S.width); py_i = (int) (pixel / (uint32_t) S.width);
     } else {
         W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = 0; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.dist = 0;
@@ -321,7 +325,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             f3 o, d; float mint, maxt;
             sample_ray(P, px, py, o, d, mint, maxt);
             L = f3(0, 0, 0); T = f3(1, 1, 1); depth = 1; flags = F_EMITTED;
-            plen = 0.0f; trOpt = 0.0f;
+            plen = 0.0f; trOpt = 0.0f; etaPath = 1.0f;
             C.paths++;
             ev = EV_NONE;
             itsT = intersect_shape(S, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
@@ -329,7 +333,20 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
                 if (!S.hide_emitters) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }   // volpath.cpp:194-201
                 ev = EV_PATH_DONE;
             } else if (depth >= maxDepth && maxDepth != -1) ev = EV_PATH_DONE;
-            else {
+            else if (dielectric) {
+                // hdielectric boundary (N2): reflect away (the ray escapes: environment, weight 1) or refract into the medium
+                if (!S.calibrated_transient) plen += itsT;
+                f3 x, wo;
+                if (!dielectric_event<CURVED, RIF>(P, rng, o, d, itsT, false, T, etaPath, x, wo)) {
+                    L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen);
+                    ev = EV_PATH_DONE;
+                } else {
+                    ps = x; dsave = wo;
+                    if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
+                    else { itsT = intersect_shape(S, x, wo, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
+                    ev = (CURVED || itsValid) ? EV_AFTER_LOOKUP : EV_PATH_DONE;       // Russian roulette, scattered = true, next segment
+                }
+            } else {
                 (void) rng.next1D(); (void) rng.next1D();                      // null bsdf->sample(..., nextSample2D())
                 if (!S.calibrated_transient) plen += itsT;                     // the camera edge (bdpt_proc.cpp:163-176)
                 const f3 ro = o + d * itsT;
@@ -462,7 +479,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             ev = EV_NONE;
             bool alive = true;
             if (depth++ >= S.rr_depth) {                                              // volpath.cpp:326-336
-                const float q = fminf(max3(T) * 1.0f * 1.0f, 0.95f);
+                const float q = fminf(max3(T) * etaPath * etaPath, 0.95f);
                 if (rng.next1D() >= q) { ev = EV_PATH_DONE; alive = false; }
                 else T = T / q;
             }
@@ -479,6 +496,22 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
             T = T * (m.transmittance / m.pdfFailure);
             if (CURVED) { T = T * m.refRatioSq; SET_FLAG(F_ITSVALID, true); }         // edge.cpp:45-60
             ev = EV_PATH_DONE;
+            if (dielectric && itsValid && !(depth >= maxDepth && maxDepth != -1)) {
+                // hdielectric boundary from inside: total internal / Fresnel reflection keeps the path in the medium
+                f3 ro = ps, rd = dsave; float tHit = itsT;
+                if (CURVED) { ro = m.p; rd = normalize(m.d); tHit = intersect_shape(S, ro, rd, 0.0f, MER_INF); if (!(tHit >= 0)) tHit = 0.0f; }   // re-hit (edge.cpp:45-60)
+                f3 x, wo;
+                if (!dielectric_event<CURVED, RIF>(P, rng, ro, rd, tHit, true, T, etaPath, x, wo)) {
+                    L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen);
+                } else {
+                    ps = x; dsave = wo;
+                    if (CURVED) itsT = 0;
+                    else { itsT = intersect_shape(S, x, wo, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
+                    if (CURVED || itsValid) ev = EV_AFTER_LOOKUP;
+                }
+            } else if (dielectric) {
+                if (!itsValid && emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
+            } else
             if (!itsValid) {
                 if (emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
             } else if (!(depth >= maxDepth && maxDepth != -1)) {
@@ -518,7 +551,7 @@ __global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32
         SLOT(CO_PHASEPDF) = __float_as_uint(phasePdf); SLOT(CO_ITST) = __float_as_uint(itsT);
         SLOT(CO_N0) = __float_as_uint(W.n0); SLOT(CO_TRSUM) = __float_as_uint(W.trsum);
         SLOT(CO_SDENS) = __float_as_uint(W.sdens); SLOT(CO_TMIN) = __float_as_uint(W.tmin);
-        SLOT(CO_PLEN) = __float_as_uint(plen); SLOT(CO_TROPT) = __float_as_uint(trOpt);
+        SLOT(CO_PLEN) = __float_as_uint(plen); SLOT(CO_TROPT) = __float_as_uint(trOpt); if (EXTRA) SLOT(CO_ETA) = __float_as_uint(etaPath);
         marching = !connecting;
     }
     }   // j < count

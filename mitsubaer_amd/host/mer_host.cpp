@@ -168,11 +168,12 @@ void Shape::addChild(const std::string &name, ObjRef child) {
     if (cls == "Medium") {
         if (name == "interior") {
             interior = std::static_pointer_cast<Medium>(child);
-            if (interior->isheterogeneousrefractive() && hasBSDF)        // shape.cpp:172-176
+            if (interior->isheterogeneousrefractive() && hasBSDF && bsdf != MER_BSDF_HDIELECTRIC)        // shape.cpp:172-176
                 Log_EError("A shape with heterogeneous refractive index medium should only have a bsdf that is also heterogeneous!");
         } else if (name == "exterior") Log_EError("Shape: an 'exterior' medium is not supported on the GPU path (the sensor must be in vacuum)");
         else Log_EError("Shape: Invalid medium child (must be named 'interior' or 'exterior')!");    // shape.cpp:186-188
-    } else ConfigurableObject::addChild(name, child);
+    } else if (cls == "BSDF") { /* recorded before the children are attached (see build()) */ }
+    else ConfigurableObject::addChild(name, child);
 }
 void Film::addChild(const std::string &name, ObjRef child) {
     if (std::string(child->getClassName()) == "ReconstructionFilter") rfilter = std::static_pointer_cast<ReconstructionFilter>(child);
@@ -371,6 +372,15 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
         if (type != "independent" && type != "ldsampler") Log_EError("sampler \"" + type + "\" is not supported on the GPU path");
         o->sampleCount = props.getInteger("sampleCount", 4);
         out = o;
+    } else if (tag == "bsdf") {
+        auto o = std::make_shared<BSDF>();
+        if (type == "null") o->kind = MER_BSDF_NULL;
+        else if (type == "hdielectric") {                                  // src/bsdfs/hdielectric.cpp:46-60
+            o->kind = MER_BSDF_HDIELECTRIC;
+            const Spectrum r = props.getSpectrum("specularReflectance", Spectrum{{1, 1, 1}}), t = props.getSpectrum("specularTransmittance", Spectrum{{1, 1, 1}});
+            for (int i = 0; i < 3; i++) if (r.c[i] != 1.0f || t.c[i] != 1.0f) Log_EError("hdielectric: specularReflectance / specularTransmittance other than 1 are not supported on the GPU path");
+        } else Log_EError("bsdf \"" + type + "\" is not supported on the GPU path (null, hdielectric)");
+        out = o;
     } else if (tag == "emitter") {
         auto o = std::make_shared<Emitter>();
         if (type == "constant") o->radiance = props.getSpectrum("radiance", Spectrum{{1, 1, 1}});
@@ -523,7 +533,6 @@ struct Loader {
         return false;
     }
     ObjRef build(const Node &n) {
-        if (n.tag == "bsdf") Log_EError("bsdf plugins are not supported on the GPU path: the medium boundary is index-matched (null BSDF)");
         Properties props(attr(n, "type"));
         std::vector<std::pair<std::string, ObjRef>> children;
         for (const Node &c : n.children) {
@@ -553,7 +562,8 @@ struct Loader {
             else Log_EError("Unsupported property tag <" + c.tag + ">");
         }
         ObjRef obj = createObject(n.tag, props, baseDir);
-        if (n.tag == "shape") for (auto &ch : children) if (std::string(ch.second->getClassName()) == "BSDF") std::static_pointer_cast<Shape>(obj)->hasBSDF = true;
+        if (n.tag == "shape") for (auto &ch : children) if (std::string(ch.second->getClassName()) == "BSDF") {
+            std::static_pointer_cast<Shape>(obj)->hasBSDF = true; std::static_pointer_cast<Shape>(obj)->bsdf = std::static_pointer_cast<BSDF>(ch.second)->kind; }
         for (auto &ch : children) obj->addChild(ch.first, ch.second);
         obj->configure();
         if (n.attr.count("id")) byId[subst(n.attr.at("id"))] = obj;
@@ -605,7 +615,7 @@ void Integrator::flatten(const Scene &scene, mer_scene_desc &d) const {
     const Shape *shape = NULL;
     for (auto &s : scene.shapes) if (s->interior) { if (shape) Log_EError("Only one shape with an interior medium is supported on the GPU path"); shape = s.get(); }
     if (!shape) Log_EError("No shape with an 'interior' medium was found");
-    d.boundary = shape->boundary;
+    d.boundary = shape->boundary; d.boundary_bsdf = shape->bsdf;
     for (int i = 0; i < 3; i++) { d.bmin[i] = shape->bmin[i]; d.bmax[i] = shape->bmax[i]; d.sph_center[i] = shape->center[i]; }
     d.sph_radius = shape->radius;
     const Medium &m = *shape->interior;

@@ -128,7 +128,15 @@ public:
     int boundary = MER_BOUNDARY_AABB;
     float bmin[3] = {-1, -1, -1}, bmax[3] = {1, 1, 1}, center[3] = {0, 0, 0}, radius = 1;
     std::shared_ptr<Medium> interior;
-    bool hasBSDF = false;
+    bool hasBSDF = false;              ///< a bsdf child was given (null | hdielectric)
+    int bsdf = MER_BSDF_NULL;          ///< MER_BSDF_*
+};
+/// BSDF of the medium shape: `null` (index-matched) or `hdielectric` (src/bsdfs/hdielectric.cpp: eta = RIF at the hit point)
+class BSDF : public ConfigurableObject {
+public:
+    const char *getClassName() const override { return "BSDF"; }
+    int kind = MER_BSDF_NULL;
+    bool isheterogeneousbsdf() const { return kind == MER_BSDF_HDIELECTRIC; }
 };
 
 class ReconstructionFilter : public ConfigurableObject {

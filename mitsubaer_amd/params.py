@@ -19,6 +19,7 @@ STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL = 0, 1, 2
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 ALBEDO_CONST, ALBEDO_GRID = 0, 1
 DECOMPOSITION_NONE, DECOMPOSITION_TRANSIENT = 0, 1
+BSDF_NULL, BSDF_HDIELECTRIC = 0, 1
 MODULATION_NONE, MODULATION_SINE, MODULATION_SQUARE, MODULATION_HAMILTONIAN, MODULATION_MSEQ, MODULATION_DEPTHSELECTIVE = 0, 1, 2, 3, 4, 5
 
 
@@ -50,6 +51,7 @@ class SceneParams:
         self.max_depth = -1; self.rr_depth = 5; self.hide_emitters = False
         # shape: cube [-1,1]^3 (scenes/volumetric/bounds.obj), null BSDF
         self.boundary = BOUNDARY_AABB
+        self.boundary_bsdf = BSDF_NULL                            # BSDF_HDIELECTRIC: smooth dielectric, eta = RIF at the hit point
         self.bmin = [-1.0, -1.0, -1.0]; self.bmax = [1.0, 1.0, 1.0]
         self.sph_center = [0.0, 0.0, 0.0]; self.sph_radius = 1.0
         # medium

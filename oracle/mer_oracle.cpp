@@ -655,6 +655,29 @@ struct Scene {
         if (farT <= maxt) return farT;
         return -1;
     }
+    /* outward geometric normal of the boundary shape at a surface point (cube: the face whose plane the point is closest to) */
+    inline Vec shapeNormal(const Vec &x) const {
+        if (s.boundary == ORC_BOUNDARY_SPHERE) {
+            Vec n(x.x - s.sph_center[0], x.y - s.sph_center[1], x.z - s.sph_center[2]);
+            return normalize(n);
+        }
+        Float best = -1; int axis = 0; Float sign = 1;
+        const Float xx[3] = {x.x, x.y, x.z};
+        for (int i = 0; i < 3; ++i) {
+            const Float c = 0.5f * (s.bmin[i] + s.bmax[i]), hsz = 0.5f * (s.bmax[i] - s.bmin[i]);
+            const Float r = std::fabs(xx[i] - c) / hsz;
+            if (r > best) { best = r; axis = i; sign = xx[i] >= c ? 1.0f : -1.0f; }
+        }
+        return Vec(axis == 0 ? sign : 0.0f, axis == 1 ? sign : 0.0f, axis == 2 ? sign : 0.0f);
+    }
+    /* eta of the hdielectric boundary: the RIF at the hit point (hdielectric.cpp:115-118), queried just inside the grid */
+    inline Float boundaryEta(const Vec &x) const {
+        if (s.rif_mode == ORC_RIF_CONST) return s.rif_const;
+        Counters dummy; Vec q = x;
+        const Float *mn = s.rif.aabb_min, *mx = s.rif.aabb_max;
+        q.x = std::min(std::max(q.x, mn[0]), mx[0]); q.y = std::min(std::max(q.y, mn[1]), mx[1]); q.z = std::min(std::max(q.z, mn[2]), mx[2]);
+        return s.rif_double ? (Float) rifD.value(V3<double>(q), dummy) : rifF.value(V3<float>(q), dummy);
+    }
     inline Spec albedoAt(const Vec &p) const {
         if (s.albedo_mode == ORC_ALBEDO_GRID) return albedoGrid.lookupSpectrum(p);
         return Spec(s.albedo[0], s.albedo[1], s.albedo[2]);       /* constvolume.cpp:57-64 */
@@ -987,6 +1010,19 @@ template <typename FLOAT> struct Connector {
 };
 
 
+/* src/libcore/util.cpp:665-695 */
+inline Float fresnelDielectricExt(Float cosThetaI_, Float &cosThetaT_, Float eta) {
+    if (eta == 1) { cosThetaT_ = -cosThetaI_; return 0.0f; }
+    Float scale = (cosThetaI_ > 0) ? 1 / eta : eta, cosThetaTSqr = 1 - (1 - cosThetaI_ * cosThetaI_) * (scale * scale);
+    if (cosThetaTSqr <= 0.0f) { cosThetaT_ = 0.0f; return 1.0f; }
+    Float cosThetaI = std::abs(cosThetaI_);
+    Float cosThetaT = std::sqrt(cosThetaTSqr);
+    Float Rs = (cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT);
+    Float Rp = (eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT);
+    cosThetaT_ = (cosThetaI_ > 0) ? -cosThetaT : cosThetaT;
+    return 0.5f * (Rs * Rs + Rp * Rp);
+}
+
 /* ------------------------------------------------------------------ media */
 struct Walker {
     const Scene &S; Pcg32 &rng; Counters &C;
@@ -1273,7 +1309,11 @@ struct Walker {
     Spec Li(Vec ro, Vec rd, Float rmint, Float rmaxt) {
         const orc_scene &P = S.s;
         const Spec env(P.env_radiance[0], P.env_radiance[1], P.env_radiance[2]);
-        const bool hasEnv = !env.isZero();
+        const bool dielectric = P.boundary_bsdf == ORC_BSDF_HDIELECTRIC;
+        /* a dielectric boundary blocks emitter sampling and emitter look-ups from inside (Scene::evalTransmittance stops at a non-null
+           surface): the environment is reached only by paths that refract out */
+        const bool hasEnvAny = !env.isZero();
+        const bool hasEnv = hasEnvAny && !dielectric;
         const bool hasEmission = P.emission[0] != 0 || P.emission[1] != 0 || P.emission[2] != 0;
         const Spec pointI(P.point_intensity[0], P.point_intensity[1], P.point_intensity[2]);
         const bool hasPoint = !pointI.isZero();
@@ -1417,6 +1457,45 @@ struct Walker {
                     break;
                 }
                 if (depth >= maxDepth && maxDepth != -1) break;
+                if (dielectric) {
+                    /* hdielectric boundary (N2): BSDF sampling of volpath.cpp:259-316 with HDielectric::sample (hdielectric.cpp:183-242);
+                       not smooth => no luminaire sampling; only sample.x is used (:196) */
+                    const Float u1 = rng.next1D(); (void) rng.next1D();
+                    if (S.curved && medium) {                  /* edge.cpp:45-60: the surface point is re-found from mRec.p along mRec.d */
+                        const Float tHit = S.intersectShape(ro, rd, 0.0f, std::numeric_limits<Float>::infinity());
+                        itsT = tHit >= 0 ? tHit : 0;
+                    }
+                    if (!medium && !P.calibrated_transient) plen += itsT;
+                    const Vec x = ro + rd * itsT;
+                    const Vec n = S.shapeNormal(x);
+                    const Float cosI = dot(-rd, n);            /* Frame::cosTheta(bRec.wi), wi = -ray.d */
+                    const Float etaB = S.boundaryEta(x), invEtaB = 1 / etaB;          /* hdielectric.cpp:115-118 */
+                    Float cosT; const Float F = fresnelDielectricExt(cosI, cosT, etaB);
+                    Vec wo; bool inside;
+                    if (u1 <= F) {                             /* reflect(wi) = (-x,-y,z) locally: 2 (wi.n) n - wi */
+                        wo = rd + n * (2 * cosI);
+                        inside = medium;
+                    } else {                                   /* refract (:121-126): (scale wi.x, scale wi.y, cosThetaT) locally */
+                        const Float scale = -(cosT < 0 ? invEtaB : etaB);
+                        const Vec wi = -rd;
+                        wo = (wi - n * cosI) * scale + n * cosT;
+                        const Float factor = cosT < 0 ? invEtaB : etaB;               /* ERadiance: solid-angle compression (:213-216) */
+                        throughput *= factor * factor;
+                        eta *= (cosT < 0 ? etaB : invEtaB);                            /* bRec.eta (:208) */
+                        inside = cosT < 0;
+                    }
+                    ro = x; rd = wo; medium = inside;
+                    if (!medium) {
+                        /* rayIntersectAndLookForEmitter: the shape is convex, the ray escapes to the environment; delta BSDF => weight 1 */
+                        if (hasEnvAny) { Li += throughput * env; contribute(throughput * env, plen); }
+                        itsValid = false; itsT = -1;
+                    } else {
+                        itsT = S.curved ? 0 : S.intersectShape(ro, rd, Epsilon, std::numeric_limits<Float>::infinity());
+                        itsValid = S.curved ? true : itsT >= 0;
+                        if (!itsValid) medium = false;
+                    }
+                    emitted = false;                           /* ERadianceNoEmission (volpath.cpp:322) */
+                } else {
                 /* null BSDF (shape.cpp:48-70): no NEE (not smooth), pass-through sample */
                 (void) rng.next1D(); (void) rng.next1D();     /* bsdf->sample(bRec, pdf, rRec.nextSample2D()) */
                 if (!medium && !P.calibrated_transient) plen += itsT;      /* the camera edge (bdpt_proc.cpp:163-176: startIndex 2 | 3) */
@@ -1430,6 +1509,7 @@ struct Walker {
                 } else { itsValid = false; itsT = -1; }
                 depth++;
                 continue;
+                }
             }
             if (depth++ >= P.rr_depth) {                      /* volpath.cpp:326-336 */
                 Float q = std::min(throughput.max() * eta * eta, (Float) 0.95f);

@@ -82,7 +82,11 @@ typedef struct {
        3 hamiltonian, 4 mseq, 5 depthselective.  With a modulation the transient film has one frame and every contribution is
        weighted by correlationFunction(pathLength) (bdpt_proc.cpp:446-447). */
     int32_t modulation; float mod_lambda, mod_phase_deg; int32_t mod_P, mod_neighbors;
+    /* BSDF of the medium's boundary shape: 0 = null (index-matched), 1 = hdielectric (src/bsdfs/hdielectric.cpp: smooth dielectric
+       whose eta is the RIF at the hit point, exterior index 1) */
+    int32_t boundary_bsdf;
 } orc_scene;
+enum { ORC_BSDF_NULL = 0, ORC_BSDF_HDIELECTRIC = 1 };
 
 enum {
     ORC_C_PATHS = 0, ORC_C_STEPS, ORC_C_RIF_EVALS, ORC_C_TENTATIVE, ORC_C_REAL,

@@ -53,6 +53,7 @@ class Scene(C.Structure):
         ("decomposition", C.c_int32), ("min_bound", C.c_float), ("max_bound", C.c_float), ("bin_width", C.c_float),
         ("calibrated_transient", C.c_int32),
         ("modulation", C.c_int32), ("mod_lambda", C.c_float), ("mod_phase_deg", C.c_float), ("mod_P", C.c_int32), ("mod_neighbors", C.c_int32),
+        ("boundary_bsdf", C.c_int32),
     ]
 
 
@@ -130,6 +131,7 @@ def make_scene(p):
     s.decomposition = p.decomposition; s.min_bound = p.min_bound; s.max_bound = p.max_bound; s.bin_width = p.bin_width
     s.calibrated_transient = int(p.calibrated_transient)
     s.modulation = p.modulation; s.mod_lambda = p.mod_lambda; s.mod_phase_deg = p.mod_phase_deg; s.mod_P = p.mod_P; s.mod_neighbors = p.mod_neighbors
+    s.boundary_bsdf = p.boundary_bsdf
     return s, keep
 
 

@@ -38,6 +38,12 @@ CASES = {
     "cfg5_rgb_albedo_grid_emissive": lambda: scenes.curved_scene(N=24, albedo_mode=P.ALBEDO_GRID, albedo_grid=scenes.rgb_albedo(24), emission=[0.2, 0.12, 0.06]),
     "point_curved_cfg5_rgb_albedo_emissive": lambda: scenes.curved_scene(N=24, w=32, h=24, albedo_mode=P.ALBEDO_GRID, albedo_grid=scenes.rgb_albedo(24), emission=[0.2, 0.12, 0.06],
                                                                          env_radiance=[0, 0, 0], point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5]),
+    "dielectric_homogeneous": lambda: scenes.homogeneous_scene(rif_const=1.5, boundary_bsdf=P.BSDF_HDIELECTRIC),
+    "dielectric_straight_grid": lambda: scenes.straight_scene(N=24, rif_const=1.33, boundary_bsdf=P.BSDF_HDIELECTRIC),
+    "dielectric_curved_trilinear": lambda: scenes.curved_scene(N=24, boundary_bsdf=P.BSDF_HDIELECTRIC),
+    "dielectric_curved_sphere_radial": lambda: scenes.curved_scene(N=24, rif="radial", boundary=P.BOUNDARY_SPHERE, sph_radius=0.9, boundary_bsdf=P.BSDF_HDIELECTRIC),
+    "dielectric_curved_bspline": lambda: scenes.bspline_scene(N=24, boundary_bsdf=P.BSDF_HDIELECTRIC),
+    "point_curved_dielectric": lambda: scenes.curved_scene(N=24, w=32, h=24, boundary_bsdf=P.BSDF_HDIELECTRIC, point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5]),
     "emissive_rgb": lambda: scenes.curved_scene(N=24, env_radiance=[0, 0, 0], emission=[1.0, 0.6, 0.3], albedo=[0.95, 0.9, 0.8]),
 }
 
@@ -60,7 +66,8 @@ def test_per_path_radiance_matches_oracle(ctx, orc, name):
         v.destroy()
 
 
-@pytest.mark.parametrize("name", ["cfg2_straight_ratio", "cfg3_curved_rk4_trilinear", "parity_verlet_bspline", "cfg1_homogeneous_isotropic"])
+@pytest.mark.parametrize("name", ["cfg2_straight_ratio", "cfg3_curved_rk4_trilinear", "parity_verlet_bspline", "cfg1_homogeneous_isotropic",
+                                  "dielectric_straight_grid", "dielectric_curved_trilinear"])
 def test_film_matches_oracle_at_equal_spp(ctx, orc, name):
     p = CASES[name]()
     sc, vols = ctx.upload_scene(p)

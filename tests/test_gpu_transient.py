@@ -18,6 +18,7 @@ CASES = {
     "curved_env_rk4": lambda: scenes.curved_scene(N=24, w=24, h=20, **TR),
     "curved_env_woodcock2_calibrated": lambda: scenes.curved_scene(N=24, w=24, h=20, tr_estimator=P.TR_WOODCOCK2, calibrated_transient=True, **TR),
     "curved_homogeneous_sigma": lambda: scenes.curved_scene(N=24, w=24, h=20, sigma_mode=P.SIGMA_HOMOGENEOUS, stepper=P.STEP_VERLET, **TR),
+    "curved_dielectric_boundary": lambda: scenes.curved_scene(N=24, w=24, h=20, boundary_bsdf=P.BSDF_HDIELECTRIC, **TR),
     "curved_point_emissive": lambda: scenes.curved_scene(N=24, w=24, h=20, emission=[0.2, 0.12, 0.06], **POINT, **TR),
 }
 

@@ -146,3 +146,19 @@ def test_modulated_film_flattens_to_one_frame(tmp_path):
     d, _ = host.flatten_xml(_scene(tmp_path, body))
     assert d.decomposition == P.DECOMPOSITION_TRANSIENT and d.modulation == P.MODULATION_SINE
     assert abs(d.mod_lambda - 2.5) < 1e-7 and d.mod_phase_deg == 90 and (d.mod_P, d.mod_neighbors) == (32, 3)    # pathlengthsampler.cpp:14-17 defaults
+
+
+def test_hdielectric_boundary_flattens(tmp_path):
+    """shape.cpp:172-176: a refractive medium's shape may only carry a heterogeneous bsdf (hdielectric)"""
+    dens, rif = _vols(tmp_path)
+    med = ('<medium type="heterogeneousrefractive" id="m"><spectrum name="sigmaS" value="1"/><spectrum name="sigmaA" value="0.1"/>'
+           '<volume name="rif" type="gridvolume"><string name="filename" value="%s"/></volume></medium>' % rif)
+    ok = '<integrator type="volpath"/>' + CAM + med + '<shape type="cube"><bsdf type="hdielectric"/><ref name="interior" id="m"/></shape>'
+    d, _ = host.flatten_xml(_scene(tmp_path, ok))
+    assert d.boundary_bsdf == P.BSDF_HDIELECTRIC and d.rif_mode == P.RIF_TRILINEAR
+    d, _ = host.flatten_xml(_scene(tmp_path, ok.replace('<bsdf type="hdielectric"/>', '')))
+    assert d.boundary_bsdf == P.BSDF_NULL
+    with pytest.raises(host.HostError, match="should only have a bsdf that is also heterogeneous"):
+        host.flatten_xml(_scene(tmp_path, ok.replace('type="hdielectric"', 'type="null"')))
+    with pytest.raises(host.HostError, match="not supported on the GPU path"):
+        host.flatten_xml(_scene(tmp_path, ok.replace('type="hdielectric"', 'type="diffuse"')))

@@ -443,3 +443,42 @@ def test_modulation_needs_a_transient_film(orc):
     p = scenes.homogeneous_scene(w=2, h=2, modulation=P.MODULATION_SINE)
     with pytest.raises(RuntimeError, match="needs decomposition = transient"):
         orc.render(p, 0, 1, 0)
+
+
+# ----------------------------------------------------------------------------- N2: hdielectric boundary
+def test_dielectric_fresnel_reflectance_at_normal_incidence(orc):
+    """maxDepth = 2 leaves exactly one surface event: the camera ray reflects off the cube face with probability F and then sees
+    the unit environment (delta BSDF: weight 1); the refracted part never comes back.  Head-on: F = ((n-1)/(n+1))^2."""
+    for n, F in ((1.5, 0.04), (1.33, (0.33 / 2.33) ** 2)):
+        p = scenes.homogeneous_scene(w=2, h=2, fov_x_deg=0.05, rif_const=n, boundary_bsdf=P.BSDF_HDIELECTRIC, max_depth=2,
+                                     rfilter=P.FILTER_BOX, rfilter_param=0.5)
+        film, _ = orc.render(p, 0, 200000, 1)
+        got = film[..., 0].sum() / film[..., 4].sum()
+        assert abs(got - F) < 4 * np.sqrt(F * (1 - F) / 800000) + 1e-4, (n, got, F)
+
+
+@pytest.mark.parametrize("kind", ["homogeneous", "grid", "empty_glass"])
+def test_dielectric_furnace_constant_index(orc, kind):
+    """non-absorbing medium of constant index behind a smooth dielectric boundary, unit environment: radiance 1 along every
+    camera ray (the 1/eta^2 on the way in and eta^2 on the way out of hdielectric.cpp:213-216 cancel; total internal reflection
+    only redirects)."""
+    kw = dict(w=12, h=12, fov_x_deg=40.0, boundary_bsdf=P.BSDF_HDIELECTRIC, rr_depth=100000, rfilter=P.FILTER_BOX, rfilter_param=0.5)
+    if kind == "homogeneous":
+        p = scenes.homogeneous_scene(sigma_a=[0, 0, 0], sigma_s=[1.0, 1.0, 1.0], rif_const=1.5, **kw)
+    elif kind == "grid":
+        p = scenes.straight_scene(N=16, albedo=[1, 1, 1], rif_const=1.33, **kw)
+    else:
+        p = scenes.straight_scene(N=16, albedo=[1, 1, 1], rif_const=1.5, density_scale=1e-6, **kw)
+    film, _ = orc.render(p, 0, 400, 3)
+    img = film[..., :3] / film[..., 4:5]
+    assert abs(img.mean() - 1.0) < 5e-3, img.mean()
+
+
+def test_dielectric_index_one_is_the_null_boundary_in_expectation(orc):
+    """eta = 1: F = 0 and the refracted direction is the incident one -- the dielectric boundary degenerates to the index-matched
+    one, except that the environment is then collected on exit instead of by emitter sampling (same expectation)."""
+    kw = dict(N=16, w=6, h=6, fov_x_deg=30.0, rfilter=P.FILTER_BOX, rfilter_param=0.5, albedo=[0.8, 0.7, 0.6])
+    a, _ = orc.render(scenes.straight_scene(**kw), 0, 4000, 2)
+    b, _ = orc.render(scenes.straight_scene(boundary_bsdf=P.BSDF_HDIELECTRIC, rif_const=1.0, **kw), 0, 4000, 2)
+    ma = a[..., :3].sum((0, 1)) / a[..., 4].sum(); mb = b[..., :3].sum((0, 1)) / b[..., 4].sum()
+    np.testing.assert_allclose(mb, ma, rtol=0.02)
