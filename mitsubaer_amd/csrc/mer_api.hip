@@ -409,19 +409,50 @@ int mer_volume_build_spline(mer_context *ctx, mer_volume h) {
     if (v.coeff) return 0;
     const int nx = v.desc.res[0], ny = v.desc.res[1], nz = v.desc.res[2];
     const size_t n = (size_t) nx * ny * nz;
-    float *a = nullptr, *b = nullptr;
+    float *a = nullptr, *b = nullptr, *t = nullptr;
     HIP_CHECK(ctx, hipMalloc((void **) &a, n * 4));
     HIP_CHECK(ctx, hipMalloc((void **) &b, n * 4));
     // along y (lines indexed by x and z), then x (by y and z), then z (by x and y): basisspline.h:868-887
-    hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) nx * nz)), dim3(256), 0, ctx->stream,
-                       (const float *) v.dense, a, nx, nz, (int64_t) 1, (int64_t) nx * ny, (int64_t) nx, ny);
-    hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) ny * nz)), dim3(256), 0, ctx->stream,
-                       (const float *) a, b, ny, nz, (int64_t) nx, (int64_t) nx * ny, (int64_t) 1, nx);
-    hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) nx * ny)), dim3(256), 0, ctx->stream,
-                       (const float *) b, a, nx, ny, (int64_t) 1, (int64_t) nx, (int64_t) nx * ny, nz);
+    const bool seq = getenv("MER_PREFILTER_SEQ") != nullptr || std::min(nx, std::min(ny, nz)) < 16;
+    if (seq) {                 // one thread per line (reference order of operations; tiny grids)
+        hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) nx * nz)), dim3(256), 0, ctx->stream,
+                           (const float *) v.dense, a, nx, nz, (int64_t) 1, (int64_t) nx * ny, (int64_t) nx, ny);
+        hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) ny * nz)), dim3(256), 0, ctx->stream,
+                           (const float *) a, b, ny, nz, (int64_t) nx, (int64_t) nx * ny, (int64_t) 1, nx);
+        hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) nx * ny)), dim3(256), 0, ctx->stream,
+                           (const float *) b, a, nx, ny, (int64_t) 1, (int64_t) nx, (int64_t) nx * ny, nz);
+    } else {
+        if (getenv("MER_PREFILTER_TWO_KERNEL") || getenv("MER_PREFILTER_NO_LDS")) HIP_CHECK(ctx, hipMalloc((void **) &t, n * 4));
+        auto pass = [&](const float *src, float *dst, int na, int nb, int64_t sa, int64_t sb, int64_t sl, int size) {
+            const int64_t threads = (int64_t) na * nb * ((size + MER_PF_SEG - 1) / MER_PF_SEG);
+            hipLaunchKernelGGL(bspline_causal_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, src, t, na, nb, sa, sb, sl, size);
+            hipLaunchKernelGGL(bspline_anticausal_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, (const float *) t, dst, na, nb, sa, sb, sl, size);
+        };
+        auto win = [&](const float *src, float *dst, int na, int nb, int64_t sb, int64_t sl, int size) {     // fused sweeps, unit stride in a
+            const int64_t threads = (int64_t) na * nb * ((size + MER_PF_SEG - 1) / MER_PF_SEG);
+            hipLaunchKernelGGL(bspline_win_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, src, dst, na, nb, sb, sl, size);
+        };
+        const bool two_kernel = getenv("MER_PREFILTER_TWO_KERNEL") != nullptr;
+        if (two_kernel) pass((const float *) v.dense, a, nx, nz, 1, (int64_t) nx * ny, nx, ny);          // y
+        else win((const float *) v.dense, a, nx, nz, (int64_t) nx * ny, nx, ny);
+        if (getenv("MER_PREFILTER_NO_LDS")) pass(a, b, ny, nz, nx, (int64_t) nx * ny, 1, nx);           // x, strided form
+        else {                                                                                        // x: lines are contiguous -> LDS tiles
+            const int64_t nlines = (int64_t) ny * nz;
+            if (nx % 4 == 0 && !getenv("MER_PREFILTER_LDS")) {
+                const int64_t threads = nlines * ((nx + MER_PF_SEG - 1) / MER_PF_SEG);
+                hipLaunchKernelGGL(bspline_x_reg_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, (const float *) a, b, nlines, nx);
+            } else {
+                const int64_t blocks = ((nlines + MER_PFX_ROWS - 1) / MER_PFX_ROWS) * ((nx + MER_PFX_COLS - 1) / MER_PFX_COLS);
+                hipLaunchKernelGGL(bspline_x_kernel, dim3((unsigned) blocks), dim3(256), 0, ctx->stream, (const float *) a, b, nlines, nx);
+            }
+        }
+        if (two_kernel) pass(b, a, nx, ny, 1, nx, (int64_t) nx * ny, nz);                                // z
+        else win(b, a, nx, ny, nx, (int64_t) nx * ny, nz);
+    }
     HIP_CHECK(ctx, hipGetLastError());
     HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     (void) hipFree(b);
+    if (t) (void) hipFree(t);
     v.coeff = a;
     return 0;
 }

@@ -464,6 +464,174 @@ __global__ void bspline_pass_kernel(const float *src, float *dst, int nlines_a, 
     }
 }
 
+// K_prefilter, parallel form.  The filter's pole is z1 = sqrt(3)-2 = -0.268: a coefficient depends on samples k positions away with
+// weight z1^k, below float resolution (2^-24 relative) after 13 samples and below 1e-23 after 40.  So a line is cut into segments that
+// are filtered independently after a warm-up of MER_PF_WARM samples (the first segment starts from the exact mirror sum, the last
+// anti-causal one from the exact end condition): same arithmetic per sample as the sequential recursion, N^3 / SEG threads instead
+// of N^2, every global access coalesced.  Two kernels per axis (causal -> tmp, anti-causal -> out): the anti-causal warm-up of one
+// segment reads causal values that a neighbouring segment would otherwise already have overwritten.
+#define MER_PF_WARM 40
+#define MER_PF_SEG 32
+__device__ __forceinline__ float bspline_cp0(const float *src, int64_t offset, int64_t stride_line, int size, float z1) {
+    // basisspline.h:826-838: pow(z1, i) in double, sum in float; terms beyond z1^64 (< 1e-36) cannot change a float sum
+    const int nf = size < 64 ? size : 64;
+    float cp0 = 0.0f; double zp = 1.0;
+    for (int i = 0; i < nf; i++) { cp0 += (float) ((double) src[offset + i * stride_line] * zp); zp *= (double) z1; }
+    if (size <= 64) {
+        for (int i = size - 2; i > 0; i--) cp0 += (float) ((double) src[offset + i * stride_line] * pow((double) z1, (double) (2 * size - 2 - i)));
+        cp0 = (float) ((double) cp0 / (1.0 - pow((double) z1, (double) (2 * size - 2))));
+    }
+    return cp0;
+}
+// thread <-> (a, segment, b); a is the fastest index: pass stride_a = 1 (y and z passes) for coalesced accesses
+__global__ void bspline_causal_kernel(const float *src, float *tmp, int na, int nb, int64_t stride_a, int64_t stride_b, int64_t stride_line, int size) {
+    const int nseg = (size + MER_PF_SEG - 1) / MER_PF_SEG;
+    const int64_t id = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t) na * nseg * nb) return;
+    const int64_t a = id % na, r = id / na; const int seg = (int) (r % nseg); const int64_t b = r / nseg;
+    const int64_t offset = a * stride_a + b * stride_b;
+    const float z1 = -2.0f + sqrtf(3.0f);
+    const int i0 = seg * MER_PF_SEG, i1 = min(i0 + MER_PF_SEG, size);
+    int w0 = max(i0 - MER_PF_WARM, 0);
+    float c;
+    if (w0 == 0) { c = bspline_cp0(src, offset, stride_line, size, z1); if (i0 == 0) tmp[offset] = c; }
+    else c = src[offset + (int64_t) w0 * stride_line];
+    for (int i = w0 + 1; i < i0; i++) c = src[offset + (int64_t) i * stride_line] + z1 * c;
+    for (int i = max(i0, 1); i < i1; i++) { c = src[offset + (int64_t) i * stride_line] + z1 * c; tmp[offset + (int64_t) i * stride_line] = c; }
+}
+__global__ void bspline_anticausal_kernel(const float *tmp, float *out, int na, int nb, int64_t stride_a, int64_t stride_b, int64_t stride_line, int size) {
+    const int nseg = (size + MER_PF_SEG - 1) / MER_PF_SEG;
+    const int64_t id = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t) na * nseg * nb) return;
+    const int64_t a = id % na, r = id / na; const int seg = (int) (r % nseg); const int64_t b = r / nseg;
+    const int64_t offset = a * stride_a + b * stride_b;
+    const float z1 = -2.0f + sqrtf(3.0f);
+    const int i0 = seg * MER_PF_SEG, i1 = min(i0 + MER_PF_SEG, size);
+    const int w1 = min(i1 + MER_PF_WARM, size);
+    float cn; int i;
+    if (w1 == size) {            // basisspline.h:850-853: exact end condition
+        cn = z1 / (z1 * z1 - 1) * (tmp[offset + (int64_t) (size - 1) * stride_line] + z1 * tmp[offset + (int64_t) (size - 2) * stride_line]);
+        if (i1 == size) out[offset + (int64_t) (size - 1) * stride_line] = 6 * cn;
+        i = size - 2;
+    } else { cn = 0.0f; i = w1 - 1; }
+    for (; i >= i1; i--) cn = z1 * (cn - tmp[offset + (int64_t) i * stride_line]);
+    for (; i >= i0; i--) { cn = z1 * (cn - tmp[offset + (int64_t) i * stride_line]); out[offset + (int64_t) i * stride_line] = 6 * cn; }
+}
+
+// The pass along x (lines contiguous in memory): a block stages 256 lines x (32 outputs + 40 warm-up samples on either side) in LDS
+// with row-contiguous (coalesced) loads, each thread filters one line of the tile causally and anti-causally in place (row pitch
+// 113 words: conflict-free), and the 32 outputs per line go back with coalesced stores -- one read and one write of the volume.
+#define MER_PFX_ROWS 256
+#define MER_PFX_COLS 32
+#define MER_PFX_W (MER_PFX_COLS + 2 * MER_PF_WARM)
+#define MER_PFX_LD (MER_PFX_W + 1)
+__global__ void __launch_bounds__(256) bspline_x_kernel(const float *src, float *out, int64_t nlines, int n) {
+    __shared__ float lds[MER_PFX_ROWS * MER_PFX_LD];
+    const int ntile = (n + MER_PFX_COLS - 1) / MER_PFX_COLS;
+    const int tile = (int) (blockIdx.x % (unsigned) ntile);              // neighbouring column tiles run together: the warm-up overlap is an L2 hit
+    const int64_t row0 = (int64_t) (blockIdx.x / (unsigned) ntile) * MER_PFX_ROWS;
+    const int c0 = tile * MER_PFX_COLS, c1 = min(c0 + MER_PFX_COLS, n);
+    const int lo = max(c0 - MER_PF_WARM, 0), hi = min(c1 + MER_PF_WARM, n), w = hi - lo;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < MER_PFX_ROWS; r += 4) {
+        const int64_t row = row0 + r;
+        if (row < nlines) for (int i = lane; i < w; i += 64) lds[r * MER_PFX_LD + i] = src[row * n + lo + i];
+    }
+    __syncthreads();
+    const float z1 = -2.0f + sqrtf(3.0f);
+    if (row0 + threadIdx.x < nlines) {
+        float *L = lds + threadIdx.x * MER_PFX_LD;
+        float c = (lo == 0) ? bspline_cp0(L, 0, 1, n, z1) : L[0];
+        L[0] = c;
+        for (int i = 1; i < w; i++) { c = L[i] + z1 * c; L[i] = c; }
+        float cn; int i;
+        if (hi == n) { cn = z1 / (z1 * z1 - 1) * (L[w - 1] + z1 * L[w - 2]); if (c1 == n) L[w - 1] = 6 * cn; i = w - 2; }
+        else { cn = 0.0f; i = w - 1; }
+        for (; i >= c1 - lo; i--) cn = z1 * (cn - L[i]);
+        for (; i >= c0 - lo; i--) { cn = z1 * (cn - L[i]); L[i] = 6 * cn; }
+    }
+    __syncthreads();
+    for (int r = wave; r < MER_PFX_ROWS; r += 4) {
+        const int64_t row = row0 + r;
+        if (row < nlines) for (int i = lane; i < c1 - c0; i += 64) out[row * n + c0 + i] = lds[r * MER_PFX_LD + (c0 - lo) + i];
+    }
+}
+
+// x pass, register form (n % 4 == 0): thread <-> (segment of 32 outputs, line); the 112-sample window (40 + 32 + 40) is fetched with
+// 28 independent 16-byte loads -- adjacent lanes own adjacent 128-byte segments of one line, so a wave reads one contiguous 8 KB
+// span (plus halo) and every line it touches is shared through L1 -- filtered in registers, and written with 8 16-byte stores.
+__global__ void __launch_bounds__(256) bspline_x_reg_kernel(const float *src, float *out, int64_t nlines, int n) {
+    const int nseg = (n + MER_PF_SEG - 1) / MER_PF_SEG;
+    const int64_t id = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nlines * nseg) return;
+    const int seg = (int) (id % nseg); const int64_t row = id / nseg;
+    const float *S = src + row * n; float *O = out + row * n;
+    const int c0 = seg * MER_PF_SEG, g0 = c0 - MER_PF_WARM;
+    const float z1 = -2.0f + sqrtf(3.0f);
+    float v[MER_PFX_W];
+#pragma unroll
+    for (int q = 0; q < MER_PFX_W / 4; q++) {
+        const int g = g0 + 4 * q;
+        float4 t = make_float4(0, 0, 0, 0);
+        if (g >= 0 && g < n) t = *(const float4 *) (S + g);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    float c = 0.0f;
+    if (g0 <= 0) c = bspline_cp0(S, 0, 1, n, z1);                  // the window reaches the line start: exact mirror-sum initialisation
+#pragma unroll
+    for (int j = 0; j < MER_PFX_W; j++) {
+        const int g = g0 + j;
+        if (g == 0 || (g0 > 0 && j == 0)) { if (g0 > 0) c = v[0]; }     // start: cp0 at the line start, the first sample otherwise
+        else if (g > 0 && g < n) c = v[j] + z1 * c;
+        v[j] = c;
+    }
+    float cn = 0.0f;
+#pragma unroll
+    for (int j = MER_PFX_W - 1; j >= MER_PF_WARM; j--) {
+        const int g = g0 + j;
+        if (g == n - 1) { cn = z1 / (z1 * z1 - 1) * (v[j] + z1 * v[j - 1]); v[j] = 6 * cn; }    // basisspline.h:850-853 (v[j-1]: n >= 16)
+        else if (g < n - 1) { cn = z1 * (cn - v[j]); v[j] = 6 * cn; }
+    }
+#pragma unroll
+    for (int q = 0; q < MER_PF_SEG / 4; q++) {
+        const int g = c0 + 4 * q;
+        if (g < n) *(float4 *) (O + g) = make_float4(v[MER_PF_WARM + 4 * q], v[MER_PF_WARM + 4 * q + 1], v[MER_PF_WARM + 4 * q + 2], v[MER_PF_WARM + 4 * q + 3]);
+    }
+}
+
+// y / z passes, register-window form: thread <-> (a = x index, segment, b); the 112-sample window is strided by the line pitch, every
+// load and store is coalesced across the wave (adjacent lanes = adjacent x); causal and anti-causal sweeps fused: one read, one write.
+__global__ void __launch_bounds__(256) bspline_win_kernel(const float *src, float *out, int na, int nb, int64_t stride_b, int64_t stride_line, int n) {
+    const int nseg = (n + MER_PF_SEG - 1) / MER_PF_SEG;
+    const int64_t id = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (int64_t) na * nseg * nb) return;
+    const int64_t a = id % na, r = id / na; const int seg = (int) (r % nseg); const int64_t b = r / nseg;
+    const float *S = src + a + b * stride_b; float *O = out + a + b * stride_b;
+    const int c0 = seg * MER_PF_SEG, g0 = c0 - MER_PF_WARM;
+    const float z1 = -2.0f + sqrtf(3.0f);
+    float v[MER_PFX_W];
+#pragma unroll
+    for (int j = 0; j < MER_PFX_W; j++) { const int g = g0 + j; v[j] = (g >= 0 && g < n) ? S[(int64_t) g * stride_line] : 0.0f; }
+    float c = 0.0f;
+    if (g0 <= 0) c = bspline_cp0(S, 0, stride_line, n, z1);
+#pragma unroll
+    for (int j = 0; j < MER_PFX_W; j++) {
+        const int g = g0 + j;
+        if (g == 0 || (g0 > 0 && j == 0)) { if (g0 > 0) c = v[0]; }
+        else if (g > 0 && g < n) c = v[j] + z1 * c;
+        v[j] = c;
+    }
+    float cn = 0.0f;
+#pragma unroll
+    for (int j = MER_PFX_W - 1; j >= MER_PF_WARM; j--) {
+        const int g = g0 + j;
+        if (g == n - 1) { cn = z1 / (z1 * z1 - 1) * (v[j] + z1 * v[j - 1]); v[j] = 6 * cn; }
+        else if (g < n - 1) { cn = z1 * (cn - v[j]); v[j] = 6 * cn; }
+    }
+#pragma unroll
+    for (int j = 0; j < MER_PF_SEG; j++) { const int g = c0 + j; if (g < n) O[(int64_t) g * stride_line] = v[MER_PF_WARM + j]; }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Synthetic fields of BASELINE.json's configs, generated in HBM
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {

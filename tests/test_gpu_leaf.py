@@ -60,6 +60,19 @@ def test_trilinear_value_grad_bit_exact(ctx, orc, layout):
     assert np.array_equal(g.view(np.uint32), go.view(np.uint32))
 
 
+@pytest.mark.parametrize("shape", [(40, 33, 70), (16, 130, 17), (97, 16, 64), (20, 18, 16), (18, 24, 128), (17, 19, 36)])
+def test_bspline_parallel_prefilter_matches_sequential_and_oracle(ctx, orc, shape, monkeypatch):
+    """K_prefilter's segmented form (warm-up 40, segments of 32) against the one-thread-per-line form and the oracle's build3d
+    (include/mitsuba/core/basisspline.h:812-890): lines shorter than, equal to and longer than a segment + warm-up, ragged tails."""
+    rng = np.random.RandomState(7)
+    data = (1.3 + 0.3 * rng.rand(*shape)).astype(np.float32)
+    par = ctx.upload_volume(data, [-1] * 3, [1] * 3).build_spline().download_spline()
+    monkeypatch.setenv("MER_PREFILTER_SEQ", "1")
+    seq = ctx.upload_volume(data, [-1] * 3, [1] * 3).build_spline().download_spline()
+    assert np.abs(par - seq).max() < 2e-6               # same recursion per sample; only the truncated warm-up differs
+    assert np.abs(par - orc.bspline_build(data)).max() < 5e-6
+
+
 def test_bspline_prefilter_and_eval(ctx, orc):
     rng = np.random.RandomState(3)
     shape = (17, 20, 33)
