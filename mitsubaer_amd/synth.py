@@ -51,3 +51,25 @@ def radial_rif(N, aabb_min=(-1, -1, -1), aabb_max=(1, 1, 1), shape=None):
     for k in range(nz):
         out[k] = (2.0 - (xy + z[k] ** 2) / (R * R)).astype(np.float32)
     return out
+
+
+def rif_from_sdf(sdf, nmin=1.10, nmax=1.50, r=1.0, flip=False):
+    """mfiles/createRIFFromSD.m:12-38: d = max(+-sdf, 0) (depth below the surface; `flip` for grids that store the
+    inside as negative), h = max(d), n = nmin + (nmax - nmin) / h^r * d^r -- the index rises from nmin at the surface to nmax at
+    the deepest voxel; r = 1 is linear, the script writes r in (1, 1.5, 2, 3, 10)."""
+    d = np.asarray(sdf, np.float64)
+    if flip:
+        d = -d
+    d = np.maximum(d, 0.0)
+    h = d.max()
+    if not h > 0:
+        raise ValueError("the signed distance grid has no interior (max depth is 0)")
+    k = (nmax - nmin) / h ** r
+    return (nmin + k * d ** r).astype(np.float32)
+
+
+def sphere_sdf(N, radius=0.75, aabb_min=(-1, -1, -1), aabb_max=(1, 1, 1)):
+    """signed distance to a centred sphere sampled on an N^3 grid, positive inside (the convention createRIFFromSD.m ends up with)"""
+    ax = [np.linspace(aabb_min[i], aabb_max[i], N) for i in range(3)]
+    z, y, x = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+    return (radius - np.sqrt(x * x + y * y + z * z)).astype(np.float32)

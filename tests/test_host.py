@@ -87,3 +87,22 @@ def test_shard_arithmetic_partitions_the_job(world):
     assert sorted(tiles) == list(range(100))
     with pytest.raises(ValueError):
         mdist.shard_args(mdist.SHARD_SAMPLES, world, world, spp)
+
+
+def test_rif_from_sdf_follows_the_reference_recipe():
+    """mfiles/createRIFFromSD.m: n = nmin at and outside the surface, nmax at the deepest voxel, power law in between"""
+    from mitsubaer_amd import synth
+    sdf = synth.sphere_sdf(33, radius=0.75)
+    for r in (1.0, 2.0, 10.0):
+        n = synth.rif_from_sdf(sdf, nmin=1.10, nmax=1.50, r=r)
+        assert n.dtype == np.float32 and n.shape == sdf.shape
+        assert abs(n.max() - 1.50) < 1e-6 and abs(n.min() - 1.10) < 1e-6
+        assert np.all(n[sdf <= 0] == np.float32(1.10))
+        mid = sdf == sdf.max()
+        assert np.allclose(n[mid], 1.50)
+        d = np.maximum(sdf.astype(np.float64), 0); h = d.max()
+        np.testing.assert_allclose(n, 1.10 + 0.40 * (d / h) ** r, atol=2e-7)
+    flipped = synth.rif_from_sdf(-sdf, flip=True)
+    np.testing.assert_array_equal(flipped, synth.rif_from_sdf(sdf))
+    with pytest.raises(ValueError):
+        synth.rif_from_sdf(-np.abs(sdf))
