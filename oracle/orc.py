@@ -68,9 +68,11 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libmer_oracle.so")
-        if not os.path.exists(so):
-            build()
+        so = os.environ.get("ORC_LIB")                  # e.g. a sanitizer build of the oracle (CPU only)
+        if not so:
+            so = os.path.join(_HERE, "libmer_oracle.so")
+            if not os.path.exists(so):
+                build()
         _LIB = C.CDLL(so)
         _LIB.orc_last_error.restype = C.c_char_p
         _LIB.orc_render.restype = C.c_int
