@@ -575,7 +575,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     if (need_slots < nslots) nslots = (uint32_t) need_slots;
     P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.eq = ctx->eq; P.mq[0] = ctx->mq[0]; P.mq[1] = ctx->mq[1]; P.sq[0] = ctx->sq[0]; P.sq[1] = ctx->sq[1]; P.cq = ctx->cq;
     P.hitq = ctx->hitq; P.hitq_cap = ctx->hitq_cap; P.hitq_ctr = ctx->hitq_ctr; P.gen_iters = 8; P.gen_all = getenv("MER_GEN_ALL") ? 1 : 0;
-    P.ksteps = 64;
+    P.ksteps = 96;            // eikonal steps per lane per pass (48..128 measured; 96: fewest K_event passes without stretching K_march tails)
     { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) P.ksteps = atoi(e); }
     HIP_CHECK(ctx, hipMemsetAsync(ctx->slots, 0, (size_t) nslots * MER_SLOT_WORDS * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));

@@ -241,8 +241,13 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
 // src/libbidir/edge.cpp:45-60,91-93 and src/libbidir/vertex.cpp:251-255, plus pixel regeneration
 // (src/librender/integrator.cpp:162-187) and ImageBlock::put (include/mitsuba/render/imageblock.h:124-205).
 // EXTRA: the scene has a point emitter and / or a modulated film (the plain kernel carries neither)
+#ifdef MER_EVENT_WAVES
+#define MER_EVENT_BOUNDS __launch_bounds__(MER_BLOCK, MER_EVENT_WAVES)
+#else
+#define MER_EVENT_BOUNDS __launch_bounds__(MER_BLOCK)
+#endif
 template <bool CURVED, int RIF, int STEPPER, int SIGMA, bool EXTRA>
-__global__ void __launch_bounds__(MER_BLOCK) event_kernel(const Params P, uint32_t pass) {
+__global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
     typedef Walk<CURVED, RIF, STEPPER, SIGMA> WalkT;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
