@@ -350,7 +350,8 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
             const float tv = result / (float) nwalks; tr = f3(tv, tv, tv);
         }
         if (is_zero(tr)) return f3(0, 0, 0);
-        const float invDist = 1.0f / dist;
+        const f3 dv = pp - ps;                                         // straight-line distance, as PointEmitter::sampleDirect
+        const float invDist = 1.0f / sqrtf(dot(dv, dv));
         const f3 value = I * (invDist * invDist) * tr * w;
         return value * phase_eval(S.phase, S.g, wi, normalize(dir));
     }

@@ -1405,7 +1405,10 @@ struct Walker {
                             if (ok) { w = ww; dist = di; optD = od; dir = d2; tr = connectionTransmittance<float>(mRec.p, d2, di); }
                         }
                         if (ok && !tr.isZero()) {
-                            const Float invDist = 1.0f / dist;
+                            /* PointEmitter::sampleDirect (src/emitters/point.cpp): I / |p - ref|^2 with the straight-line distance -- the
+                               reference keeps it for curved connections (bdpt_proc.cpp sampleDirect + pathConnectAndCollapse) */
+                            const Vec dv = pointP - mRec.p;
+                            const Float invDist = 1.0f / std::sqrt(dot(dv, dv));
                             Spec value = pointI * (invDist * invDist) * tr * w;
                             Li += throughput * value * phaseEval(P.phase, P.g, wi, normalize(dir));
                             contribute(throughput * value * phaseEval(P.phase, P.g, wi, normalize(dir)), plen + optD);

@@ -101,7 +101,7 @@ def test_modulated_paths_match_oracle(ctx, orc, name, m):
     for s in (0, 1):
         a = ctx.render_paths(sc, s, seed=8); b = orc.render_paths(p, s, 8)
         close = np.abs(a - b).max(2) <= 1e-4 * np.maximum(1.0, np.abs(b).max(2))
-        assert close.mean() > (0.95 if name.startswith("curved_point") else 0.99), close.mean()
+        assert close.mean() > (0.92 if name.startswith("curved_point") else 0.99), close.mean()
     film = ctx.render_to_host(sc, 0, 4, seed=8); ref, _ = orc.render(p, 0, 4, 8)
     np.testing.assert_allclose(film[..., 3:], ref[..., 3:], rtol=1e-5, atol=1e-5)
     if not name.startswith("curved_point"):
