@@ -30,7 +30,7 @@ enum { MER_VOL_F32 = 1, MER_VOL_U8 = 3 };
 enum { MER_SIGMA_HOMOGENEOUS = 0, MER_SIGMA_GRID = 1 };       /* medium `homogeneous` | `heterogeneous` */
 enum { MER_RIF_CONST = 0, MER_RIF_TRILINEAR = 1, MER_RIF_BSPLINE3 = 2 };  /* none | gridvolume | splinevolume */
 enum { MER_STEP_VERLET = 0, MER_STEP_RK4 = 1 };
-enum { MER_BOUNDARY_AABB = 0, MER_BOUNDARY_SPHERE = 1 };
+enum { MER_BOUNDARY_AABB = 0, MER_BOUNDARY_SPHERE = 1, MER_BOUNDARY_SDF = 2 };
 enum { MER_PHASE_ISOTROPIC = 0, MER_PHASE_HG = 1 };
 enum { MER_TR_WOODCOCK2 = 0, MER_TR_RATIO = 1 };
 enum { MER_STRATEGY_BALANCE = 0, MER_STRATEGY_SINGLE = 1, MER_STRATEGY_MANUAL = 2 };
@@ -92,6 +92,11 @@ typedef struct {
     /* BSDF of the medium's boundary shape: MER_BSDF_NULL (index-matched, src/librender/shape.cpp:48-70) or MER_BSDF_HDIELECTRIC
        (src/bsdfs/hdielectric.cpp: smooth dielectric whose eta is the RIF at the hit point, exterior index 1) */
     int32_t boundary_bsdf;
+    /* boundary = MER_BOUNDARY_SDF: the medium shape is the negative region of this signed-distance grid (1-channel float32 volume,
+       trilinear; the reference's `sdf` child of heterogeneousrefractive, src/medium/heterogeneousrefractive.cpp:366-375, negative
+       inside :481).  Camera rays find it by sphere tracing, the dielectric normal is the normalized gradient (:980-984).
+       mer_render only; the leaf entry points know the cube / sphere boundaries. */
+    mer_volume sdf;
 } mer_scene_desc;
 enum { MER_BSDF_NULL = 0, MER_BSDF_HDIELECTRIC = 1 };
 enum { MER_MODULATION_NONE = 0, MER_MODULATION_SINE, MER_MODULATION_SQUARE, MER_MODULATION_HAMILTONIAN, MER_MODULATION_MSEQ,

@@ -55,6 +55,7 @@ class SceneDesc(C.Structure):
         ("calibrated_transient", C.c_int32),
         ("modulation", C.c_int32), ("mod_lambda", C.c_float), ("mod_phase_deg", C.c_float), ("mod_P", C.c_int32), ("mod_neighbors", C.c_int32),
         ("boundary_bsdf", C.c_int32),
+        ("sdf", C.c_int32),
     ]
 
 
@@ -179,7 +180,7 @@ class Context:
         return v
 
     # ---- scene ---------------------------------------------------------------------------------
-    def scene_desc(self, p, density=None, albedo_grid=None, rif=None):
+    def scene_desc(self, p, density=None, albedo_grid=None, rif=None, sdf=None):
         """p: params.SceneParams; volumes as Volume objects."""
         s = SceneDesc()
         s.width, s.height = p.width, p.height
@@ -211,6 +212,7 @@ class Context:
         s.calibrated_transient = int(p.calibrated_transient)
         s.modulation = p.modulation; s.mod_lambda = p.mod_lambda; s.mod_phase_deg = p.mod_phase_deg; s.mod_P = p.mod_P; s.mod_neighbors = p.mod_neighbors
         s.boundary_bsdf = p.boundary_bsdf
+        s.sdf = sdf.handle if sdf is not None else 0
         return s
 
     def upload_scene(self, p, layout=LAYOUT_DENSE, rif_layout=None):
@@ -229,7 +231,11 @@ class Context:
             if p.rif_mode == P.RIF_BSPLINE3:
                 rif.build_spline()
             vols.append(rif)
-        return self.scene_desc(p, dens, alb, rif), vols
+        sdf = None
+        if p.boundary == P.BOUNDARY_SDF and p.sdf is not None:
+            sdf = self.upload_volume(p.sdf, p.sdf_aabb[0], p.sdf_aabb[1], LAYOUT_DENSE)
+            vols.append(sdf)
+        return self.scene_desc(p, dens, alb, rif, sdf), vols
 
     # ---- film + render -------------------------------------------------------------------------
     def film_channels(self, scene):

@@ -122,7 +122,7 @@ static int film_frames(mer_context *ctx, const mer_scene_desc *sc, int &frames) 
     frames = (int) f;
     return 0;
 }
-static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P) {
+static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bool allow_sdf = false) {
     std::memset(&P, 0, sizeof(P));
     P.sc = *sc;
     if (sc->width <= 0 || sc->height <= 0) return fail(ctx, "film: width/height must be positive");
@@ -207,6 +207,14 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P) {
         for (int i = 0; i < 3; i++) if (!(sc->bmin[i] < sc->bmax[i])) return fail(ctx, "medium shape: empty bounding box");
     } else if (sc->boundary == MER_BOUNDARY_SPHERE) {
         if (!(sc->sph_radius > 0)) return fail(ctx, "medium shape: sphere radius must be positive");
+    } else if (sc->boundary == MER_BOUNDARY_SDF) {
+        if (!allow_sdf) return fail(ctx, "the signed-distance boundary is known to mer_render only (leaf entry points: cube / sphere)");
+        auto it = ctx->volumes.find(sc->sdf);
+        if (it == ctx->volumes.end()) return fail(ctx, "heterogeneousrefractive: no sdf volume (boundary = sdf)");
+        if (it->second.desc.channels != 1 || it->second.desc.dtype != MER_VOL_F32) return fail(ctx, "heterogeneousrefractive: the sdf must be a 1-channel float32 grid");
+        fill_dgrid(it->second, P.sdf);
+        float d2 = 0; for (int i = 0; i < 3; i++) d2 += (P.sdf.bmax[i] - P.sdf.bmin[i]) * (P.sdf.bmax[i] - P.sdf.bmin[i]);
+        P.sdf_eps = 1e-4f * std::sqrt(d2);
     } else return fail(ctx, "unknown medium boundary");
     {
         const bool has_point = sc->point_intensity[0] != 0 || sc->point_intensity[1] != 0 || sc->point_intensity[2] != 0;
@@ -215,6 +223,7 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P) {
             // curved-ray connections are solved for end points inside the medium shape only (boundary refraction = next row N2)
             bool inside = true;
             if (sc->boundary == MER_BOUNDARY_AABB) { for (int i = 0; i < 3; i++) inside = inside && sc->point_position[i] > sc->bmin[i] && sc->point_position[i] < sc->bmax[i]; }
+            else if (sc->boundary == MER_BOUNDARY_SDF) inside = true;            // not checked on the host: a connection that leaves the shape is rejected per sample
             else { float d2 = 0; for (int i = 0; i < 3; i++) d2 += (sc->point_position[i] - sc->sph_center[i]) * (sc->point_position[i] - sc->sph_center[i]); inside = d2 < sc->sph_radius * sc->sph_radius; }
             if (!inside) return fail(ctx, "heterogeneousrefractive: a point emitter must lie inside the medium shape (boundary refraction of connections is not built yet)");
         }
@@ -229,9 +238,9 @@ template <typename F> static int dispatch_modes(mer_context *ctx, const mer_scen
     const bool grid = sc->sigma_mode == MER_SIGMA_GRID;
     if (!curved) {
         if (grid) return f(std::integral_constant<bool, false>(), std::integral_constant<int, MER_RIF_TRILINEAR>(),
-                           std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_GRID>());
+                           std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_GRID>(), std::integral_constant<int, 0>());
         return f(std::integral_constant<bool, false>(), std::integral_constant<int, MER_RIF_TRILINEAR>(),
-                 std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_HOMOGENEOUS>());
+                 std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_HOMOGENEOUS>(), std::integral_constant<int, 0>());
     }
     // internal fetch kind of the trilinear RIF (mer_device.hpp): layout x {global, buffer} loads
     int rifk = sc->rif_mode;
@@ -244,7 +253,7 @@ template <typename F> static int dispatch_modes(mer_context *ctx, const mer_scen
 #define MER_CASE(R, S, G)                                                                                         \
     if (rifk == R && sc->stepper == S && (int) grid == G)                                                         \
         return f(std::integral_constant<bool, true>(), std::integral_constant<int, R>(), std::integral_constant<int, S>(), \
-                 std::integral_constant<int, G>());
+                 std::integral_constant<int, G>(), std::integral_constant<int, 0>());
     MER_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET, 1) MER_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4, 1)
     MER_CASE(RIFK_DENSE_BUF, MER_STEP_VERLET, 1) MER_CASE(RIFK_DENSE_BUF, MER_STEP_RK4, 1)
     MER_CASE(RIFK_CELL8, MER_STEP_VERLET, 1) MER_CASE(RIFK_CELL8, MER_STEP_RK4, 1)
@@ -257,6 +266,37 @@ template <typename F> static int dispatch_modes(mer_context *ctx, const mer_scen
     MER_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET, 0) MER_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4, 0)
 #undef MER_CASE
     return fail(ctx, "unsupported rif_mode / stepper combination");
+}
+// boundary = MER_BOUNDARY_SDF: a reduced set of kernels (straight rays; dense-global / cell8-buffer trilinear and B-spline RIFs)
+template <typename F> static int dispatch_modes_sdf(mer_context *ctx, const mer_scene_desc *sc, F &&f) {
+    const bool curved = sc->rif_mode != MER_RIF_CONST;
+    const bool grid = sc->sigma_mode == MER_SIGMA_GRID;
+    typedef std::integral_constant<int, 1> B1;
+    if (!curved) {
+        if (grid) return f(std::integral_constant<bool, false>(), std::integral_constant<int, MER_RIF_TRILINEAR>(),
+                           std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_GRID>(), B1());
+        return f(std::integral_constant<bool, false>(), std::integral_constant<int, MER_RIF_TRILINEAR>(),
+                 std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_HOMOGENEOUS>(), B1());
+    }
+    int rifk = sc->rif_mode;
+    if (sc->rif_mode == MER_RIF_TRILINEAR) {
+        const Volume &rv = ctx->volumes.find(sc->rif)->second;
+        DGrid tmp; fill_dgrid(rv, tmp);
+        if (tmp.layout == MER_LAYOUT_CELL8) rifk = tmp.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
+        else rifk = MER_RIF_TRILINEAR;                        // dense: global loads
+    }
+#define MER_CASE(R, S, G)                                                                                         \
+    if (rifk == R && sc->stepper == S && (int) grid == G)                                                         \
+        return f(std::integral_constant<bool, true>(), std::integral_constant<int, R>(), std::integral_constant<int, S>(), \
+                 std::integral_constant<int, G>(), B1());
+    MER_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET, 1) MER_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4, 1)
+    MER_CASE(RIFK_CELL8_BUF, MER_STEP_VERLET, 1) MER_CASE(RIFK_CELL8_BUF, MER_STEP_RK4, 1)
+    MER_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET, 1) MER_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4, 1)
+    MER_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET, 0) MER_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4, 0)
+    MER_CASE(RIFK_CELL8_BUF, MER_STEP_VERLET, 0) MER_CASE(RIFK_CELL8_BUF, MER_STEP_RK4, 0)
+    MER_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET, 0) MER_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4, 0)
+#undef MER_CASE
+    return fail(ctx, "signed-distance boundary: the RIF must be dense, cell8 below 4 GiB, or a B-spline volume");
 }
 
 // staging helpers for the leaf entry points -------------------------------------------------------------
@@ -507,7 +547,7 @@ int mer_device_free(mer_context *ctx, void *p) { HIP_CHECK(ctx, hipFree(p)); ret
 static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed,
                          float *film_dev, float *path_out_dev) {
     Params P;
-    if (make_params(ctx, scene, P)) return 1;
+    if (make_params(ctx, scene, P, true)) return 1;
     if (!shard || shard->spp_count < 0 || shard->spp_stride <= 0 || shard->tile_count <= 0 || shard->tile_rank < 0 ||
         shard->tile_rank >= shard->tile_count || shard->spp_begin < 0)
         return fail(ctx, "invalid shard");
@@ -527,9 +567,10 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     if (mode && std::strcmp(mode, "mega") == 0) {
         if (scene->decomposition != MER_DECOMPOSITION_NONE) return fail(ctx, "MER_MODE=mega renders steady-state films only; use the default wavefront mode");
         if (scene->boundary_bsdf != MER_BSDF_NULL) return fail(ctx, "MER_MODE=mega knows the index-matched boundary only; use the default wavefront mode");
+        if (scene->boundary == MER_BOUNDARY_SDF) return fail(ctx, "MER_MODE=mega knows the cube / sphere boundaries only; use the default wavefront mode");
         if (scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0)
             return fail(ctx, "MER_MODE=mega does not sample point emitters; use the default wavefront mode");
-        return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
+        return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma, auto bnd) -> int {
             auto kern = render_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
             int per_cu = 0;
             HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, MER_BLOCK, 0));
@@ -582,15 +623,17 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1], &ctx->cq})
         HIP_CHECK(ctx, hipMemsetAsync(q->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->hitq_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
-    return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
+    auto body = [&](auto curved, auto rif, auto stepper, auto sigma, auto bnd) -> int {
+        constexpr int BND = decltype(bnd)::value;
         const bool has_point = scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0;
-        const bool extra = has_point || scene->modulation != MER_MODULATION_NONE || scene->boundary_bsdf != MER_BSDF_NULL;
-        auto kev = extra ? event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, true>
-                         : event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, false>;
-        auto kma = march_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
-        auto kco = connect_stage_kernel<decltype(curved)::value ? decltype(rif)::value : MER_RIF_TRILINEAR, decltype(stepper)::value, decltype(sigma)::value>;
+        // the signed-distance boundary exists in the EXTRA kernels only
+        const bool extra = BND != 0 || has_point || scene->modulation != MER_MODULATION_NONE || scene->boundary_bsdf != MER_BSDF_NULL;
+        auto kev = (extra || BND != 0) ? event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, true, BND>
+                                       : event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, BND != 0, BND>;
+        auto kma = march_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, BND>;
+        auto kco = connect_stage_kernel<decltype(curved)::value ? decltype(rif)::value : MER_RIF_TRILINEAR, decltype(stepper)::value, decltype(sigma)::value, BND>;
         const bool connect_stage = has_point && decltype(curved)::value;
-        auto kge = extra ? gen_kernel<decltype(curved)::value, true> : gen_kernel<decltype(curved)::value, false>;
+        auto kge = (extra || BND != 0) ? gen_kernel<decltype(curved)::value, true, BND> : gen_kernel<decltype(curved)::value, BND != 0, BND>;
         const unsigned gen_blocks = std::max(1u, std::min(nslots / MER_BLOCK, 1024u));      // 4096 waves x 512 ids per launch
         bool work_left = true;
         const unsigned blocks = nslots / MER_BLOCK;
@@ -639,7 +682,8 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         }
         if (getenv("MER_VERBOSE")) { float ms = 0; (void) hipEventSynchronize(ctx->ev1); (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); fprintf(stderr, "[mer] wavefront: %u passes, K=%d, nslots=%u, %.3f ms\n", pass, P.ksteps, nslots, ms); }
         return 0;
-    });
+    };
+    return scene->boundary == MER_BOUNDARY_SDF ? dispatch_modes_sdf(ctx, scene, body) : dispatch_modes(ctx, scene, body);
 }
 
 int mer_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed, float *film_dev) {
@@ -787,7 +831,7 @@ int mer_sample_distance(mer_context *ctx, const mer_scene_desc *scene, const flo
     P.seed = seed;
     DevBuf a(ctx), b(ctx), c(ctx), r(ctx);
     if (a.upload(o, n * 12) || b.upload(d, n * 12) || c.upload(maxt, n * 4) || r.alloc(n * 80)) return 1;
-    int rc = dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
+    int rc = dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma, auto bnd) -> int {
         hipLaunchKernelGGL((sample_distance_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>),
                            dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), c.as<float>(), n, r.as<float>());
         HIP_CHECK(ctx, hipGetLastError());
@@ -804,7 +848,7 @@ int mer_eval_transmittance(mer_context *ctx, const mer_scene_desc *scene, const 
     P.seed = seed;
     DevBuf a(ctx), b(ctx), c(ctx), r(ctx);
     if (a.upload(o, n * 12) || b.upload(d, n * 12) || c.upload(maxt, n * 4) || r.alloc(n * 12)) return 1;
-    int rc = dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma) -> int {
+    int rc = dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma, auto bnd) -> int {
         hipLaunchKernelGGL((eval_transmittance_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>),
                            dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), c.as<float>(), n, r.as<float>());
         HIP_CHECK(ctx, hipGetLastError());

@@ -103,7 +103,7 @@ __device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, CellCache &c
     }
 }
 
-template <int RIF> struct Connector {
+template <int RIF, int BND = 0> struct Connector {
     const Params &P;
     float tol, rrweight; int precision, maxIter, maxSteps;
     mutable CellCache cc;                       // the 8 corners of the cell the ray is in (trilinear RIF): reused across evaluations
@@ -161,7 +161,7 @@ template <int RIF> struct Connector {
                 }
                 found = true;
                 break;
-            } else if (!inside_shape(P.sc, p)) return false;
+            } else if (!inside_shape_b<BND>(P, p)) return false;
         }
         if (!found) return false;
         float rr; f3 dvdt;
@@ -222,7 +222,7 @@ template <int RIF> struct Connector {
             oldp = p; oldv = v;
             verlet(p, v, h);
             signNew = dot(p - p2, v) < 0.0f;
-            if (!inside_shape(P.sc, p)) return false;
+            if (!inside_shape_b<BND>(P, p)) return false;
             if (signNew != signOld) {
                 while (nBisect > 0) {
                     nBisect--;
@@ -275,7 +275,7 @@ template <int RIF> struct Connector {
 // pdf 1, EDiscrete => no MIS partner) + Scene::evalTransmittance (straight rays, src/librender/scene.cpp:619-678) or
 // Medium::eval through the RIF (curved rays, heterogeneousrefractive.cpp:571-640).  Returns value * phase (to be
 // multiplied by the path throughput).  Synchronous: it runs inside K_event.
-template <bool CURVED, int RIF, int STEPPER, int SIGMA>
+template <bool CURVED, int RIF, int STEPPER, int SIGMA, int BND = 0>
 __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi, int depth, float &optLen) {
     optLen = 0.0f;
     const mer_scene_desc &S = P.sc;
@@ -290,7 +290,7 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
         dvec = dvec * invDist;
         f3 value = I * (invDist * invDist);
         optLen = dist * S.rif_const;
-        const float tExit = intersect_shape(S, ps, dvec, 0.0f, MER_INF);
+        const float tExit = intersect_shape_b<BND>(P, ps, dvec, 0.0f, MER_INF);
         const bool crosses = tExit >= 0 && tExit < dist;
         const float L = crosses ? tExit : dist;
         f3 tr(1, 1, 1);
@@ -319,7 +319,7 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
         if (is_zero(value)) return f3(0, 0, 0);
         return value * phase_eval(S.phase, S.g, wi, dvec);
     } else {
-        Connector<RIF> K(P);
+        Connector<RIF, BND> K(P);
         float w = 1.0f, od = 0, dist = 0; f3 dir(0, 0, 1), rev(0, 0, 1);
         if (!K.connect(ps, pp, normalize(pp - ps), rng, w, dir, rev, od, dist)) return f3(0, 0, 0);
         optLen = od;
@@ -337,7 +337,7 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
                     for (int q = 0; q <= steps && inside; ++q) {
                         const float hq = q < steps ? h : rem;
                         er_step<RIF, STEPPER>(P.rif, cc, p, v, hq, opt); C.steps++;
-                        if (!inside_shape(S, p)) { er_step<RIF, STEPPER>(P.rif, cc, p, v, -hq, opt); C.steps++; inside = false; }
+                        if (!inside_shape_b<BND>(P, p)) { er_step<RIF, STEPPER>(P.rif, cc, p, v, -hq, opt); C.steps++; inside = false; }
                     }
                     if (!inside) break;
                     left -= s;

@@ -427,6 +427,7 @@ struct Params {
     uint32_t *slots; uint32_t nslots; int32_t ksteps;
     uint32_t *live;                     // live[0]: number of finished slots
     SegQueue eq, mq[2], sq[2];          // event queue, march lists (by pass parity), starved lists (by pass parity)
+    DGrid sdf; float sdf_eps;           // boundary = MER_BOUNDARY_SDF: signed-distance grid (negative inside), 1e-4 x its diagonal
     SegQueue cq;                        // connection requests of this pass (curved-ray point-emitter NEE, K_connect)
     unsigned long long *hitq; unsigned long long hitq_cap;     // ring of work ids that will march (power-of-two capacity)
     unsigned long long *hitq_ctr;       // [0] produced (tail), [1] consumed (head)
@@ -502,6 +503,47 @@ __device__ __forceinline__ f3 shape_normal(const mer_scene_desc &s, f3 x) {
     }
     return f3(axis == 0 ? sign : 0.0f, axis == 1 ? sign : 0.0f, axis == 2 ? sign : 0.0f);
 }
+// ---- boundary kind as a template switch (BND = 1: the negative region of a signed-distance grid, the reference's `sdf` child,
+// src/medium/heterogeneousrefractive.cpp:366-375,481).  Kept out of the BND = 0 kernels: the hot loop must not carry a second gather.
+__device__ __forceinline__ float sdf_value(const Params &P, f3 p) {        // lookupFloat is 0 outside the grid: far outside here
+    int idx4[4];
+    const float v = lookup_float(P.sdf, p, idx4);
+    return idx4[3] >= 0 ? v : 1e30f;
+}
+template <int BND> __device__ __forceinline__ bool inside_shape_b(const Params &P, f3 p) {
+    if (BND == 0) return inside_shape(P.sc, p);
+    return sdf_value(P, p) < 0.0f;
+}
+// sphere tracing on the grid; entry points come back with sdf < eps/2, exit points with sdf in [eps, ~2 eps); a start within 4 eps of the
+// surface is a start from the inside side and must get below 0 ("armed") before an exit counts
+template <int BND> __device__ __forceinline__ float intersect_shape_b(const Params &P, f3 o, f3 d, float mint, float maxt) {
+    if (BND == 0) return intersect_shape(P.sc, o, d, mint, maxt);
+    float nearT, farT;
+    if (!aabb_intersect(P.sdf.bmin, P.sdf.bmax, o, d, nearT, farT)) return -1.0f;
+    const float t0 = fmaxf(nearT, mint), t1 = fminf(farT, maxt), eps = P.sdf_eps;
+    if (!(t0 <= t1)) return -1.0f;
+    float t = t0, v = sdf_value(P, o + d * t);
+    const bool insideStart = v < 4 * eps;
+    bool armed = false;
+    for (int it = 0; it < 1024; ++it) {
+        if (insideStart) {
+            if (v < 0) armed = true;
+            else if (armed && v >= eps) return t;
+            else if (!armed && it >= 16) return t;
+        } else if (v < 0.5f * eps) return t;
+        t += v > 1e29f ? eps : fmaxf(fabsf(v), eps);
+        if (t > t1) return insideStart ? (farT <= maxt ? farT : -1.0f) : -1.0f;
+        v = sdf_value(P, o + d * t);
+    }
+    return -1.0f;
+}
+template <int BND> __device__ __forceinline__ f3 shape_normal_b(const Params &P, f3 x) {
+    if (BND == 0) return shape_normal(P.sc, x);
+    float v; f3 g; CellCache cc; cc.reset();
+    trilinear_value_grad<MER_RIF_TRILINEAR>(P.sdf, cc, x, v, g);           // normalized SDF gradient (heterogeneousrefractive.cpp:980-984)
+    return normalize(g);
+}
+
 // fresnelDielectricExt (src/libcore/util.cpp:665-695)
 __device__ __forceinline__ float fresnel_dielectric_ext(float cosThetaI_, float &cosThetaT_, float eta) {
     if (eta == 1.0f) { cosThetaT_ = -cosThetaI_; return 0.0f; }
@@ -515,13 +557,13 @@ __device__ __forceinline__ float fresnel_dielectric_ext(float cosThetaI_, float 
 }
 // HDielectric::sample (src/bsdfs/hdielectric.cpp:183-242, ERadiance) at the boundary point ro + rd*t of the medium shape; eta is the
 // RIF there (:115-118).  Returns true when the sampled direction wo stays in / enters the medium.
-template <bool CURVED, int RIF>
+template <bool CURVED, int RIF, int BND = 0>
 __device__ __forceinline__ bool dielectric_event(const Params &P, Rng &rng, f3 ro, f3 rd, float t, bool from_inside, f3 &T, float &etaPath,
                                                  f3 &x, f3 &wo) {
     const mer_scene_desc &S = P.sc;
     const float u1 = rng.next1D(); (void) rng.next1D();          // only sample.x is used (:196)
     x = ro + rd * t;
-    const f3 n = shape_normal(S, x);
+    const f3 n = shape_normal_b<BND>(P, x);
     const float cosI = dot(-rd, n);                              // Frame::cosTheta(wi), wi = -ray.d
     float etaB = S.rif_const;
     if (CURVED) {

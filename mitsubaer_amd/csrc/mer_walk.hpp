@@ -22,7 +22,7 @@ struct LaneCounters {
 };
 
 // State of the ray a lane is currently marching.
-template <bool CURVED, int RIF, int STEPPER, int SIGMA>
+template <bool CURVED, int RIF, int STEPPER, int SIGMA, int BND = 0>
 struct Walk {
     // ray: curved -> p = position, v = optical momentum n*d ; straight -> p = origin, v = direction
     f3 p, v;
@@ -130,7 +130,7 @@ struct Walk {
                 if (seg_inf) dist -= hprev;                                   // traceTillBoundary :757-759 (as shipped)
                 return EV_EXITED;
             }
-            if (!inside_shape(P.sc, p)) { backstep = 1; hprev = h; return EV_NONE; }   // (:678-681)
+            if (!inside_shape_b<BND>(P, p)) { backstep = 1; hprev = h; return EV_NONE; }   // (:678-681)
             dist += h;
             if (full) {
                 steps_left--;
@@ -205,8 +205,8 @@ struct MRec {
 };
 
 // Fill the record at the end of a free-flight walk (success = real collision).
-template <bool CURVED, int RIF, int STEPPER, int SIGMA>
-__device__ __forceinline__ void finish_free_flight(const Params &P, LaneCounters &C, Walk<CURVED, RIF, STEPPER, SIGMA> &W,
+template <bool CURVED, int RIF, int STEPPER, int SIGMA, int BND>
+__device__ __forceinline__ void finish_free_flight(const Params &P, LaneCounters &C, Walk<CURVED, RIF, STEPPER, SIGMA, BND> &W,
                                                    bool success, float sigma, MRec &m) {
     m.refRatioSq = 1.0f; m.opticalLength = W.opt;
     m.p = W.pos(); m.d = W.v; m.t = CURVED ? W.dist : W.t;

@@ -88,7 +88,7 @@ __device__ __forceinline__ void flush_counters(const Params &P, const LaneCounte
 // forbids entering it -- is retired here (environment radiance + film splat); a sample that will march is handed to
 // K_event as a work id through the hit ring.  Without this, K_event's regeneration is a per-lane loop with a geometric
 // trip count (80% of the bench scene's camera rays miss) that leaves most lanes of every wave idle.
-template <bool CURVED, bool EXTRA>
+template <bool CURVED, bool EXTRA, int BND = 0>
 __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
     const mer_scene_desc &S = P.sc;
     const f3 env(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
@@ -121,13 +121,13 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
                 sample_ray(P, px, py, o, d, mint, maxt);
                 f3 L(0, 0, 0);
                 float plen = 0.0f;                                   // transient film: optical path length so far
-                const float itsT = intersect_shape(S, o, d, mint, maxt);
+                const float itsT = intersect_shape_b<BND>(P, o, d, mint, maxt);
                 if (itsT < 0) { if (!S.hide_emitters) L = env; }
                 else if (1 >= maxDepth && maxDepth != -1) { }
                 else if (EXTRA && S.boundary_bsdf == MER_BSDF_HDIELECTRIC) hit = true;      // Fresnel sampling at the surface: K_event
                 else {
                     bool medium = true;
-                    if (!CURVED) { const f3 ro = o + d * itsT; medium = intersect_shape(S, ro, d, MER_EPSILON, MER_INF) >= 0; }
+                    if (!CURVED) { const f3 ro = o + d * itsT; medium = intersect_shape_b<BND>(P, ro, d, MER_EPSILON, MER_INF) >= 0; }
                     if (!(2 <= maxDepth || maxDepth < 0)) { }
                     else if (!medium) { if (!S.hide_emitters) L = env; if (!S.calibrated_transient) plen = itsT; }
                     else hit = true;
@@ -194,7 +194,7 @@ __device__ __forceinline__ void queue_clear_row(const SegQueue &q, uint32_t row,
 #ifndef MER_MARCH_WAVES
 #define MER_MARCH_WAVES 4
 #endif
-template <bool CURVED, int RIF, int STEPPER, int SIGMA>
+template <bool CURVED, int RIF, int STEPPER, int SIGMA, int BND = 0>
 __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const Params P, uint32_t pass) {
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
     if (j < count) {
         i = queue_item(P.mq[pass & 1u], pass, j);
         uint32_t fl;
-        Walk<CURVED, RIF, STEPPER, SIGMA> W;
+        Walk<CURVED, RIF, STEPPER, SIGMA, BND> W;
         Rng rng; uint32_t pixel, sample; float sigma;
         load_hot(P, i, fl, W, rng, pixel, sample, sigma);
         W.cc.reset(); W.n0 = 1.0f; W.tmin = 0.0f; W.trsum = 0.0f; W.sdens = 0.0f;
@@ -246,9 +246,9 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
 #else
 #define MER_EVENT_BOUNDS __launch_bounds__(MER_BLOCK)
 #endif
-template <bool CURVED, int RIF, int STEPPER, int SIGMA, bool EXTRA>
+template <bool CURVED, int RIF, int STEPPER, int SIGMA, bool EXTRA, int BND = 0>
 __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
-    typedef Walk<CURVED, RIF, STEPPER, SIGMA> WalkT;
+    typedef Walk<CURVED, RIF, STEPPER, SIGMA, BND> WalkT;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
     // pass 0: every slot is new; later passes: the compacted list of slots K_march parked on an event
@@ -333,7 +333,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             plen = 0.0f; trOpt = 0.0f; etaPath = 1.0f;
             C.paths++;
             ev = EV_NONE;
-            itsT = intersect_shape(S, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
+            itsT = intersect_shape_b<BND>(P, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
             if (itsT < 0) {
                 if (!S.hide_emitters) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }   // volpath.cpp:194-201
                 ev = EV_PATH_DONE;
@@ -342,13 +342,13 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
                 // hdielectric boundary (N2): reflect away (the ray escapes: environment, weight 1) or refract into the medium
                 if (!S.calibrated_transient) plen += itsT;
                 f3 x, wo;
-                if (!dielectric_event<CURVED, RIF>(P, rng, o, d, itsT, false, T, etaPath, x, wo)) {
+                if (!dielectric_event<CURVED, RIF, BND>(P, rng, o, d, itsT, false, T, etaPath, x, wo)) {
                     L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen);
                     ev = EV_PATH_DONE;
                 } else {
                     ps = x; dsave = wo;
                     if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
-                    else { itsT = intersect_shape(S, x, wo, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
+                    else { itsT = intersect_shape_b<BND>(P, x, wo, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
                     ev = (CURVED || itsValid) ? EV_AFTER_LOOKUP : EV_PATH_DONE;       // Russian roulette, scattered = true, next segment
                 }
             } else {
@@ -357,7 +357,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
                 const f3 ro = o + d * itsT;
                 bool medium = true;
                 if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
-                else { itsT = intersect_shape(S, ro, d, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); if (!itsValid) medium = false; }
+                else { itsT = intersect_shape_b<BND>(P, ro, d, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); if (!itsValid) medium = false; }
                 depth++;
                 if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
                 else if (!medium) { if (!S.hide_emitters) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); } ev = EV_PATH_DONE; }
@@ -415,7 +415,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
                 trOpt = 0.0f;
                 if (interactions != 0) {                                              // scene.cpp:619-678: one null crossing
                     float tExit = 0.0f;
-                    if (!CURVED) tExit = intersect_shape(S, ps, dd, 0.0f, MER_INF);
+                    if (!CURVED) tExit = intersect_shape_b<BND>(P, ps, dd, 0.0f, MER_INF);
                     if (tExit >= 0) {
                         itsT = tExit;
                         if (!CURVED) trOpt = tExit * S.rif_const;
@@ -459,7 +459,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             if (EXTRA && hasPoint && ev == EV_PHASE) {
                 if (CURVED) { connecting = true; break; }
                 float optLen = 0.0f;
-                const f3 c = T * point_nee<false, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth, optLen);
+                const f3 c = T * point_nee<false, RIF, STEPPER, SIGMA, BND>(P, rng, C, ps, wi, depth, optLen);
                 L = L + mod_weight<EXTRA>(P, c, plen + optLen);
                 film_contribute(P, px, py, c, plen + optLen);
             }
@@ -469,7 +469,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             phase_sample(S.phase, S.g, wi, p2x, p2y, wo, phasePdf);
             dsave = wo;
             if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
-            else { itsT = intersect_shape(S, ps, wo, 0.0f, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
+            else { itsT = intersect_shape_b<BND>(P, ps, wo, 0.0f, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
             if (hasEnv) {
                 W.kind = K_LOOKUP;
                 trOpt = (!CURVED && itsValid) ? itsT * S.rif_const : 0.0f;
@@ -504,14 +504,14 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             if (dielectric && itsValid && !(depth >= maxDepth && maxDepth != -1)) {
                 // hdielectric boundary from inside: total internal / Fresnel reflection keeps the path in the medium
                 f3 ro = ps, rd = dsave; float tHit = itsT;
-                if (CURVED) { ro = m.p; rd = normalize(m.d); tHit = intersect_shape(S, ro, rd, 0.0f, MER_INF); if (!(tHit >= 0)) tHit = 0.0f; }   // re-hit (edge.cpp:45-60)
+                if (CURVED) { ro = m.p; rd = normalize(m.d); tHit = intersect_shape_b<BND>(P, ro, rd, 0.0f, MER_INF); if (!(tHit >= 0)) tHit = 0.0f; }   // re-hit (edge.cpp:45-60)
                 f3 x, wo;
-                if (!dielectric_event<CURVED, RIF>(P, rng, ro, rd, tHit, true, T, etaPath, x, wo)) {
+                if (!dielectric_event<CURVED, RIF, BND>(P, rng, ro, rd, tHit, true, T, etaPath, x, wo)) {
                     L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen);
                 } else {
                     ps = x; dsave = wo;
                     if (CURVED) itsT = 0;
-                    else { itsT = intersect_shape(S, x, wo, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
+                    else { itsT = intersect_shape_b<BND>(P, x, wo, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
                     if (CURVED || itsValid) ev = EV_AFTER_LOOKUP;
                 }
             } else if (dielectric) {
@@ -570,7 +570,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
 // K_connect: curved-ray luminaire sampling of the point emitter for the slots K_event parked on a scattering event
 // (Medium::eval -> makeDirectConnections, src/medium/heterogeneousrefractive.cpp:571-640,1087-1163).  One lane per
 // connection; the sampler stream continues where K_event left it, so the draw order is the oracle's.
-template <int RIF, int STEPPER, int SIGMA>
+template <int RIF, int STEPPER, int SIGMA, int BND = 0>
 __global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P, uint32_t pass) {
     constexpr bool EXTRA = true;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P
         const f3 T(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ)), ps(SLOTF(CO_PSX), SLOTF(CO_PSY), SLOTF(CO_PSZ)), wi(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
         const int depth = (int) SLOT(CO_DEPTH);
         float optLen = 0.0f;
-        const f3 c0 = T * point_nee<true, RIF, STEPPER, SIGMA>(P, rng, C, ps, wi, depth, optLen);
+        const f3 c0 = T * point_nee<true, RIF, STEPPER, SIGMA, BND>(P, rng, C, ps, wi, depth, optLen);
         film_contribute(P, SLOTF(CO_PXF), SLOTF(CO_PYF), c0, SLOTF(CO_PLEN) + optLen);
         const f3 c = mod_weight<EXTRA>(P, c0, SLOTF(CO_PLEN) + optLen);
         SLOT(CO_LX) = __float_as_uint(SLOTF(CO_LX) + c.x); SLOT(CO_LY) = __float_as_uint(SLOTF(CO_LY) + c.y); SLOT(CO_LZ) = __float_as_uint(SLOTF(CO_LZ) + c.z);

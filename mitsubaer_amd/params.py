@@ -12,7 +12,7 @@ VOL_F32, VOL_U8 = 1, 3
 SIGMA_HOMOGENEOUS, SIGMA_GRID = 0, 1
 RIF_CONST, RIF_TRILINEAR, RIF_BSPLINE3 = 0, 1, 2
 STEP_VERLET, STEP_RK4 = 0, 1
-BOUNDARY_AABB, BOUNDARY_SPHERE = 0, 1
+BOUNDARY_AABB, BOUNDARY_SPHERE, BOUNDARY_SDF = 0, 1, 2
 PHASE_ISOTROPIC, PHASE_HG = 0, 1
 TR_WOODCOCK2, TR_RATIO = 0, 1
 STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL = 0, 1, 2
@@ -54,6 +54,7 @@ class SceneParams:
         self.boundary_bsdf = BSDF_NULL                            # BSDF_HDIELECTRIC: smooth dielectric, eta = RIF at the hit point
         self.bmin = [-1.0, -1.0, -1.0]; self.bmax = [1.0, 1.0, 1.0]
         self.sph_center = [0.0, 0.0, 0.0]; self.sph_radius = 1.0
+        self.sdf = None; self.sdf_aabb = ([-1, -1, -1], [1, 1, 1])    # BOUNDARY_SDF: signed-distance grid, negative inside
         # medium
         self.sigma_mode = SIGMA_GRID
         self.sigma_a = [0.05, 0.05, 0.05]; self.sigma_s = [0.5, 3.5, 7.5]

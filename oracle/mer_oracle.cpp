@@ -506,6 +506,7 @@ struct Scene {
     Float mediumSamplingWeight, samplingDensity;
     Float maxDensity, invMaxDensity;
     bool curved;
+    Grid sdfGrid; Float sdfEps = 0;
     int frames = 1;                /* film.cpp:71-78 */
     Float modPhase = 0;            /* radians */
     /* include/mitsuba/render/pathlengthsampler.h:32-42 */
@@ -552,6 +553,12 @@ struct Scene {
         }
         if (s.albedo_mode == ORC_ALBEDO_GRID) albedoGrid.configure(s.albedo_grid);
         curved = s.rif_mode != ORC_RIF_CONST;
+        if (s.boundary == ORC_BOUNDARY_SDF) {
+            if (!s.sdf.data || s.sdf.channels != 1 || s.sdf.dtype != ORC_VOL_F32) { g_err = "heterogeneousrefractive: the sdf must be a 1-channel float32 grid"; return false; }
+            sdfGrid.configure(s.sdf);
+            Float d2 = 0; for (int i = 0; i < 3; ++i) d2 += (s.sdf.aabb_max[i] - s.sdf.aabb_min[i]) * (s.sdf.aabb_max[i] - s.sdf.aabb_min[i]);
+            sdfEps = 1e-4f * std::sqrt(d2);
+        }
         frames = 1;
         modPhase = (Float) (s.mod_phase_deg * M_PI / 180);                            /* pathlengthsampler.cpp:15 */
         if (s.modulation < 0 || s.modulation > 5) { g_err = "The \"modulation\" parameter must be equal toeither \"none\", \"square\", or \"hamiltonian\", or \"mseq\", or \"depthselective\"!"; return false; }
@@ -623,8 +630,16 @@ struct Scene {
                 camM[1][0] * dl.x + camM[1][1] * dl.y + camM[1][2] * dl.z,
                 camM[2][0] * dl.x + camM[2][1] * dl.y + camM[2][2] * dl.z);
     }
+    /* signed distance at p: trilinear lookup (gridvolume lookupFloat); outside the grid (where lookupFloat returns 0) far outside */
+    inline Float sdfValue(const Vec &p) const {
+        int idx4[4];
+        const Float v = sdfGrid.lookupFloat(p, idx4);
+        return idx4[3] >= 0 ? v : (Float) 1e30f;
+    }
     /* medium boundary shape: heterogeneousrefractive.cpp:707-726 generalised to data */
     template <typename FLOAT> inline bool insideShape(const V3<FLOAT> &p) const {
+        if (s.boundary == ORC_BOUNDARY_SDF)                     /* negative inside (:481); lookupFloat is 0 outside the grid */
+            return sdfValue(Vec((Float) p.x, (Float) p.y, (Float) p.z)) < 0;
         if (s.boundary == ORC_BOUNDARY_SPHERE) {
             V3<FLOAT> q(p.x - (FLOAT) s.sph_center[0], p.y - (FLOAT) s.sph_center[1], p.z - (FLOAT) s.sph_center[2]);
             return dot(q, q) < (FLOAT) s.sph_radius * (FLOAT) s.sph_radius;
@@ -634,6 +649,30 @@ struct Scene {
     /* ray / boundary-shape intersection in [mint, maxt]; returns t or -1 */
     inline Float intersectShape(const Vec &o, const Vec &d, Float mint, Float maxt) const {
         Float nearT, farT;
+        if (s.boundary == ORC_BOUNDARY_SDF) {
+            /* sphere tracing on the signed-distance grid (new: the reference intersects the mesh; the SDF is its inside test).  A start
+               point near the surface counts as inside (eps = 1e-4 x grid diagonal): the walk then looks for the exit */
+            if (!Grid::aabbIntersect(sdfGrid.bmin, sdfGrid.bmax, o, d, nearT, farT)) return -1;
+            const Float t0 = std::max(nearT, mint), t1 = std::min(farT, maxt);
+            if (!(t0 <= t1)) return -1;
+            Float t = t0;
+            Float v = sdfValue(o + d * t);
+            /* Entry points are returned with sdf < eps/2 and exit points with sdf in [eps, ~2 eps): a start within 4 eps of the surface
+               is a start from the inside side; it first has to get below 0 ("armed") before an exit counts */
+            const bool insideStart = v < 4 * sdfEps;
+            bool armed = false;
+            for (int it = 0; it < 1024; ++it) {
+                if (insideStart) {
+                    if (v < 0) armed = true;
+                    else if (armed && v >= sdfEps) return t;
+                    else if (!armed && it >= 16) return t;          /* grazing / outward start: it never went in */
+                } else if (v < 0.5f * sdfEps) return t;
+                t += v > 1e29f ? sdfEps : std::max(std::fabs(v), sdfEps);       /* a sample on the grid's face may round to outside it */
+                if (t > t1) return insideStart ? (farT <= maxt ? farT : (Float) -1) : (Float) -1;
+                v = sdfValue(o + d * t);
+            }
+            return -1;
+        }
         if (s.boundary == ORC_BOUNDARY_SPHERE) {
             /* src/shapes/sphere.cpp rayIntersect: double-precision quadratic */
             double ox = (double) o.x - s.sph_center[0], oy = (double) o.y - s.sph_center[1], oz = (double) o.z - s.sph_center[2];
@@ -657,6 +696,11 @@ struct Scene {
     }
     /* outward geometric normal of the boundary shape at a surface point (cube: the face whose plane the point is closest to) */
     inline Vec shapeNormal(const Vec &x) const {
+        if (s.boundary == ORC_BOUNDARY_SDF) {                   /* normalized SDF gradient (heterogeneousrefractive.cpp:980-984) */
+            Float v; V3<float> g;
+            trilinearValueGrad<float>(sdfGrid, V3<float>(x), v, g);
+            return normalize(Vec(g.x, g.y, g.z));
+        }
         if (s.boundary == ORC_BOUNDARY_SPHERE) {
             Vec n(x.x - s.sph_center[0], x.y - s.sph_center[1], x.z - s.sph_center[2]);
             return normalize(n);
@@ -1474,6 +1518,7 @@ struct Walker {
                     const Float cosI = dot(-rd, n);            /* Frame::cosTheta(bRec.wi), wi = -ray.d */
                     const Float etaB = S.boundaryEta(x), invEtaB = 1 / etaB;          /* hdielectric.cpp:115-118 */
                     Float cosT; const Float F = fresnelDielectricExt(cosI, cosT, etaB);
+                    if (dbg) printf("orc DIEL depth=%d medium=%d itsT=%g x=(%g %g %g) n=(%g %g %g) cosI=%g eta=%g F=%g u1=%g T=%g\n", depth, (int) medium, itsT, x.x, x.y, x.z, n.x, n.y, n.z, cosI, etaB, F, u1, throughput[0]);
                     Vec wo; bool inside;
                     if (u1 <= F) {                             /* reflect(wi) = (-x,-y,z) locally: 2 (wi.n) n - wi */
                         wo = rd + n * (2 * cosI);

@@ -36,7 +36,7 @@ typedef struct {
 enum { ORC_SIGMA_HOMOGENEOUS = 0, ORC_SIGMA_GRID = 1 };
 enum { ORC_RIF_CONST = 0, ORC_RIF_TRILINEAR = 1, ORC_RIF_BSPLINE3 = 2 };
 enum { ORC_STEP_VERLET = 0, ORC_STEP_RK4 = 1 };
-enum { ORC_BOUNDARY_AABB = 0, ORC_BOUNDARY_SPHERE = 1 };
+enum { ORC_BOUNDARY_AABB = 0, ORC_BOUNDARY_SPHERE = 1, ORC_BOUNDARY_SDF = 2 };
 enum { ORC_PHASE_ISOTROPIC = 0, ORC_PHASE_HG = 1 };
 enum { ORC_TR_WOODCOCK2 = 0, ORC_TR_RATIO = 1 };
 enum { ORC_STRATEGY_BALANCE = 0, ORC_STRATEGY_SINGLE = 1, ORC_STRATEGY_MANUAL = 2 };
@@ -85,6 +85,9 @@ typedef struct {
     /* BSDF of the medium's boundary shape: 0 = null (index-matched), 1 = hdielectric (src/bsdfs/hdielectric.cpp: smooth dielectric
        whose eta is the RIF at the hit point, exterior index 1) */
     int32_t boundary_bsdf;
+    /* boundary = ORC_BOUNDARY_SDF: the shape is the negative region of a signed-distance grid (the reference's `sdf` child,
+       src/medium/heterogeneousrefractive.cpp:366-375; negative inside, :481) */
+    orc_grid sdf;
 } orc_scene;
 enum { ORC_BSDF_NULL = 0, ORC_BSDF_HDIELECTRIC = 1 };
 

@@ -54,6 +54,7 @@ class Scene(C.Structure):
         ("calibrated_transient", C.c_int32),
         ("modulation", C.c_int32), ("mod_lambda", C.c_float), ("mod_phase_deg", C.c_float), ("mod_P", C.c_int32), ("mod_neighbors", C.c_int32),
         ("boundary_bsdf", C.c_int32),
+        ("sdf", Grid),
     ]
 
 
@@ -124,6 +125,7 @@ def make_scene(p):
     s.albedo_grid = make_grid(p.albedo_grid, p.albedo_aabb[0], p.albedo_aabb[1], keep) if p.albedo_grid is not None else Grid()
     s.rif_mode, s.rif_const = p.rif_mode, p.rif_const
     s.rif = make_grid(p.rif, p.rif_aabb[0], p.rif_aabb[1], keep) if p.rif is not None else Grid()
+    s.sdf = make_grid(p.sdf, p.sdf_aabb[0], p.sdf_aabb[1], keep) if p.sdf is not None else Grid()
     s.stepper, s.stepsize, s.rif_double = p.stepper, p.stepsize, int(getattr(p, "rif_double", 0))
     s.phase, s.g = p.phase, p.g
     s.tr_estimator = p.tr_estimator
