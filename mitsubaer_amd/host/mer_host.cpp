@@ -157,7 +157,8 @@ void Medium::configure() {
         if (!albedo) Log_EError("No albedo specified!");
     } else if (kind == "heterogeneousrefractive") {
         if (!rif) Log_EError("No RIF specified!");                  // heterogeneousrefractive.cpp:368-369
-        // the reference also demands an `sdf` child for its winding-number inside test; the boundary is the shape here (D5)
+        // the reference demands an `sdf` child; here it is optional: without it the boundary is the shape itself (D5), with it the
+        // negative region of the grid
         if (rif->channels != 1 || rif->dtype != MER_VOL_F32) Log_EError("The RIF must be a 1-channel float32 volume");
         if (density && !albedo) Log_EError("No albedo specified!");
     }
@@ -615,11 +616,17 @@ void Integrator::flatten(const Scene &scene, mer_scene_desc &d) const {
     const Shape *shape = NULL;
     for (auto &s : scene.shapes) if (s->interior) { if (shape) Log_EError("Only one shape with an interior medium is supported on the GPU path"); shape = s.get(); }
     if (!shape) Log_EError("No shape with an 'interior' medium was found");
-    d.boundary = shape->boundary; d.boundary_bsdf = shape->bsdf;
+    d.boundary = shape->boundary; d.boundary_bsdf = shape->bsdf; d.sdf = 0;
     for (int i = 0; i < 3; i++) { d.bmin[i] = shape->bmin[i]; d.bmax[i] = shape->bmax[i]; d.sph_center[i] = shape->center[i]; }
     d.sph_radius = shape->radius;
     const Medium &m = *shape->interior;
     if (m.density && m.density->isConstant()) Log_EError("heterogeneous: a constant 'density' volume is a homogeneous medium; use the 'homogeneous' plugin");
+    // an `sdf` child makes the medium shape the negative region of that grid (heterogeneousrefractive.cpp:366-375); the mesh then only
+    // has to enclose it
+    if (m.sdf) {
+        if (m.sdf->isConstant() || m.sdf->channels != 1 || m.sdf->dtype != MER_VOL_F32) Log_EError("heterogeneousrefractive: the sdf must be a 1-channel float32 grid volume");
+        d.boundary = MER_BOUNDARY_SDF;
+    }
     const bool grid = m.density != NULL;
     d.sigma_mode = grid ? MER_SIGMA_GRID : MER_SIGMA_HOMOGENEOUS;
     for (int i = 0; i < 3; i++) { d.sigma_a[i] = m.sigmaA.c[i]; d.sigma_s[i] = m.sigmaS.c[i]; }
@@ -670,6 +677,7 @@ std::vector<float> Integrator::render(const Scene &scene, int device, int spp, u
         d.rif = upload(*m.rif, m.rif->isSpline() ? MER_LAYOUT_DENSE : layout);
         if (m.rif->isSpline() && mer_volume_build_spline(ctx, d.rif)) fail();
     }
+    if (m.sdf) d.sdf = upload(*m.sdf, MER_LAYOUT_DENSE);
     float *film_dev = NULL;
     if (mer_film_channels(ctx, &d, &channels)) fail();
     std::vector<float> film((size_t) d.width * d.height * channels, 0.0f);

@@ -162,3 +162,17 @@ def test_hdielectric_boundary_flattens(tmp_path):
         host.flatten_xml(_scene(tmp_path, ok.replace('type="hdielectric"', 'type="null"')))
     with pytest.raises(host.HostError, match="not supported on the GPU path"):
         host.flatten_xml(_scene(tmp_path, ok.replace('type="hdielectric"', 'type="diffuse"')))
+
+
+def test_sdf_child_selects_the_signed_distance_boundary(tmp_path):
+    dens, rif = _vols(tmp_path)
+    sdf = str(tmp_path / "sdf.vol")
+    volio.write_vol(sdf, -synth.sphere_sdf(16, radius=0.8), [-1] * 3, [1] * 3)
+    med = ('<medium type="heterogeneousrefractive" id="m"><spectrum name="sigmaS" value="1"/><spectrum name="sigmaA" value="0.1"/>'
+           '<volume name="rif" type="gridvolume"><string name="filename" value="%s"/></volume>'
+           '<volume name="sdf" type="gridvolume"><string name="filename" value="%s"/></volume></medium>' % (rif, sdf))
+    body = '<integrator type="volpath"/>' + CAM + med + '<shape type="cube"><bsdf type="hdielectric"/><ref name="interior" id="m"/></shape>'
+    d, _ = host.flatten_xml(_scene(tmp_path, body))
+    assert d.boundary == P.BOUNDARY_SDF and d.boundary_bsdf == P.BSDF_HDIELECTRIC
+    d, _ = host.flatten_xml(_scene(tmp_path, body.replace('<volume name="sdf" type="gridvolume"><string name="filename" value="%s"/></volume>' % sdf, '')))
+    assert d.boundary == P.BOUNDARY_AABB
