@@ -45,3 +45,42 @@ def render_xml(path, defines=None, device=0, spp=0, seed=0, layout=capi.LAYOUT_C
                                 C.c_int32(layout), film.ctypes.data_as(C.c_void_p)) != 0:
         raise HostError(lib().merhost_last_error().decode())
     return film
+
+
+def write_exr(path, rgb):
+    """rgb: float32 [h][w][3] -> uncompressed scan-line OpenEXR (merhost::writeExr)"""
+    a = np.ascontiguousarray(rgb, np.float32)
+    if lib().merhost_write_exr(path.encode(), a.ctypes.data_as(C.c_void_p), C.c_int32(a.shape[0]), C.c_int32(a.shape[1])) != 0:
+        raise HostError(lib().merhost_last_error().decode())
+
+
+def read_exr_uncompressed(path):
+    """Minimal reader for the subset write_exr produces (OpenEXR 2 file layout: magic, version, attributes, offset table,
+    scan lines); returns ({attribute name: (type, bytes)}, float32 [h][w][3] RGB)."""
+    import struct
+    b = open(path, "rb").read()
+    magic, version = struct.unpack_from("<II", b, 0)
+    if magic != 20000630 or (version & 0xFF) != 2:
+        raise ValueError("not an OpenEXR 2 file")
+    pos = 8; attrs = {}
+    while b[pos] != 0:
+        e = b.index(b"\0", pos); name = b[pos:e].decode(); pos = e + 1
+        e = b.index(b"\0", pos); typ = b[pos:e].decode(); pos = e + 1
+        size, = struct.unpack_from("<I", b, pos); pos += 4
+        attrs[name] = (typ, b[pos:pos + size]); pos += size
+    pos += 1
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    if attrs["compression"][1] != b"\0":
+        raise ValueError("compressed EXR")
+    names = []; c = attrs["channels"][1]; q = 0
+    while c[q] != 0:
+        e = c.index(b"\0", q); names.append(c[q:e].decode()); q = e + 1 + 16
+    offsets = struct.unpack_from("<%dQ" % h, b, pos)
+    img = np.empty((h, w, 3), np.float32)
+    for y in range(h):
+        yy, size = struct.unpack_from("<iI", b, offsets[y])
+        rows = np.frombuffer(b, "<f4", len(names) * w, offsets[y] + 8).reshape(len(names), w)
+        for k, n in enumerate(names):
+            img[yy - y0, :, "RGB".index(n)] = rows[k]
+    return attrs, img

@@ -719,6 +719,39 @@ void writePfm(const std::string &path, const float *rgb, int h, int w) {
     for (int y = h - 1; y >= 0; y--) f.write((const char *) (rgb + (size_t) y * w * 3), (std::streamsize) ((size_t) w * 12));
 }
 
+void writeExr(const std::string &path, const float *rgb, int h, int w) {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) Log_EError("Unable to write \"" + path + "\"");
+    auto put32 = [&](uint32_t v) { f.write((const char *) &v, 4); };
+    auto puts0 = [&](const char *s) { f.write(s, (std::streamsize) std::strlen(s) + 1); };
+    auto attr = [&](const char *name, const char *type, const void *data, uint32_t size) { puts0(name); puts0(type); put32(size); f.write((const char *) data, size); };
+    put32(20000630u); put32(2u);                                            // magic, version 2 (scan lines, no flags)
+    {   // chlist: name\0, int32 pixel type (2 = FLOAT), uint8 pLinear + 3 reserved, int32 xSampling, ySampling; terminated by \0
+        std::string ch;
+        for (const char *c : {"B", "G", "R"}) { ch += c; ch += '\0'; int32_t t = 2, one = 1; char lin[4] = {0, 0, 0, 0};
+            ch.append((const char *) &t, 4); ch.append(lin, 4); ch.append((const char *) &one, 4); ch.append((const char *) &one, 4); }
+        ch += '\0';
+        attr("channels", "chlist", ch.data(), (uint32_t) ch.size());
+    }
+    { unsigned char c = 0; attr("compression", "compression", &c, 1); }    // NO_COMPRESSION
+    { int32_t b[4] = {0, 0, w - 1, h - 1}; attr("dataWindow", "box2i", b, 16); attr("displayWindow", "box2i", b, 16); }
+    { unsigned char c = 0; attr("lineOrder", "lineOrder", &c, 1); }        // INCREASING_Y
+    { float a = 1.0f; attr("pixelAspectRatio", "float", &a, 4); }
+    { float c[2] = {0, 0}; attr("screenWindowCenter", "v2f", c, 8); }
+    { float a = 1.0f; attr("screenWindowWidth", "float", &a, 4); }
+    f.put('\0');                                                           // end of header
+    const uint64_t line_bytes = (uint64_t) w * 3 * 4, table = (uint64_t) f.tellp() + (uint64_t) h * 8;
+    for (int y = 0; y < h; y++) { uint64_t off = table + (uint64_t) y * (8 + line_bytes); f.write((const char *) &off, 8); }
+    std::vector<float> row((size_t) w);
+    for (int y = 0; y < h; y++) {
+        put32((uint32_t) y); put32((uint32_t) line_bytes);
+        for (int c = 2; c >= 0; c--) {                                      // channels in alphabetical order: B, G, R
+            for (int x = 0; x < w; x++) row[(size_t) x] = rgb[((size_t) y * w + x) * 3 + c];
+            f.write((const char *) row.data(), (std::streamsize) w * 4);
+        }
+    }
+}
+
 }  // namespace merhost
 
 // ------------------------------------------------------------------------------------------------ C exports
@@ -736,6 +769,9 @@ static std::map<std::string, std::string> parseDefines(const char *defs) {
     return m;
 }
 extern "C" {
+int merhost_write_exr(const char *path, const float *rgb, int32_t h, int32_t w) {
+    try { merhost::writeExr(path, rgb, h, w); return 0; } catch (const std::exception &e) { g_host_error = e.what(); return 1; }
+}
 const char *merhost_last_error(void) { return g_host_error.c_str(); }
 int merhost_flatten_xml(const char *path, const char *defines, mer_scene_desc *out, int32_t *spp) {
     try {

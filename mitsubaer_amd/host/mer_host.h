@@ -211,6 +211,9 @@ std::shared_ptr<Scene> loadSceneFromString(const std::string &xml, const std::ma
 std::vector<float> develop(const std::vector<float> &film, int w, int h, int frames = 1);
 void writeNpy(const std::string &path, const float *data, int h, int w, int c);
 void writePfm(const std::string &path, const float *rgb, int h, int w);
+/// OpenEXR 2 scan-line file, uncompressed, three float32 channels B, G, R (what HDRFilm::develop writes through OpenEXR,
+/// src/films/hdrfilm.cpp:527; no OpenEXR library is needed for this subset)
+void writeExr(const std::string &path, const float *rgb, int h, int w);
 
 }  // namespace merhost
 

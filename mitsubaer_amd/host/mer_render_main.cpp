@@ -19,7 +19,7 @@ int main(int argc, char **argv) {
         else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (a == "--dense") layout = MER_LAYOUT_DENSE;
         else if (a == "--raw") raw = true;
-        else if (a == "-h" || a == "--help") { std::printf("usage: mer_render [-D key=value]... [-s spp] [-o out.npy|out.pfm] [--raw] [--dense] [--device n] scene.xml\n"); return 0; }
+        else if (a == "-h" || a == "--help") { std::printf("usage: mer_render [-D key=value]... [-s spp] [-o out.npy|out.pfm|out.exr] [--raw] [--dense] [--device n] scene.xml\n"); return 0; }
         else scenePath = a;
     }
     if (scenePath.empty()) { std::fprintf(stderr, "mer_render: no scene file given\n"); return 2; }
@@ -32,7 +32,14 @@ int main(int argc, char **argv) {
         else {
             std::vector<float> rgb = merhost::develop(film, w, h, frames);
             const bool pfm = out.size() > 4 && out.substr(out.size() - 4) == ".pfm";
-            if (frames == 1) { if (pfm) merhost::writePfm(out, rgb.data(), h, w); else merhost::writeNpy(out, rgb.data(), h, w, 3); }
+            const bool exr = out.size() > 4 && out.substr(out.size() - 4) == ".exr";
+            if (frames == 1) { if (pfm) merhost::writePfm(out, rgb.data(), h, w); else if (exr) merhost::writeExr(out, rgb.data(), h, w); else merhost::writeNpy(out, rgb.data(), h, w, 3); }
+            else if (exr) {
+                for (int f = 0; f < frames; f++) {
+                    char suffix[32]; std::snprintf(suffix, sizeof(suffix), "_%04d.exr", f);
+                    merhost::writeExr(out.substr(0, out.size() - 4) + suffix, rgb.data() + (size_t) f * w * h * 3, h, w);
+                }
+            }
             else if (pfm) {                       // one file per frame, as the reference's hdrfilm writes <name>_<frame>
                 for (int f = 0; f < frames; f++) {
                     char suffix[32]; std::snprintf(suffix, sizeof(suffix), "_%04d.pfm", f);

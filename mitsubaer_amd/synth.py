@@ -73,3 +73,18 @@ def sphere_sdf(N, radius=0.75, aabb_min=(-1, -1, -1), aabb_max=(1, 1, 1)):
     ax = [np.linspace(aabb_min[i], aabb_max[i], N) for i in range(3)]
     z, y, x = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
     return (radius - np.sqrt(x * x + y * y + z * z)).astype(np.float32)
+
+
+def acoustic_rif(N, n0=1.33, nmax=1e-3, mode=0, kr=None, aabb_min=(-1, -1, -1), aabb_max=(1, 1, 1), axis=2):
+    """Sampled form of the reference's analytic ultrasound field (src/volume/acousticrifvolume.cpp:101-105,224-342): a standing
+    Bessel mode in a cylinder, n = n0 + nmax * J_m(k_r r) * cos(m phi), r and phi in the plane normal to `axis`.  k_r defaults to
+    the first zero of J_m over the half width of the box (a node on the cylinder wall)."""
+    from scipy import special
+    ax = [np.linspace(aabb_min[i], aabb_max[i], N) for i in range(3)]
+    z, y, x = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+    u, v = [(y, z), (x, z), (x, y)][axis]
+    r = np.sqrt(u * u + v * v); phi = np.arctan2(v, u)
+    if kr is None:
+        half = 0.5 * min(aabb_max[i] - aabb_min[i] for i in range(3) if i != axis)
+        kr = special.jn_zeros(mode, 1)[0] / half
+    return (n0 + nmax * special.jv(mode, kr * r) * np.cos(mode * phi)).astype(np.float32)

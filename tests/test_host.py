@@ -106,3 +106,28 @@ def test_rif_from_sdf_follows_the_reference_recipe():
     np.testing.assert_array_equal(flipped, synth.rif_from_sdf(sdf))
     with pytest.raises(ValueError):
         synth.rif_from_sdf(-np.abs(sdf))
+
+
+def test_exr_writer_round_trip(tmp_path):
+    """the host's OpenEXR writer (uncompressed scan lines, float32 B,G,R): header attributes and pixels read back"""
+    from mitsubaer_amd import host
+    rng = np.random.RandomState(2)
+    img = rng.rand(7, 11, 3).astype(np.float32) * 10
+    f = str(tmp_path / "a.exr")
+    host.write_exr(f, img)
+    attrs, back = host.read_exr_uncompressed(f)
+    assert np.array_equal(back, img)
+    assert attrs["channels"][0] == "chlist" and attrs["compression"] == ("compression", b"\0") and attrs["lineOrder"][1] == b"\0"
+    assert struct.unpack("<4i", attrs["dataWindow"][1]) == (0, 0, 10, 6) == struct.unpack("<4i", attrs["displayWindow"][1])
+    assert os.path.getsize(f) > 7 * 11 * 12
+
+
+def test_acoustic_rif_is_a_bessel_mode():
+    from scipy import special
+    n = synth.acoustic_rif(33, n0=1.33, nmax=2e-3, mode=0)
+    assert n.dtype == np.float32 and n.shape == (33, 33, 33)
+    assert abs(n[:, 16, 16].max() - (1.33 + 2e-3)) < 1e-6                      # J_0(0) = 1 on the axis
+    assert np.allclose(n[5], n[20])                                             # constant along the cylinder axis
+    assert abs(n[0, 16, 32] - 1.33) < 2e-6                                      # node of J_0 on the wall (k_r = j_01 / half width)
+    m2 = synth.acoustic_rif(33, mode=2, nmax=1e-3)
+    assert abs(m2[0, 16, 16] - 1.33) < 1e-7 and m2.max() - 1.33 < 1e-3 * special.jv(2, special.jnp_zeros(2, 1)[0]) + 1e-6
