@@ -1436,7 +1436,7 @@ struct Walker {
                         }
                     } else {
                         /* connection through the RIF: Medium::eval (heterogeneousrefractive.cpp:571-640) */
-                        bool ok; Float w = 1, dist = 0, optD = 0; Vec dir; Spec tr(0.0f);
+                        bool ok; Float w = 1, dist = 0, optD = 0; Vec dir(0, 0, 1); Spec tr(0.0f);
                         if (S.s.rif_double) {
                             Connector<double> K(S, C, rng); V3<double> d2, rev; double ww = 1, od = 0, di = 0;
                             V3<double> a(mRec.p), b(pointP);
