@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--layout", default="cell8", choices=["dense", "cell8"])
+    ap.add_argument("--layout", default="cell8", choices=["dense", "cell8", "brick27"])
     ap.add_argument("--shard", default="samples", choices=["samples", "tiles"])
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force this GPU index for every rank (rehearsal on one GPU)")
@@ -128,7 +128,7 @@ def main():
     p, desc = build_workload(args.workload, args.res, args.size, args.spp)
     ctx = capi.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    layout = capi.LAYOUT_CELL8 if args.layout == "cell8" else capi.LAYOUT_DENSE
+    layout = {"cell8": capi.LAYOUT_CELL8, "brick27": capi.LAYOUT_BRICK27, "dense": capi.LAYOUT_DENSE}[args.layout]
     sc, vols = ctx.upload_scene(p, layout=layout)
     film = torch.zeros((p.height, p.width, 5), dtype=torch.float32, device=dev)
     # weak scaling: every rank renders args.spp samples per pixel of a (spp * world)-sample job

@@ -65,7 +65,9 @@ struct Rng {
 // Device view of an uploaded grid (GridDataSource / SplineDataSource).
 struct DGrid {
     const void  *data;        // dense: x fastest [z][y][x][c]
-    const float *cell8;       // MER_LAYOUT_CELL8: 8 corner values per cell, [z][y][x][8] over (res-1)^3 cells
+    const float *cell8;       // MER_LAYOUT_CELL8: 8 corner values per cell, [z][y][x][8] over (res-1)^3 cells;
+                              // MER_LAYOUT_BRICK27: 27 corners (+5 pad) per 2x2x2-cell brick, [bz][by][bx][32], b[(dz*3+dy)*3+dx]
+    int32_t nbx, nby;         // BRICK27: bricks along x and y
     const float *coeff;       // cubic B-spline coefficients (dense) or NULL
     int32_t res[3];
     int32_t channels, dtype, layout;
@@ -159,7 +161,12 @@ struct CellCache {
     int cell;                 // linear index of the cached cell's base corner, -1 = empty
     float cx, cy, cz;         // the cached cell's base corner in grid coordinates (exact small integers)
     float d000, d001, d010, d011, d100, d101, d110, d111;
-    __device__ __forceinline__ void reset() { cell = -1; cx = cy = cz = -1.0e30f; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f; }
+    // BRICK27 kinds only (dead registers otherwise): the 3x3x3 corners of the current 2x2x2-cell brick -- a cell change inside the brick
+    // is a register selection, not a memory request
+    int brick; float b[27];
+    __device__ __forceinline__ void reset() { cell = -1; brick = -1; cx = cy = cz = -1.0e30f; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f;
+#pragma unroll
+                                              for (int i = 0; i < 27; i++) b[i] = 0.0f; }
 };
 
 // Internal fetch kinds of the trilinear RIF (template parameter RIF of the kernels):
@@ -167,6 +174,8 @@ struct CellCache {
 //   RIFK_CELL8 (4): cell-major grid, global loads                   RIFK_CELL8_BUF (5): cell-major, buffer loads
 // Buffer loads take a 32-bit byte offset against a wave-uniform descriptor: one VGPR of address arithmetic per
 // fetch instead of eight 64-bit adds, and the +row / +slice strides ride in the scalar offset operand.
+#define RIFK_BRICK27_BUF 6
+#define RIFK_BRICK27 7
 #define RIFK_DENSE_BUF 3
 #define RIFK_CELL8 4
 #define RIFK_CELL8_BUF 5
@@ -195,6 +204,39 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
         const int x1 = (int) cc.cx, y1 = (int) cc.cy, z1 = (int) cc.cz;
         fx = px - cc.cx; fy = py - cc.cy; fz = pz - cc.cz;
         const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);
+        if (RIFK == RIFK_BRICK27 || RIFK == RIFK_BRICK27_BUF) {
+            if (base != cc.cell) {
+                cc.cell = base;
+                const int brick = (int) (__umul24(__umul24(z1 >> 1, g.nby) + (y1 >> 1), g.nbx) + (x1 >> 1));
+                if (brick != cc.brick) {                       // one 128-byte record: seven 16-byte loads of one cache line
+                    cc.brick = brick;
+#pragma unroll
+                    for (int q = 0; q < 7; q++) {
+                        u32x4 u;
+                        if (RIFK == RIFK_BRICK27_BUF) {
+                            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
+                            u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, brick * 128 + q * 16, 0, 0);
+                        } else u = *(const u32x4 *) (g.cell8 + (size_t) brick * 32 + q * 4);
+                        cc.b[4 * q] = __uint_as_float(u.x);
+                        if (4 * q + 1 < 27) cc.b[4 * q + 1] = __uint_as_float(u.y);
+                        if (4 * q + 2 < 27) cc.b[4 * q + 2] = __uint_as_float(u.z);
+                        if (4 * q + 3 < 27) cc.b[4 * q + 3] = __uint_as_float(u.w);
+                    }
+                }
+                // the cell's 8 corners out of the brick's 27: select along x, then y, then z (26 v_cndmask)
+                const bool sx = x1 & 1, sy = y1 & 1, sz = z1 & 1;
+                float lo[9], hi[9], l2[6], h2[6];
+#pragma unroll
+                for (int r = 0; r < 9; r++) { lo[r] = sx ? cc.b[3 * r + 1] : cc.b[3 * r]; hi[r] = sx ? cc.b[3 * r + 2] : cc.b[3 * r + 1]; }
+#pragma unroll
+                for (int z = 0; z < 3; z++) {
+                    l2[2 * z] = sy ? lo[3 * z + 1] : lo[3 * z]; l2[2 * z + 1] = sy ? lo[3 * z + 2] : lo[3 * z + 1];
+                    h2[2 * z] = sy ? hi[3 * z + 1] : hi[3 * z]; h2[2 * z + 1] = sy ? hi[3 * z + 2] : hi[3 * z + 1];
+                }
+                cc.d000 = sz ? l2[2] : l2[0]; cc.d010 = sz ? l2[3] : l2[1]; cc.d100 = sz ? l2[4] : l2[2]; cc.d110 = sz ? l2[5] : l2[3];
+                cc.d001 = sz ? h2[2] : h2[0]; cc.d011 = sz ? h2[3] : h2[1]; cc.d101 = sz ? h2[4] : h2[2]; cc.d111 = sz ? h2[5] : h2[3];
+            }
+        } else
         if (MER_CELL_TEST(base != cc.cell)) {
             cc.cell = base;
             if (RIFK == RIFK_CELL8 || RIFK == RIFK_CELL8_BUF) {

@@ -129,6 +129,34 @@ def test_cell8_layout_is_bit_identical(ctx):
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("shape", [(24, 24, 24), (25, 24, 23), (9, 12, 17), (3, 2, 5)])
+@pytest.mark.parametrize("stepper", [P.STEP_RK4, P.STEP_VERLET])
+def test_brick27_layout_is_bit_identical(ctx, shape, stepper):
+    """BRICK27 (3x3x3 corners of every 2x2x2-cell brick per 128-byte record) is a storage choice: the corners a cell reads are the same
+    floats, so the render is bit-identical to the dense layout -- even and odd cell counts (padded bricks), ragged and tiny grids."""
+    rng = np.random.RandomState(5)
+    rif = (1.3 + 0.3 * rng.rand(*shape)).astype(np.float32)
+    p = scenes.curved_scene(N=16, rif=rif, stepper=stepper, stepsize=0.03)
+    sc, vols = ctx.upload_scene(p, layout=capi.LAYOUT_DENSE)
+    sc2, vols2 = ctx.upload_scene(p, layout=capi.LAYOUT_BRICK27)
+    for s in (0, 1):
+        assert np.array_equal(ctx.render_paths(sc, s, seed=1), ctx.render_paths(sc2, s, seed=1))
+    pts = rng.uniform(-1.1, 1.1, (4096, 3)).astype(np.float32)
+    v0, g0 = ctx.rif_value_grad(vols[-1], P.RIF_TRILINEAR, pts)
+    v1, g1 = ctx.rif_value_grad(vols2[-1], P.RIF_TRILINEAR, pts)
+    assert np.array_equal(v0, v1) and np.array_equal(g0, g1)
+    for v in vols + vols2:
+        v.destroy()
+
+
+def test_brick27_is_for_the_rif_only(ctx):
+    p = scenes.straight_scene(N=16)
+    with pytest.raises(RuntimeError, match="refractive-index field only"):
+        dens = ctx.upload_volume(p.density, p.density_aabb[0], p.density_aabb[1], capi.LAYOUT_BRICK27)
+        sc = ctx.scene_desc(p, dens)
+        ctx.render_paths(sc, 0)
+
+
 def test_constant_rif_reproduces_straight_rays(ctx):
     """a constant RIF through the curved code path = the straight-ray estimator (same expectation)."""
     N = 24
