@@ -161,12 +161,7 @@ struct CellCache {
     int cell;                 // linear index of the cached cell's base corner, -1 = empty
     float cx, cy, cz;         // the cached cell's base corner in grid coordinates (exact small integers)
     float d000, d001, d010, d011, d100, d101, d110, d111;
-    // BRICK27 kinds only (dead registers otherwise): the 3x3x3 corners of the current 2x2x2-cell brick -- a cell change inside the brick
-    // is a register selection, not a memory request
-    int brick; float b[27];
-    __device__ __forceinline__ void reset() { cell = -1; brick = -1; cx = cy = cz = -1.0e30f; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f;
-#pragma unroll
-                                              for (int i = 0; i < 27; i++) b[i] = 0.0f; }
+    __device__ __forceinline__ void reset() { cell = -1; cx = cy = cz = -1.0e30f; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f; }
 };
 
 // Internal fetch kinds of the trilinear RIF (template parameter RIF of the kernels):
@@ -206,35 +201,25 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
         const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);
         if (RIFK == RIFK_BRICK27 || RIFK == RIFK_BRICK27_BUF) {
             if (base != cc.cell) {
+                // the cell's 8 corners as four x-pairs out of its brick's 128-byte record: four 8-byte loads of ONE cache line -- a cell
+                // change inside the brick is an L1 hit, only a brick change goes to L2 / the fabric (half as often as a cell change)
                 cc.cell = base;
                 const int brick = (int) (__umul24(__umul24(z1 >> 1, g.nby) + (y1 >> 1), g.nbx) + (x1 >> 1));
-                if (brick != cc.brick) {                       // one 128-byte record: seven 16-byte loads of one cache line
-                    cc.brick = brick;
-#pragma unroll
-                    for (int q = 0; q < 7; q++) {
-                        u32x4 u;
-                        if (RIFK == RIFK_BRICK27_BUF) {
-                            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
-                            u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, brick * 128 + q * 16, 0, 0);
-                        } else u = *(const u32x4 *) (g.cell8 + (size_t) brick * 32 + q * 4);
-                        cc.b[4 * q] = __uint_as_float(u.x);
-                        if (4 * q + 1 < 27) cc.b[4 * q + 1] = __uint_as_float(u.y);
-                        if (4 * q + 2 < 27) cc.b[4 * q + 2] = __uint_as_float(u.z);
-                        if (4 * q + 3 < 27) cc.b[4 * q + 3] = __uint_as_float(u.w);
-                    }
+                const int o = brick * 32 + ((z1 & 1) * 3 + (y1 & 1)) * 3 + (x1 & 1);          // word index of corner (0,0,0) of the cell
+                u32x2 r00, r01, r10, r11;
+                if (RIFK == RIFK_BRICK27_BUF) {
+                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
+                    r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, 0, 0);
+                    r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4 + 12, 0, 0);
+                    r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4 + 36, 0, 0);
+                    r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4 + 48, 0, 0);
+                } else {
+                    const float *q = g.cell8 + (size_t) brick * 32 + (((z1 & 1) * 3 + (y1 & 1)) * 3 + (x1 & 1));
+                    r00 = u32x2{__float_as_uint(q[0]), __float_as_uint(q[1])}; r01 = u32x2{__float_as_uint(q[3]), __float_as_uint(q[4])};
+                    r10 = u32x2{__float_as_uint(q[9]), __float_as_uint(q[10])}; r11 = u32x2{__float_as_uint(q[12]), __float_as_uint(q[13])};
                 }
-                // the cell's 8 corners out of the brick's 27: select along x, then y, then z (26 v_cndmask)
-                const bool sx = x1 & 1, sy = y1 & 1, sz = z1 & 1;
-                float lo[9], hi[9], l2[6], h2[6];
-#pragma unroll
-                for (int r = 0; r < 9; r++) { lo[r] = sx ? cc.b[3 * r + 1] : cc.b[3 * r]; hi[r] = sx ? cc.b[3 * r + 2] : cc.b[3 * r + 1]; }
-#pragma unroll
-                for (int z = 0; z < 3; z++) {
-                    l2[2 * z] = sy ? lo[3 * z + 1] : lo[3 * z]; l2[2 * z + 1] = sy ? lo[3 * z + 2] : lo[3 * z + 1];
-                    h2[2 * z] = sy ? hi[3 * z + 1] : hi[3 * z]; h2[2 * z + 1] = sy ? hi[3 * z + 2] : hi[3 * z + 1];
-                }
-                cc.d000 = sz ? l2[2] : l2[0]; cc.d010 = sz ? l2[3] : l2[1]; cc.d100 = sz ? l2[4] : l2[2]; cc.d110 = sz ? l2[5] : l2[3];
-                cc.d001 = sz ? h2[2] : h2[0]; cc.d011 = sz ? h2[3] : h2[1]; cc.d101 = sz ? h2[4] : h2[2]; cc.d111 = sz ? h2[5] : h2[3];
+                cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
+                cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
             }
         } else
         if (MER_CELL_TEST(base != cc.cell)) {
