@@ -4,7 +4,7 @@
   python bench.py --gpus N --steps K --warmup W
 
 A step = one full render of the workload (default: config 3 = 256^3 sigma_t grid + 256^3 linear RIF,
-RK4 eikonal stepping on the trilinear field, HG g=0.8, 512^2 x 256 spp, half-voxel steps, ratio-tracking
+RK4 eikonal stepping on the trilinear field (BRICK27 records), HG g=0.8, 512^2 x 256 spp, half-voxel steps, ratio-tracking
 transmittance, box filter) with all inputs resident in HBM.  N > 1 (launched by torch.distributed.run) shards
 sample indices across ranks (weak scaling: every rank renders 512^2 x 256 spp of a 512^2 x (256 N) spp job)
 and sum-reduces the film with RCCL inside the timed region.  Rank 0 prints ONE JSON line.
@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--layout", default="cell8", choices=["dense", "cell8", "brick27"])
+    ap.add_argument("--layout", default="brick27", choices=["dense", "cell8", "brick27", "brick125"])
     ap.add_argument("--shard", default="samples", choices=["samples", "tiles"])
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force this GPU index for every rank (rehearsal on one GPU)")
@@ -128,7 +128,7 @@ def main():
     p, desc = build_workload(args.workload, args.res, args.size, args.spp)
     ctx = capi.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    layout = {"cell8": capi.LAYOUT_CELL8, "brick27": capi.LAYOUT_BRICK27, "dense": capi.LAYOUT_DENSE}[args.layout]
+    layout = {"cell8": capi.LAYOUT_CELL8, "brick27": capi.LAYOUT_BRICK27, "brick125": capi.LAYOUT_BRICK125, "dense": capi.LAYOUT_DENSE}[args.layout]
     sc, vols = ctx.upload_scene(p, layout=layout)
     film = torch.zeros((p.height, p.width, 5), dtype=torch.float32, device=dev)
     # weak scaling: every rank renders args.spp samples per pixel of a (spp * world)-sample job
@@ -195,7 +195,7 @@ def main():
                        "stepsize": p.stepsize, "estimator": "volpath + delta tracking on eikonal rays, ratio-tracking NEE",
                        "device": name, "cus": cus},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "mer::march_kernel<curved, cell8/buffer trilinear, rk4, grid>",
+                         "traffic": None, "kernel": "mer::march_kernel<curved, %s trilinear, rk4, grid>" % args.layout,
                          "kernel_avg_launch_ms": per_launch_ms, "launches_per_step": n_pass, "algorithmic_bytes_per_launch": per_launch_bytes,
                          "kernel_ms_per_step": m_ms, "event_kernel_ms_per_step": e_ms,
                          "whole_step": {"ms": k_ms, "algorithmic_bytes": b_alg, "achieved": achieved_step, "frac": achieved_step / HBM_PEAK_GBS},
@@ -206,7 +206,7 @@ def main():
         # HBM traffic cannot be counted inside this process: it comes from separate `rocprofv3 --pmc` passes of this very
         # command (FETCH_SIZE / WRITE_SIZE, gfx950 read correction applied), committed under profiles/
         tf = os.path.join(ROOT, "profiles", "round1", "pmc_traffic_cfg3_n1.json")
-        if args.workload == "cfg3" and args.res == 256 and args.size == 512 and args.spp == 256 and args.layout == "cell8" and os.path.exists(tf):
+        if args.workload == "cfg3" and args.res == 256 and args.size == 512 and args.spp == 256 and args.layout == "brick27" and os.path.exists(tf):
             try:
                 t = json.load(open(tf))["march_kernel"]
                 out["roofline"]["traffic"] = t["traffic_bytes_per_launch_with_gfx950_x2_read_correction"]

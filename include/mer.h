@@ -40,7 +40,7 @@ enum { MER_ALBEDO_CONST = 0, MER_ALBEDO_GRID = 1 };
 /* device layouts of a 1-channel float32 grid (the index contract stays (x,y,z)): DENSE = the VOL payload; CELL8 = the 8 corners of every
    cell in one 32-byte record; BRICK27 = the 3x3x3 corners of every 2x2x2-cell brick in one 128-byte record (one cache line serves
    eight cells: half the memory requests of CELL8 along a ray).  CELL8 / BRICK27 are for the refractive-index field. */
-enum { MER_LAYOUT_DENSE = 0, MER_LAYOUT_CELL8 = 1, MER_LAYOUT_BRICK27 = 2 };
+enum { MER_LAYOUT_DENSE = 0, MER_LAYOUT_CELL8 = 1, MER_LAYOUT_BRICK27 = 2, MER_LAYOUT_BRICK125 = 3 /* 4x4x4-cell bricks: 5x5x5 corners per 512-byte record */ };
 
 /* replaces GridDataSource::loadFromFile header fields (src/volume/gridvolume.cpp:217-287) */
 typedef struct {

@@ -11,7 +11,7 @@ _LIB = None
 
 C_PATHS, C_STEPS, C_RIF_EVALS, C_TENTATIVE, C_REAL, C_SEGMENTS, C_NEE, C_LOOP_ITERS, C_ACTIVE_LANES = range(9)
 C_COUNT = 16
-LAYOUT_DENSE, LAYOUT_CELL8, LAYOUT_BRICK27 = 0, 1, 2
+LAYOUT_DENSE, LAYOUT_CELL8, LAYOUT_BRICK27, LAYOUT_BRICK125 = 0, 1, 2, 3
 
 # every symbol include/mer.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
@@ -220,7 +220,7 @@ class Context:
         vols = []
         dens = alb = rif = None
         if p.sigma_mode == P.SIGMA_GRID and p.density is not None:
-            dl = LAYOUT_CELL8 if layout == LAYOUT_BRICK27 else layout          # BRICK27 is the RIF's layout; sigma_t keeps its cell records
+            dl = LAYOUT_CELL8 if layout in (LAYOUT_BRICK27, LAYOUT_BRICK125) else layout   # bricks are the RIF's layout; sigma_t keeps its cell records
             dens = self.upload_volume(p.density, p.density_aabb[0], p.density_aabb[1], dl if np.asarray(p.density).dtype != np.uint8 else LAYOUT_DENSE)
             vols.append(dens)
         if p.albedo_mode == P.ALBEDO_GRID and p.albedo_grid is not None:

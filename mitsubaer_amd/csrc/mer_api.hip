@@ -64,10 +64,13 @@ static void fill_dgrid(const Volume &v, DGrid &g) {
     g.data = v.dense; g.cell8 = v.cell8; g.coeff = v.coeff;
     g.layout = v.cell8 ? v.layout : MER_LAYOUT_DENSE;
     g.channels = v.desc.channels; g.dtype = v.desc.dtype;
-    g.nbx = v.desc.res[0] / 2; g.nby = v.desc.res[1] / 2;               // ceil((res-1)/2) bricks per axis
+    const bool brick = v.cell8 && (v.layout == MER_LAYOUT_BRICK27 || v.layout == MER_LAYOUT_BRICK125);
+    g.bshift = v.layout == MER_LAYOUT_BRICK125 ? 2 : 1; g.bw = (1 << g.bshift) + 1; g.recw = v.layout == MER_LAYOUT_BRICK125 ? 128 : 32;
+    const int bc = 1 << g.bshift;                                       // ceil((res-1)/bc) bricks per axis
+    g.nbx = (v.desc.res[0] - 2) / bc + 1; g.nby = (v.desc.res[1] - 2) / bc + 1;
     {
         const uint64_t bytes = !v.cell8 ? (uint64_t) v.bytes_dense
-                             : v.layout == MER_LAYOUT_BRICK27 ? (uint64_t) (v.desc.res[0] / 2) * (v.desc.res[1] / 2) * (v.desc.res[2] / 2) * 128ull
+                             : brick ? (uint64_t) g.nbx * g.nby * ((v.desc.res[2] - 2) / bc + 1) * (uint64_t) g.recw * 4ull
                              : (uint64_t) (v.desc.res[0] - 1) * (v.desc.res[1] - 1) * (v.desc.res[2] - 1) * 32ull;
         g.buf_bytes = bytes < 0xFFFFFFFFull && !getenv("MER_NO_BUFFER_LOADS") ? (uint32_t) bytes : 0u;
     }
@@ -138,7 +141,7 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bo
         auto it = ctx->volumes.find(sc->density);
         if (it == ctx->volumes.end()) return fail(ctx, "No density specified!");                                    // heterogeneous.cpp:229-230
         if (it->second.desc.channels != 1) return fail(ctx, "density volume must support float lookups");           // :270
-        if (it->second.layout == MER_LAYOUT_BRICK27) return fail(ctx, "the BRICK27 layout is for the refractive-index field only");
+        if (it->second.layout == MER_LAYOUT_BRICK27 || it->second.layout == MER_LAYOUT_BRICK125) return fail(ctx, "the BRICK layouts are for the refractive-index field only");
         fill_dgrid(it->second, P.density);
         if (!(sc->density_scale > 0)) return fail(ctx, "heterogeneous medium: 'scale' must be positive");
         // m_maxDensity = m_scale * getMaximumFloatValue() (= 1.0 for gridvolume): heterogeneous.cpp:239-242
@@ -216,7 +219,7 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bo
         auto it = ctx->volumes.find(sc->sdf);
         if (it == ctx->volumes.end()) return fail(ctx, "heterogeneousrefractive: no sdf volume (boundary = sdf)");
         if (it->second.desc.channels != 1 || it->second.desc.dtype != MER_VOL_F32) return fail(ctx, "heterogeneousrefractive: the sdf must be a 1-channel float32 grid");
-        if (it->second.layout == MER_LAYOUT_BRICK27) return fail(ctx, "the BRICK27 layout is for the refractive-index field only");
+        if (it->second.layout == MER_LAYOUT_BRICK27 || it->second.layout == MER_LAYOUT_BRICK125) return fail(ctx, "the BRICK layouts are for the refractive-index field only");
         fill_dgrid(it->second, P.sdf);
         float d2 = 0; for (int i = 0; i < 3; i++) d2 += (P.sdf.bmax[i] - P.sdf.bmin[i]) * (P.sdf.bmax[i] - P.sdf.bmin[i]);
         P.sdf_eps = 1e-4f * std::sqrt(d2);
@@ -252,7 +255,7 @@ template <typename F> static int dispatch_modes(mer_context *ctx, const mer_scen
     if (sc->rif_mode == MER_RIF_TRILINEAR) {
         const Volume &rv = ctx->volumes.find(sc->rif)->second;
         DGrid tmp; fill_dgrid(rv, tmp);
-        if (tmp.layout == MER_LAYOUT_BRICK27) rifk = tmp.buf_bytes ? RIFK_BRICK27_BUF : RIFK_BRICK27;
+        if (tmp.layout == MER_LAYOUT_BRICK27 || tmp.layout == MER_LAYOUT_BRICK125) rifk = tmp.buf_bytes ? RIFK_BRICK27_BUF : RIFK_BRICK27;
         else if (tmp.layout == MER_LAYOUT_CELL8) rifk = tmp.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
         else rifk = tmp.buf_bytes ? RIFK_DENSE_BUF : MER_RIF_TRILINEAR;
     }
@@ -292,7 +295,7 @@ template <typename F> static int dispatch_modes_sdf(mer_context *ctx, const mer_
     if (sc->rif_mode == MER_RIF_TRILINEAR) {
         const Volume &rv = ctx->volumes.find(sc->rif)->second;
         DGrid tmp; fill_dgrid(rv, tmp);
-        if (tmp.layout == MER_LAYOUT_BRICK27) return fail(ctx, "signed-distance boundary: upload the RIF dense or cell8 (brick27 is not instantiated for it)");
+        if (tmp.layout == MER_LAYOUT_BRICK27 || tmp.layout == MER_LAYOUT_BRICK125) return fail(ctx, "signed-distance boundary: upload the RIF dense or cell8 (the brick layouts are not instantiated for it)");
         if (tmp.layout == MER_LAYOUT_CELL8) rifk = tmp.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
         else rifk = MER_RIF_TRILINEAR;                        // dense: global loads
     }
@@ -399,13 +402,14 @@ static int volume_finish(mer_context *ctx, Volume &v, int32_t layout, mer_volume
                            v.desc.res[0], v.desc.res[1], v.desc.res[2]);
         HIP_CHECK(ctx, hipGetLastError());
         HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    } else if (layout == MER_LAYOUT_BRICK27) {
-        if (v.desc.channels != 1 || v.desc.dtype != MER_VOL_F32) return fail(ctx, "BRICK27 layout needs a 1-channel float32 grid");
-        const int nbx = v.desc.res[0] / 2, nby = v.desc.res[1] / 2, nbz = v.desc.res[2] / 2;
-        if (nbx < 1 || nby < 1 || nbz < 1) return fail(ctx, "BRICK27 layout needs at least 2 nodes per axis");
-        HIP_CHECK(ctx, hipMalloc((void **) &v.cell8, (size_t) nbx * nby * nbz * 32 * sizeof(float)));
-        hipLaunchKernelGGL(relayout_brick27_kernel, dim3(4096), dim3(256), 0, ctx->stream, (const float *) v.dense, v.cell8,
-                           v.desc.res[0], v.desc.res[1], v.desc.res[2], nbx, nby, nbz);
+    } else if (layout == MER_LAYOUT_BRICK27 || layout == MER_LAYOUT_BRICK125) {
+        if (v.desc.channels != 1 || v.desc.dtype != MER_VOL_F32) return fail(ctx, "the BRICK layouts need a 1-channel float32 grid");
+        const int bshift = layout == MER_LAYOUT_BRICK125 ? 2 : 1, bc = 1 << bshift, recw = layout == MER_LAYOUT_BRICK125 ? 128 : 32;
+        for (int i = 0; i < 3; i++) if (v.desc.res[i] < 2) return fail(ctx, "the BRICK layouts need at least 2 nodes per axis");
+        const int nbx = (v.desc.res[0] - 2) / bc + 1, nby = (v.desc.res[1] - 2) / bc + 1, nbz = (v.desc.res[2] - 2) / bc + 1;
+        HIP_CHECK(ctx, hipMalloc((void **) &v.cell8, (size_t) nbx * nby * nbz * recw * sizeof(float)));
+        hipLaunchKernelGGL(relayout_brick_kernel, dim3(4096), dim3(256), 0, ctx->stream, (const float *) v.dense, v.cell8,
+                           v.desc.res[0], v.desc.res[1], v.desc.res[2], nbx, nby, nbz, bshift, recw);
         HIP_CHECK(ctx, hipGetLastError());
         HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     } else if (layout != MER_LAYOUT_DENSE) return fail(ctx, "unknown volume layout");
@@ -806,7 +810,7 @@ int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0,
         od.alloc(n * 4) || oo.alloc(n * 4) || ok.alloc(n * 4)) return 1;
     int rifk = scene->rif_mode;
     if (scene->rif_mode == MER_RIF_TRILINEAR) {
-        if (P.rif.layout == MER_LAYOUT_BRICK27) return fail(ctx, "this leaf entry point takes the RIF in the dense or cell8 layout");
+        if (P.rif.layout == MER_LAYOUT_BRICK27 || P.rif.layout == MER_LAYOUT_BRICK125) return fail(ctx, "this leaf entry point takes the RIF in the dense or cell8 layout");
         if (P.rif.layout == MER_LAYOUT_CELL8) rifk = P.rif.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
         else rifk = P.rif.buf_bytes ? RIFK_DENSE_BUF : MER_RIF_TRILINEAR;
     }
@@ -835,7 +839,7 @@ int mer_connect(mer_context *ctx, const mer_scene_desc *scene, const float *p1, 
     if (a.upload(p1, n * 12) || b.upload(p2, n * 12) || r.alloc(n * 48)) return 1;
     int rifk = scene->rif_mode;
     if (scene->rif_mode == MER_RIF_TRILINEAR) {
-        if (P.rif.layout == MER_LAYOUT_BRICK27) return fail(ctx, "this leaf entry point takes the RIF in the dense or cell8 layout");
+        if (P.rif.layout == MER_LAYOUT_BRICK27 || P.rif.layout == MER_LAYOUT_BRICK125) return fail(ctx, "this leaf entry point takes the RIF in the dense or cell8 layout");
         if (P.rif.layout == MER_LAYOUT_CELL8) rifk = P.rif.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
         else rifk = P.rif.buf_bytes ? RIFK_DENSE_BUF : MER_RIF_TRILINEAR;
     }

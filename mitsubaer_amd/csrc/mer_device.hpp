@@ -67,7 +67,8 @@ struct DGrid {
     const void  *data;        // dense: x fastest [z][y][x][c]
     const float *cell8;       // MER_LAYOUT_CELL8: 8 corner values per cell, [z][y][x][8] over (res-1)^3 cells;
                               // MER_LAYOUT_BRICK27: 27 corners (+5 pad) per 2x2x2-cell brick, [bz][by][bx][32], b[(dz*3+dy)*3+dx]
-    int32_t nbx, nby;         // BRICK27: bricks along x and y
+    int32_t nbx, nby;         // BRICK layouts: bricks along x and y
+    int32_t bshift, bw, recw; // BRICK layouts: log2(cells per brick axis), corners per axis (cells + 1), words per record
     const float *coeff;       // cubic B-spline coefficients (dense) or NULL
     int32_t res[3];
     int32_t channels, dtype, layout;
@@ -201,22 +202,23 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
         const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);
         if (RIFK == RIFK_BRICK27 || RIFK == RIFK_BRICK27_BUF) {
             if (base != cc.cell) {
-                // the cell's 8 corners as four x-pairs out of its brick's 128-byte record: four 8-byte loads of ONE cache line -- a cell
-                // change inside the brick is an L1 hit, only a brick change goes to L2 / the fabric (half as often as a cell change)
+                // the cell's 8 corners as four x-pairs out of its brick's record (2^3 cells: 27 corners, one 128-byte line; 4^3 cells: 125
+                // corners, 512 bytes): a cell change inside the brick is an L1 hit, only a change of line goes to L2 / the fabric
                 cc.cell = base;
-                const int brick = (int) (__umul24(__umul24(z1 >> 1, g.nby) + (y1 >> 1), g.nbx) + (x1 >> 1));
-                const int o = brick * 32 + ((z1 & 1) * 3 + (y1 & 1)) * 3 + (x1 & 1);          // word index of corner (0,0,0) of the cell
+                const int bs = g.bshift, bm = (1 << bs) - 1, bw = g.bw;
+                const int brick = (int) (__umul24(__umul24(z1 >> bs, g.nby) + (y1 >> bs), g.nbx) + (x1 >> bs));
+                const int o = brick * g.recw + ((z1 & bm) * bw + (y1 & bm)) * bw + (x1 & bm);   // word index of the cell's corner (0,0,0)
                 u32x2 r00, r01, r10, r11;
                 if (RIFK == RIFK_BRICK27_BUF) {
                     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
                     r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, 0, 0);
-                    r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4 + 12, 0, 0);
-                    r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4 + 36, 0, 0);
-                    r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4 + 48, 0, 0);
+                    r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * 4, 0);
+                    r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * bw * 4, 0);
+                    r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, (bw * bw + bw) * 4, 0);
                 } else {
-                    const float *q = g.cell8 + (size_t) brick * 32 + (((z1 & 1) * 3 + (y1 & 1)) * 3 + (x1 & 1));
-                    r00 = u32x2{__float_as_uint(q[0]), __float_as_uint(q[1])}; r01 = u32x2{__float_as_uint(q[3]), __float_as_uint(q[4])};
-                    r10 = u32x2{__float_as_uint(q[9]), __float_as_uint(q[10])}; r11 = u32x2{__float_as_uint(q[12]), __float_as_uint(q[13])};
+                    const float *q = g.cell8 + (size_t) brick * g.recw + (((z1 & bm) * bw + (y1 & bm)) * bw + (x1 & bm));
+                    r00 = u32x2{__float_as_uint(q[0]), __float_as_uint(q[1])}; r01 = u32x2{__float_as_uint(q[bw]), __float_as_uint(q[bw + 1])};
+                    r10 = u32x2{__float_as_uint(q[bw * bw]), __float_as_uint(q[bw * bw + 1])}; r11 = u32x2{__float_as_uint(q[bw * bw + bw]), __float_as_uint(q[bw * bw + bw + 1])};
                 }
                 cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
                 cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);

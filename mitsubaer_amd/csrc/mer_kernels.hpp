@@ -285,7 +285,7 @@ __global__ void rif_value_grad_kernel(DGrid g, int interp, const float *pts, int
     const f3 p(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
     CellCache cc; cc.reset();
     if (interp == MER_RIF_BSPLINE3) bspline_value_grad(g, p, v, gr);
-    else if (g.layout == MER_LAYOUT_BRICK27) { if (g.buf_bytes) trilinear_value_grad<RIFK_BRICK27_BUF>(g, cc, p, v, gr); else trilinear_value_grad<RIFK_BRICK27>(g, cc, p, v, gr); }
+    else if (g.layout == MER_LAYOUT_BRICK27 || g.layout == MER_LAYOUT_BRICK125) { if (g.buf_bytes) trilinear_value_grad<RIFK_BRICK27_BUF>(g, cc, p, v, gr); else trilinear_value_grad<RIFK_BRICK27>(g, cc, p, v, gr); }
     else if (g.layout == MER_LAYOUT_CELL8) { if (g.buf_bytes) trilinear_value_grad<RIFK_CELL8_BUF>(g, cc, p, v, gr); else trilinear_value_grad<RIFK_CELL8>(g, cc, p, v, gr); }
     else { if (g.buf_bytes) trilinear_value_grad<RIFK_DENSE_BUF>(g, cc, p, v, gr); else trilinear_value_grad<MER_RIF_TRILINEAR>(g, cc, p, v, gr); }
     val[i] = v; grad[3 * i] = gr.x; grad[3 * i + 1] = gr.y; grad[3 * i + 2] = gr.z;
@@ -432,16 +432,16 @@ __global__ void relayout_cell8_kernel(const float *dense, float *cell8, int rx, 
 // Grid re-layout DENSE -> BRICK27: the 3x3x3 corners of every 2x2x2-cell brick in one 128-byte record (27 words + 5 of padding).  A ray
 // crosses a brick face half as often as a cell face, and a cell change inside the brick is served from registers: half the memory
 // requests of CELL8 and half its footprint.  Corners past the last node (odd cell counts) replicate the last node and are never selected.
-__global__ void relayout_brick27_kernel(const float *dense, float *rec, int rx, int ry, int rz, int nbx, int nby, int nbz) {
-    const int64_t nbrick = (int64_t) nbx * nby * nbz;
+__global__ void relayout_brick_kernel(const float *dense, float *rec, int rx, int ry, int rz, int nbx, int nby, int nbz, int bshift, int recw) {
+    const int64_t nbrick = (int64_t) nbx * nby * nbz; const int bw = (1 << bshift) + 1;
     for (int64_t c = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; c < nbrick; c += (int64_t) gridDim.x * blockDim.x) {
         const int bx = (int) (c % nbx), by = (int) ((c / nbx) % nby), bz = (int) (c / ((int64_t) nbx * nby));
-        float *q = rec + c * 32;
-        for (int dz = 0; dz < 3; dz++) for (int dy = 0; dy < 3; dy++) for (int dx = 0; dx < 3; dx++) {
-            const int x = min(2 * bx + dx, rx - 1), y = min(2 * by + dy, ry - 1), z = min(2 * bz + dz, rz - 1);
-            q[(dz * 3 + dy) * 3 + dx] = dense[((int64_t) z * ry + y) * rx + x];
+        float *q = rec + c * recw;
+        for (int dz = 0; dz < bw; dz++) for (int dy = 0; dy < bw; dy++) for (int dx = 0; dx < bw; dx++) {
+            const int x = min((bx << bshift) + dx, rx - 1), y = min((by << bshift) + dy, ry - 1), z = min((bz << bshift) + dz, rz - 1);
+            q[(dz * bw + dy) * bw + dx] = dense[((int64_t) z * ry + y) * rx + x];
         }
-        for (int k = 27; k < 32; k++) q[k] = 0.0f;
+        for (int k = bw * bw * bw; k < recw; k++) q[k] = 0.0f;
     }
 }
 

@@ -8,7 +8,7 @@
 int main(int argc, char **argv) {
     std::map<std::string, std::string> defines;
     std::string out = "out.npy", scenePath;
-    int spp = 0, device = 0, layout = MER_LAYOUT_CELL8; unsigned long long seed = 0; bool raw = false;
+    int spp = 0, device = 0, layout = MER_LAYOUT_BRICK27; unsigned long long seed = 0; bool raw = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "-D" && i + 1 < argc) { std::string kv = argv[++i]; size_t q = kv.find('='); if (q == std::string::npos) { std::fprintf(stderr, "-D expects key=value\n"); return 2; } defines[kv.substr(0, q)] = kv.substr(q + 1); }
@@ -18,8 +18,9 @@ int main(int argc, char **argv) {
         else if (a == "--seed" && i + 1 < argc) seed = std::strtoull(argv[++i], NULL, 10);
         else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
         else if (a == "--dense") layout = MER_LAYOUT_DENSE;
+        else if (a == "--cell8") layout = MER_LAYOUT_CELL8;
         else if (a == "--raw") raw = true;
-        else if (a == "-h" || a == "--help") { std::printf("usage: mer_render [-D key=value]... [-s spp] [-o out.npy|out.pfm|out.exr] [--raw] [--dense] [--device n] scene.xml\n"); return 0; }
+        else if (a == "-h" || a == "--help") { std::printf("usage: mer_render [-D key=value]... [-s spp] [-o out.npy|out.pfm|out.exr] [--raw] [--dense|--cell8] [--device n] scene.xml\n"); return 0; }
         else scenePath = a;
     }
     if (scenePath.empty()) { std::fprintf(stderr, "mer_render: no scene file given\n"); return 2; }
