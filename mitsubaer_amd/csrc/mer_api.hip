@@ -623,6 +623,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
             if (q->items) (void) hipFree(q->items);
             q->items = nullptr;
             q->segcap = 2u * (want / MER_NSEG) + 256u;          // two producer kernels may feed one segment
+            if (q == &ctx->eq) q->segcap = 2u * (want / (MER_NSEG / MER_EV_CLASSES)) + 256u;   // every lane may be of one event class
             HIP_CHECK(ctx, hipMalloc((void **) &q->items, (size_t) q->segcap * MER_NSEG * sizeof(uint32_t)));
             if (!q->counts) HIP_CHECK(ctx, hipMalloc((void **) &q->counts, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t)));
         }

@@ -109,7 +109,9 @@ __device__ __forceinline__ float lookup_float(const DGrid &g, f3 p, int *idx4 = 
     const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
     const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
     if (idx4) { idx4[0] = x1; idx4[1] = y1; idx4[2] = z1; idx4[3] = -1; }
-    if (x1 < 0 || y1 < 0 || z1 < 0 || x1 + 1 >= g.res[0] || y1 + 1 >= g.res[1] || z1 + 1 >= g.res[2]) return 0.0f;
+    // x2 = x1 + 1 >= res, written so that it cannot wrap: v_cvt_i32_f32 saturates, a coordinate of +inf (or >= 2^31) gives
+    // x1 = INT_MAX, and INT_MAX + 1 would pass the test and fetch from a wild address
+    if (x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1) return 0.0f;
     const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
                 _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
     const int base = (z1 * g.res[1] + y1) * g.res[0] + x1;
@@ -135,7 +137,7 @@ __device__ __forceinline__ float lookup_float(const DGrid &g, f3 p, int *idx4 = 
 __device__ __forceinline__ f3 lookup_spectrum(const DGrid &g, f3 p) {
     const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
     const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
-    if (x1 < 0 || y1 < 0 || z1 < 0 || x1 + 1 >= g.res[0] || y1 + 1 >= g.res[1] || z1 + 1 >= g.res[2]) return f3(0, 0, 0);
+    if (x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1) return f3(0, 0, 0);   // as lookup_float
     const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
                 _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
     const int base = (z1 * g.res[1] + y1) * g.res[0] + x1, sy = g.res[0], sz = g.res[0] * g.res[1];

@@ -169,6 +169,29 @@ __device__ __forceinline__ void queue_push(const SegQueue &q, uint32_t row, bool
         if (pred) q.items[(size_t) seg * q.segcap + base + (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL))] = i;
     }
 }
+// Event queue: the same segments, but grouped by event class (MER_NSEG / MER_EV_CLASSES segments per class), so that the
+// concatenation K_event sweeps is sorted by class and every wave but the few on a class boundary runs ONE branch of the
+// state machine (collision / end of an NEE walk / end of a look-up walk / end of a free flight) instead of their union.
+// One round trip: lane c issues the atomic of class c.
+#define MER_EV_CLASSES 4
+__device__ __forceinline__ void queue_push_class(const SegQueue &q, uint32_t row, bool pred, uint32_t i, int cls) {
+    constexpr uint32_t SPC = MER_NSEG / MER_EV_CLASSES;
+    const unsigned long long any = __ballot(pred);
+    if (any) {
+        const int lane = threadIdx.x & 63;
+        const uint32_t wave = (blockIdx.x * MER_BLOCK + threadIdx.x) >> 6;
+        const unsigned long long m0 = __ballot(pred && cls == 0), m1 = __ballot(pred && cls == 1), m2 = __ballot(pred && cls == 2),
+                                 m3 = any & ~(m0 | m1 | m2);
+        const unsigned long long lane_mask = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+        uint32_t base = 0;
+        if (lane < MER_EV_CLASSES && lane_mask)
+            base = atomicAdd(q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG + (uint32_t) lane * SPC + (wave & (SPC - 1)), (uint32_t) __popcll(lane_mask));
+        const int c = cls < 0 ? 0 : (cls > 3 ? 3 : cls);
+        base = (uint32_t) __shfl((int) base, c, 64);
+        const unsigned long long mine = c == 0 ? m0 : (c == 1 ? m1 : (c == 2 ? m2 : m3));
+        if (pred) q.items[(size_t) ((uint32_t) c * SPC + (wave & (SPC - 1))) * q.segcap + base + (uint32_t) __popcll(mine & ((1ULL << lane) - 1ULL))] = i;
+    }
+}
 __device__ __forceinline__ uint32_t queue_total(const SegQueue &q, uint32_t row) {
     const uint32_t *c = q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG;
     uint32_t t = 0;
@@ -205,7 +228,7 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
     const uint32_t count = queue_total(P.mq[pass & 1u], pass);
     LaneCounters C; C.clear();
     uint32_t iters = 0, i = 0;
-    bool has_event = false, still_marching = false;
+    bool has_event = false, still_marching = false; int ev_class = 0;
     if (j < count) {
         i = queue_item(P.mq[pass & 1u], pass, j);
         uint32_t fl;
@@ -223,10 +246,11 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
         }
         store_hot(P, i, ST_MARCH, ev, W, rng, pixel, sample, sigma);
         has_event = ev != EV_NONE;
+        ev_class = ev == EV_REAL ? 0 : (W.kind == K_NEE ? 1 : (W.kind == K_LOOKUP ? 2 : 3));
         still_marching = !has_event;
     }
-    // compaction: lanes parked on an event go to K_event's queue, the others straight to the next march list
-    queue_push(P.eq, pass + 1, has_event, i);
+    // compaction: lanes parked on an event go to K_event's queue (by class), the others straight to the next march list
+    queue_push_class(P.eq, pass + 1, has_event, i, ev_class);
     queue_push(P.mq[(pass + 1) & 1u], pass + 1, still_marching, i);
     // lane-slot accounting: every lane of the wave is held for as many trips as its slowest lane
     uint32_t wave_iters = iters;
@@ -594,7 +618,7 @@ __global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P
         SLOT(CO_LX) = __float_as_uint(SLOTF(CO_LX) + c.x); SLOT(CO_LY) = __float_as_uint(SLOTF(CO_LY) + c.y); SLOT(CO_LZ) = __float_as_uint(SLOTF(CO_LZ) + c.z);
         SLOT(H_RNG_LO) = (uint32_t) rng.state; SLOT(H_RNG_HI) = (uint32_t) (rng.state >> 32);
     }
-    queue_push(P.eq, pass + 1, mine, i);            // resumes at EV_PHASE2 in K_event of the next pass
+    queue_push_class(P.eq, pass + 1, mine, i, 1);   // resumes at EV_PHASE2 in K_event of the next pass (with the ends of NEE walks)
     flush_counters(P, C, 0);
 }
 

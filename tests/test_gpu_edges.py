@@ -84,3 +84,21 @@ def test_large_sample_indices_are_distinct_streams(ctx, orc):
     assert _agree(a, b) > 0.98 and not np.array_equal(a, ctx.render_paths(sc, 0, seed=1))
     for vv in vols:
         vv.destroy()
+
+
+def test_lookups_at_infinite_and_huge_coordinates_are_outside_the_grid(ctx, orc):
+    """float -> int conversion saturates on the GPU (+inf and anything >= 2^31 become INT_MAX): the bounds test of lookupFloat /
+    lookupSpectrum must not wrap to "inside" and fetch from a wild address.  Such points are outside the grid: value 0, linear index -1."""
+    rng = np.random.default_rng(5)
+    d = rng.random((6, 7, 8)).astype(np.float32); rgb = rng.random((6, 7, 8, 3)).astype(np.float32)
+    lo, hi = [0, 0, 0], [1, 1, 1]
+    big = [np.inf, 3e9, 1e30, 3.4e38, -np.inf, -3e9, -1e30]
+    pts = np.array([[b if a == k else 0.5 for a in range(3)] for b in big for k in range(3)] + [[np.inf] * 3, [0.5, 0.5, 0.5]], np.float32)
+    v = ctx.upload_volume(d, lo, hi); c = ctx.upload_volume(rgb, lo, hi)
+    val, idx = ctx.lookup_trilinear(v, pts)
+    oval, oidx = orc.lookup_trilinear(d, lo, hi, pts)
+    assert (val[:-1] == 0).all() and (idx[:-1, 3] == -1).all() and val[-1] == oval[-1] and idx[-1, 3] == oidx[-1, 3] >= 0
+    assert (oval[:-1] == 0).all()
+    out = ctx.lookup_trilinear_rgb(c, pts)
+    assert (out[:-1] == 0).all() and np.array_equal(out[-1], orc.lookup_trilinear_rgb(rgb, lo, hi, pts)[-1])
+    v.destroy(); c.destroy()
