@@ -624,6 +624,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
             q->items = nullptr;
             q->segcap = 2u * (want / MER_NSEG) + 256u;          // two producer kernels may feed one segment
             if (q == &ctx->eq) q->segcap = 2u * (want / (MER_NSEG / MER_EV_CLASSES)) + 256u;   // every lane may be of one event class
+            if (q == &ctx->mq[0] || q == &ctx->mq[1]) q->segcap = 2u * (want / (MER_NSEG / MER_MQ_CLASSES)) + 256u;   // ... or of one march class
             HIP_CHECK(ctx, hipMalloc((void **) &q->items, (size_t) q->segcap * MER_NSEG * sizeof(uint32_t)));
             if (!q->counts) HIP_CHECK(ctx, hipMalloc((void **) &q->counts, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t)));
         }
@@ -641,7 +642,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     if (need_slots < nslots) nslots = (uint32_t) need_slots;
     P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.eq = ctx->eq; P.mq[0] = ctx->mq[0]; P.mq[1] = ctx->mq[1]; P.sq[0] = ctx->sq[0]; P.sq[1] = ctx->sq[1]; P.cq = ctx->cq;
     P.hitq = ctx->hitq; P.hitq_cap = ctx->hitq_cap; P.hitq_ctr = ctx->hitq_ctr; P.gen_iters = 8; P.gen_all = getenv("MER_GEN_ALL") ? 1 : 0;
-    P.ksteps = 96;            // eikonal steps per lane per pass (48..128 measured; 96: fewest K_event passes without stretching K_march tails)
+    P.ksteps = 128;           // eikonal steps per lane per pass (64..256 measured with class-sorted march lists: 128 is the flat optimum at 256^3 and 512^3)
     { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) P.ksteps = atoi(e); }
     HIP_CHECK(ctx, hipMemsetAsync(ctx->slots, 0, (size_t) nslots * MER_SLOT_WORDS * sizeof(uint32_t), ctx->stream));
     HIP_CHECK(ctx, hipMemsetAsync(ctx->live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));

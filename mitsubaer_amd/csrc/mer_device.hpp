@@ -425,7 +425,7 @@ __device__ __forceinline__ float phase_sample(int kind, float g, f3 wi, float sx
 
 // ------------------------------------------------------------------------------------------------
 // A segmented work list (mer_wavefront.hpp)
-#define MER_NSEG 16
+#define MER_NSEG 32
 struct SegQueue {
     uint32_t *items;          // [MER_NSEG][segcap]
     uint32_t *counts;         // [MER_LIVE_SLOTS][MER_NSEG], row = pass & (MER_LIVE_SLOTS-1)

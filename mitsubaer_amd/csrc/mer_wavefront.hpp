@@ -169,28 +169,63 @@ __device__ __forceinline__ void queue_push(const SegQueue &q, uint32_t row, bool
         if (pred) q.items[(size_t) seg * q.segcap + base + (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL))] = i;
     }
 }
-// Event queue: the same segments, but grouped by event class (MER_NSEG / MER_EV_CLASSES segments per class), so that the
-// concatenation K_event sweeps is sorted by class and every wave but the few on a class boundary runs ONE branch of the
-// state machine (collision / end of an NEE walk / end of a look-up walk / end of a free flight) instead of their union.
-// One round trip: lane c issues the atomic of class c.
+// Class-sorted lists: the same segments, grouped by a class of the item (MER_NSEG / NCLS segments per class), so that the
+// concatenation the consumer sweeps is sorted by class.  One round trip: lane c issues the atomic of class c.
+//  * event queue (NCLS = MER_EV_CLASSES): every wave but the few on a class boundary runs ONE branch of K_event's state machine
+//    (collision / end of an NEE walk / end of a look-up walk / end of a free flight) instead of their union;
+//  * march lists (NCLS = MER_MQ_CLASSES): lanes are grouped by the estimated number of steps until their ray leaves the shape, so
+//    the lanes of a wave park at about the same trip of K_march's loop instead of idling until the slowest one has.
 #define MER_EV_CLASSES 4
+#define MER_MQ_CLASSES 8
+template <int NCLS>
 __device__ __forceinline__ void queue_push_class(const SegQueue &q, uint32_t row, bool pred, uint32_t i, int cls) {
-    constexpr uint32_t SPC = MER_NSEG / MER_EV_CLASSES;
+    constexpr uint32_t SPC = MER_NSEG / NCLS;
+    static_assert(SPC >= 1 && SPC * NCLS == MER_NSEG, "classes must divide the segments");
     const unsigned long long any = __ballot(pred);
     if (any) {
         const int lane = threadIdx.x & 63;
         const uint32_t wave = (blockIdx.x * MER_BLOCK + threadIdx.x) >> 6;
-        const unsigned long long m0 = __ballot(pred && cls == 0), m1 = __ballot(pred && cls == 1), m2 = __ballot(pred && cls == 2),
-                                 m3 = any & ~(m0 | m1 | m2);
-        const unsigned long long lane_mask = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : m3));
+        const int c = cls < 0 ? 0 : (cls >= NCLS ? NCLS - 1 : cls);
+        unsigned long long mine = 0, lane_mask = 0;
+#pragma unroll
+        for (int k = 0; k < NCLS; k++) {
+            const unsigned long long m = __ballot(pred && c == k);
+            if (c == k) mine = m;
+            if (lane == k) lane_mask = m;
+        }
         uint32_t base = 0;
-        if (lane < MER_EV_CLASSES && lane_mask)
+        if (lane < NCLS && lane_mask)
             base = atomicAdd(q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG + (uint32_t) lane * SPC + (wave & (SPC - 1)), (uint32_t) __popcll(lane_mask));
-        const int c = cls < 0 ? 0 : (cls > 3 ? 3 : cls);
         base = (uint32_t) __shfl((int) base, c, 64);
-        const unsigned long long mine = c == 0 ? m0 : (c == 1 ? m1 : (c == 2 ? m2 : m3));
         if (pred) q.items[(size_t) ((uint32_t) c * SPC + (wave & (SPC - 1))) * q.segcap + base + (uint32_t) __popcll(mine & ((1ULL << lane) - 1ULL))] = i;
     }
+}
+// Class of a marching lane: 0 = at least one whole pass (ksteps trips) left before the ray can leave the shape, 1 .. 7 = sevenths
+// of a pass, longest first (the long waves of a launch start first).  Curved rays: the chord to the boundary along the current
+// direction over the step size (the bench scene's rays bend by ~0.1 rad per unit length: good to ~10 %); straight rays: the
+// expected number of tentative collisions up to tmax.  The signed-distance boundary is not estimated (class 0).
+template <bool CURVED, int BND, class WalkT>
+__device__ __forceinline__ int march_class(const Params &P, const WalkT &W) {
+    if (BND != 0) return 0;
+    const mer_scene_desc &S = P.sc;
+    float r;
+    if (CURVED) {
+        const float vv = dot(W.v, W.v);
+        float dist;
+        if (S.boundary == MER_BOUNDARY_SPHERE) {
+            const f3 q(W.p.x - S.sph_center[0], W.p.y - S.sph_center[1], W.p.z - S.sph_center[2]);
+            const float b = dot(q, W.v) * __builtin_amdgcn_rsqf(vv), c0 = dot(q, q) - S.sph_radius * S.sph_radius;
+            dist = sqrtf(fmaxf(b * b - c0, 0.0f)) - b;
+        } else {
+            const float tx = ((W.v.x > 0 ? S.bmax[0] : S.bmin[0]) - W.p.x) * __builtin_amdgcn_rcpf(W.v.x),
+                        ty = ((W.v.y > 0 ? S.bmax[1] : S.bmin[1]) - W.p.y) * __builtin_amdgcn_rcpf(W.v.y),
+                        tz = ((W.v.z > 0 ? S.bmax[2] : S.bmin[2]) - W.p.z) * __builtin_amdgcn_rcpf(W.v.z);
+            dist = fminf(fminf(tx, ty), tz) * sqrtf(vv);
+        }
+        r = dist * __builtin_amdgcn_rcpf(S.stepsize);
+    } else r = (W.tmax - W.t) * __builtin_amdgcn_rcpf(P.inv_max_density);
+    const float f = r * ((float) (MER_MQ_CLASSES - 1) * __builtin_amdgcn_rcpf((float) P.ksteps));
+    return f >= (float) (MER_MQ_CLASSES - 1) ? 0 : (MER_MQ_CLASSES - 1) - (int) fmaxf(f, 0.0f);
 }
 __device__ __forceinline__ uint32_t queue_total(const SegQueue &q, uint32_t row) {
     const uint32_t *c = q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG;
@@ -228,7 +263,7 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
     const uint32_t count = queue_total(P.mq[pass & 1u], pass);
     LaneCounters C; C.clear();
     uint32_t iters = 0, i = 0;
-    bool has_event = false, still_marching = false; int ev_class = 0;
+    bool has_event = false, still_marching = false; int ev_class = 0, mq_class = 0;
     if (j < count) {
         i = queue_item(P.mq[pass & 1u], pass, j);
         uint32_t fl;
@@ -247,11 +282,12 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
         store_hot(P, i, ST_MARCH, ev, W, rng, pixel, sample, sigma);
         has_event = ev != EV_NONE;
         ev_class = ev == EV_REAL ? 0 : (W.kind == K_NEE ? 1 : (W.kind == K_LOOKUP ? 2 : 3));
+        mq_class = march_class<CURVED, BND>(P, W);
         still_marching = !has_event;
     }
     // compaction: lanes parked on an event go to K_event's queue (by class), the others straight to the next march list
-    queue_push_class(P.eq, pass + 1, has_event, i, ev_class);
-    queue_push(P.mq[(pass + 1) & 1u], pass + 1, still_marching, i);
+    queue_push_class<MER_EV_CLASSES>(P.eq, pass + 1, has_event, i, ev_class);
+    queue_push_class<MER_MQ_CLASSES>(P.mq[(pass + 1) & 1u], pass + 1, still_marching, i, mq_class);
     // lane-slot accounting: every lane of the wave is held for as many trips as its slowest lane
     uint32_t wave_iters = iters;
 #pragma unroll
@@ -283,7 +319,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
     queue_clear_row(P.eq, pass + 2, j); queue_clear_row(P.mq[pass & 1u], pass + 2, j); queue_clear_row(P.sq[pass & 1u], pass + 2, j);
     if (EXTRA && CURVED) queue_clear_row(P.cq, pass + 2, j);
     LaneCounters C; C.clear();
-    bool marching = false, starved_out = false, connecting = false; uint32_t i = 0;
+    bool marching = false, starved_out = false, connecting = false; uint32_t i = 0; int mq_class = 0;
     if (j < count) {
     i = pass == 0 ? j : (j < nq ? queue_item(P.eq, pass, j) : queue_item(P.sq[pass & 1u], pass, j - nq));
     const uint32_t fl = SLOT(H_FLAGS);
@@ -582,10 +618,11 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
         SLOT(CO_SDENS) = __float_as_uint(W.sdens); SLOT(CO_TMIN) = __float_as_uint(W.tmin);
         SLOT(CO_PLEN) = __float_as_uint(plen); SLOT(CO_TROPT) = __float_as_uint(trOpt); if (EXTRA) SLOT(CO_ETA) = __float_as_uint(etaPath);
         marching = !connecting;
+        mq_class = march_class<CURVED, BND>(P, W);
     }
     }   // j < count
     if (EXTRA && CURVED) queue_push(P.cq, pass, connecting, i);
-    queue_push(P.mq[pass & 1u], pass, marching, i);
+    queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class);
     queue_push(P.sq[(pass + 1) & 1u], pass + 1, starved_out, i);
     flush_counters(P, C, 0);
 }
@@ -618,7 +655,7 @@ __global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P
         SLOT(CO_LX) = __float_as_uint(SLOTF(CO_LX) + c.x); SLOT(CO_LY) = __float_as_uint(SLOTF(CO_LY) + c.y); SLOT(CO_LZ) = __float_as_uint(SLOTF(CO_LZ) + c.z);
         SLOT(H_RNG_LO) = (uint32_t) rng.state; SLOT(H_RNG_HI) = (uint32_t) (rng.state >> 32);
     }
-    queue_push_class(P.eq, pass + 1, mine, i, 1);   // resumes at EV_PHASE2 in K_event of the next pass (with the ends of NEE walks)
+    queue_push_class<MER_EV_CLASSES>(P.eq, pass + 1, mine, i, 1);   // resumes at EV_PHASE2 in K_event of the next pass (with the ends of NEE walks)
     flush_counters(P, C, 0);
 }
 
