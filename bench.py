@@ -103,7 +103,8 @@ def main():
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--spp", type=int, default=256)
-    ap.add_argument("--layout", default="brick27", choices=["dense", "cell8", "brick27", "brick125"])
+    ap.add_argument("--layout", default="auto", choices=["auto", "dense", "cell8", "brick27", "brick125"],
+                    help="HBM layout of the trilinear RIF (auto: brick27 up to 2^28 nodes, cell8 above)")
     ap.add_argument("--shard", default="samples", choices=["samples", "tiles"])
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force this GPU index for every rank (rehearsal on one GPU)")
@@ -128,6 +129,8 @@ def main():
     p, desc = build_workload(args.workload, args.res, args.size, args.spp)
     ctx = capi.Context(local)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.layout == "auto":
+        args.layout = "brick27" if args.res ** 3 <= 1 << 28 else "cell8"
     layout = {"cell8": capi.LAYOUT_CELL8, "brick27": capi.LAYOUT_BRICK27, "brick125": capi.LAYOUT_BRICK125, "dense": capi.LAYOUT_DENSE}[args.layout]
     sc, vols = ctx.upload_scene(p, layout=layout)
     film = torch.zeros((p.height, p.width, 5), dtype=torch.float32, device=dev)

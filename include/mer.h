@@ -40,7 +40,9 @@ enum { MER_ALBEDO_CONST = 0, MER_ALBEDO_GRID = 1 };
 /* device layouts of a 1-channel float32 grid (the index contract stays (x,y,z)): DENSE = the VOL payload; CELL8 = the 8 corners of every
    cell in one 32-byte record; BRICK27 = the 3x3x3 corners of every 2x2x2-cell brick in one 128-byte record (one cache line serves
    eight cells: half the memory requests of CELL8 along a ray).  CELL8 / BRICK27 are for the refractive-index field. */
-enum { MER_LAYOUT_DENSE = 0, MER_LAYOUT_CELL8 = 1, MER_LAYOUT_BRICK27 = 2, MER_LAYOUT_BRICK125 = 3 /* 4x4x4-cell bricks: 5x5x5 corners per 512-byte record */ };
+enum { MER_LAYOUT_DENSE = 0, MER_LAYOUT_CELL8 = 1, MER_LAYOUT_BRICK27 = 2, MER_LAYOUT_BRICK125 = 3 /* 4x4x4-cell bricks: 5x5x5 corners per 512-byte record */,
+       MER_LAYOUT_AUTO = 4 /* 1-channel float32 grids: BRICK27 up to 2^28 nodes (the records stay near the caches), CELL8 above (half the
+                              bytes per fetch once every fetch goes to HBM; measured 256^3 .. 1024^3); other grids: DENSE */ };
 
 /* replaces GridDataSource::loadFromFile header fields (src/volume/gridvolume.cpp:217-287) */
 typedef struct {
@@ -100,6 +102,12 @@ typedef struct {
        inside :481).  Camera rays find it by sphere tracing, the dielectric normal is the normalized gradient (:980-984).
        mer_render only; the leaf entry points know the cube / sphere boundaries. */
     mer_volume sdf;
+    /* `aggressivetracing` of heterogeneousrefractive (src/medium/heterogeneousrefractive.cpp:230,473-493,697-704): with the
+       signed-distance boundary, a trace of length s first advances, WITHOUT inside tests, by min(depth below the surface -
+       sdf_max_error, distance left) as long as that depth is at least Epsilon (1e-4), each such leg being int(d/h) full steps plus
+       the remainder step, and walks what is left with the ordinary tested trace.  sdf_max_error = the volume's maxSDFError(). */
+    int32_t aggressive_tracing;
+    float   sdf_max_error;
 } mer_scene_desc;
 enum { MER_BSDF_NULL = 0, MER_BSDF_HDIELECTRIC = 1 };
 enum { MER_MODULATION_NONE = 0, MER_MODULATION_SINE, MER_MODULATION_SQUARE, MER_MODULATION_HAMILTONIAN, MER_MODULATION_MSEQ,

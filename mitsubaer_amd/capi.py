@@ -11,7 +11,7 @@ _LIB = None
 
 C_PATHS, C_STEPS, C_RIF_EVALS, C_TENTATIVE, C_REAL, C_SEGMENTS, C_NEE, C_LOOP_ITERS, C_ACTIVE_LANES = range(9)
 C_COUNT = 16
-LAYOUT_DENSE, LAYOUT_CELL8, LAYOUT_BRICK27, LAYOUT_BRICK125 = 0, 1, 2, 3
+LAYOUT_DENSE, LAYOUT_CELL8, LAYOUT_BRICK27, LAYOUT_BRICK125, LAYOUT_AUTO = 0, 1, 2, 3, 4
 
 # every symbol include/mer.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
@@ -56,6 +56,8 @@ class SceneDesc(C.Structure):
         ("modulation", C.c_int32), ("mod_lambda", C.c_float), ("mod_phase_deg", C.c_float), ("mod_P", C.c_int32), ("mod_neighbors", C.c_int32),
         ("boundary_bsdf", C.c_int32),
         ("sdf", C.c_int32),
+        ("aggressive_tracing", C.c_int32),
+        ("sdf_max_error", C.c_float),
     ]
 
 
@@ -213,6 +215,7 @@ class Context:
         s.modulation = p.modulation; s.mod_lambda = p.mod_lambda; s.mod_phase_deg = p.mod_phase_deg; s.mod_P = p.mod_P; s.mod_neighbors = p.mod_neighbors
         s.boundary_bsdf = p.boundary_bsdf
         s.sdf = sdf.handle if sdf is not None else 0
+        s.aggressive_tracing = int(p.aggressive_tracing); s.sdf_max_error = P.sdf_max_error(p)
         return s
 
     def upload_scene(self, p, layout=LAYOUT_DENSE, rif_layout=None):
@@ -220,7 +223,7 @@ class Context:
         vols = []
         dens = alb = rif = None
         if p.sigma_mode == P.SIGMA_GRID and p.density is not None:
-            dl = LAYOUT_CELL8 if layout in (LAYOUT_BRICK27, LAYOUT_BRICK125) else layout   # bricks are the RIF's layout; sigma_t keeps its cell records
+            dl = LAYOUT_CELL8 if layout in (LAYOUT_BRICK27, LAYOUT_BRICK125, LAYOUT_AUTO) else layout   # bricks are the RIF's layout; sigma_t keeps its cell records
             dens = self.upload_volume(p.density, p.density_aabb[0], p.density_aabb[1], dl if np.asarray(p.density).dtype != np.uint8 else LAYOUT_DENSE)
             vols.append(dens)
         if p.albedo_mode == P.ALBEDO_GRID and p.albedo_grid is not None:

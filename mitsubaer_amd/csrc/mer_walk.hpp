@@ -38,7 +38,10 @@ struct Walk {
     int   kind;
     int   backstep;              // 1 => the next step is the step back after leaving the shape (trace(): :678-681)
     float hprev;
+    int   agg;                   // `aggressivetracing` (BND = 1 only): 1 => the current leg takes its steps without inside tests
+    float dleft;                 //   ... and this much of the segment is left after it
     CellCache cc;                // RIF cell cache (trilinear)
+    static constexpr int kBND = BND;
 
     __device__ __forceinline__ f3 pos() const { return CURVED ? p : p + v * t; }
 
@@ -64,6 +67,25 @@ struct Walk {
         rem = s - steps * h;
         steps_left = steps;
         seg_inf = 0;
+        agg = 0;
+        if (BND == 1 && P.sc.aggressive_tracing) agg_next(P, s);
+    }
+    // aggressivetracing (heterogeneousrefractive.cpp:476-493): while the point is at least Epsilon below the surface (less the SDF's
+    // error bound), the next leg of min(depth, distance left) is walked by aggressive_trace (:697-704: int(d/h) full steps + the
+    // remainder step, no inside tests); what is left afterwards is an ordinary tested trace().
+    __device__ __forceinline__ void agg_next(const Params &P, float dist_left) {
+        const float h = P.sc.stepsize;
+        if (dist_left > MER_EPSILON) {
+            const float depth = -sdf_value(P, p) - P.sc.sdf_max_error;
+            if (!(depth < MER_EPSILON)) {
+                const float d = fminf(depth, dist_left);
+                const int steps = (int) (d / h);
+                rem = d - steps * h; steps_left = steps; agg = 1; dleft = dist_left - d;
+                return;
+            }
+        }
+        const int steps = (int) (dist_left / h);
+        rem = dist_left - steps * h; steps_left = steps; agg = 0; dleft = 0.0f;
     }
     __device__ __forceinline__ void draw_segment(const Params &P, Rng &rng) {      // heterogeneous.cpp:634
         set_segment(P, -logf(1 - rng.next1D()) * P.inv_max_density);
@@ -74,7 +96,7 @@ struct Walk {
     __device__ __forceinline__ int begin(const Params &P, Rng &rng, LaneCounters &C, int k, f3 o, f3 d, float rayMaxt, bool first_walk = true) {
         kind = k;
         if (first_walk) { trsum = 0.0f; walk = 0; }
-        Tr = 1.0f; dist = 0.0f; opt = 0.0f; backstep = 0;
+        Tr = 1.0f; dist = 0.0f; opt = 0.0f; backstep = 0; agg = 0; dleft = 0.0f;
         if (CURVED) {
             p = o; v = d;
             if (RIF == MER_RIF_BSPLINE3 && !inside_volume_limits(P.rif, p)) return EV_GATE_FAIL;   // heterogeneousrefractive.cpp:461-466
@@ -129,6 +151,12 @@ struct Walk {
                 backstep = 0;
                 if (seg_inf) dist -= hprev;                                   // traceTillBoundary :757-759 (as shipped)
                 return EV_EXITED;
+            }
+            if (BND == 1 && agg) {                                             // a leg of aggressive_trace: no inside test
+                dist += h;
+                if (full) { steps_left--; return EV_NONE; }
+                agg_next(P, dleft);                                           // leg done: the next one, or the tested trace of the rest
+                return EV_NONE;
             }
             if (!inside_shape_b<BND>(P, p)) { backstep = 1; hprev = h; return EV_NONE; }   // (:678-681)
             dist += h;

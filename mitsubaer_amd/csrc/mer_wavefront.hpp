@@ -22,10 +22,10 @@ enum { CO_PXF = H_COUNT, CO_PYF, CO_LX, CO_LY, CO_LZ, CO_TX, CO_TY, CO_TZ, CO_DE
        CO_DSX, CO_DSY, CO_DSZ, CO_DDX, CO_DDY, CO_DDZ, CO_WIX, CO_WIY, CO_WIZ, CO_PHASEPDF, CO_ITST, CO_N0, CO_TRSUM,
        CO_SDENS, CO_TMIN, CO_WNEXT_LO, CO_WNEXT_HI, CO_WLEFT, CO_PLEN, CO_TROPT, CO_ETA, SLOT_WORDS };
 
-// H_FLAGS: st[1:0] ev[5:2] kind[7:6] seg_inf[8] backstep[9] walk[11:10]
-__device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg_inf, int backstep, int walk) {
+// H_FLAGS: st[1:0] ev[5:2] kind[7:6] seg_inf[8] backstep[9] walk[11:10] agg[12]
+__device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg_inf, int backstep, int walk, int agg) {
     return (uint32_t) st | ((uint32_t) ev << 2) | ((uint32_t) kind << 6) | ((uint32_t) seg_inf << 8) | ((uint32_t) backstep << 9) |
-           ((uint32_t) walk << 10);
+           ((uint32_t) walk << 10) | ((uint32_t) agg << 12);
 }
 
 // Slot i is one 256-byte record: words [0,20) hot, [20,48) cold, rest padding.  Lanes reach their slot through the
@@ -51,6 +51,7 @@ __device__ __forceinline__ void load_hot(const Params &P, uint32_t i, uint32_t &
     rng.state = (uint64_t) d.w | ((uint64_t) e.x << 32);
     pixel = e.y; sample = e.z; sigma = __uint_as_float(e.w);
     W.kind = (fl >> 6) & 3; W.seg_inf = (fl >> 8) & 1; W.backstep = (fl >> 9) & 1; W.walk = (fl >> 10) & 3;
+    W.agg = (fl >> 12) & 1; W.dleft = sigma;              // a marching lane keeps the rest of its aggressive segment in the sigma word
     rng.inc = (((((uint64_t) sample) << 32) | (uint64_t) pixel) << 1) | 1ULL;
 }
 template <class WalkT>
@@ -60,9 +61,10 @@ __device__ __forceinline__ void store_hot(const Params &P, uint32_t i, int st, i
     r[0] = make_uint4(__float_as_uint(W.p.x), __float_as_uint(W.p.y), __float_as_uint(W.p.z), __float_as_uint(W.v.x));
     r[1] = make_uint4(__float_as_uint(W.v.y), __float_as_uint(W.v.z), __float_as_uint(W.opt), __float_as_uint(W.dist));
     r[2] = make_uint4(__float_as_uint(W.rem), __float_as_uint(W.hprev), __float_as_uint(W.Tr), __float_as_uint(W.t));
-    r[3] = make_uint4(__float_as_uint(W.tmax), (uint32_t) W.steps_left, pack_flags(st, ev, W.kind, W.seg_inf, W.backstep, W.walk),
+    const bool agg = WalkT::kBND == 1 && W.agg != 0;
+    r[3] = make_uint4(__float_as_uint(W.tmax), (uint32_t) W.steps_left, pack_flags(st, ev, W.kind, W.seg_inf, W.backstep, W.walk, agg ? 1 : 0),
                       (uint32_t) rng.state);
-    r[4] = make_uint4((uint32_t) (rng.state >> 32), pixel, sample, __float_as_uint(sigma));
+    r[4] = make_uint4((uint32_t) (rng.state >> 32), pixel, sample, __float_as_uint((WalkT::kBND == 1 && ev == EV_NONE) ? W.dleft : sigma));
 }
 
 // Counter flush: one set of atomics per wave, spread over MER_COUNTER_REPLICAS copies (summed on the host) so that a
@@ -206,7 +208,7 @@ __device__ __forceinline__ void queue_push_class(const SegQueue &q, uint32_t row
 // expected number of tentative collisions up to tmax.  The signed-distance boundary is not estimated (class 0).
 template <bool CURVED, int BND, class WalkT>
 __device__ __forceinline__ int march_class(const Params &P, const WalkT &W) {
-    if (BND != 0) return 0;
+    if (BND != 0 || !P.mq_sort) return 0;
     const mer_scene_desc &S = P.sc;
     float r;
     if (CURVED) {
@@ -363,6 +365,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
     } else {
         W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = 0; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.dist = 0;
         W.opt = 0; W.sdens = 0; W.Tr = 1; W.trsum = 0; W.walk = 0; W.p = f3(0, 0, 0); W.v = f3(0, 0, 1); W.backstep = 0; W.hprev = 0;
+        W.agg = 0; W.dleft = 0;
         rng.state = 0; rng.inc = 1;
     }
 

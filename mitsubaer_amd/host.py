@@ -37,7 +37,7 @@ def flatten_xml(path, defines=None):
     return d, spp.value
 
 
-def render_xml(path, defines=None, device=0, spp=0, seed=0, layout=capi.LAYOUT_BRICK27):
+def render_xml(path, defines=None, device=0, spp=0, seed=0, layout=capi.LAYOUT_AUTO):
     d, _ = flatten_xml(path, defines)
     frames = int(np.ceil((d.max_bound - d.min_bound) / d.bin_width)) if (d.decomposition and not d.modulation) else 1
     film = np.zeros((d.height, d.width, frames * 3 + 2), np.float32)

@@ -280,7 +280,7 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
                 o->stepsize = props.getFloat("stepsize", 1e-3f);                                           // heterogeneousrefractive.cpp:208
                 o->scale = scale;
                 (void) props.getFloat("tol2", 1e-6f); (void) props.getFloat("rrweight", 1e-2f); (void) props.getInteger("boundaryprecision", 3);
-                if (props.getBoolean("aggressivetracing", false)) Log_EError("aggressivetracing needs an SDF volume: not supported on the GPU path yet");
+                o->aggressiveTracing = props.getBoolean("aggressivetracing", false);                       // :230
             }
         } else if (type == "heterogeneous") {                                                              // heterogeneous.cpp:183-202
             if (props.hasProperty("sigmaS") || props.hasProperty("sigmaA"))
@@ -640,6 +640,14 @@ void Integrator::flatten(const Scene &scene, mer_scene_desc &d) const {
     d.rif_mode = MER_RIF_CONST; d.rif_const = 1.0f;
     if (m.rif) d.rif_mode = m.rif->isSpline() ? MER_RIF_BSPLINE3 : MER_RIF_TRILINEAR;
     d.stepper = m.stepper; d.stepsize = m.stepsize;
+    d.aggressive_tracing = 0; d.sdf_max_error = 0.0f;
+    if (m.aggressiveTracing) {
+        if (!m.sdf) Log_EError("aggressivetracing needs the medium's `sdf` volume");
+        d.aggressive_tracing = 1;
+        double e2 = 0;                                                       // maxSDFError(): one voxel diagonal (splinevolume.cpp:282)
+        for (int i = 0; i < 3; i++) { const double st = ((double) m.sdf->aabb_max[i] - m.sdf->aabb_min[i]) / (m.sdf->res[i] - 1); e2 += st * st; }
+        d.sdf_max_error = (float) std::sqrt(e2);
+    }
     d.phase = m.phase->kind; d.g = m.phase->g;
     d.tr_estimator = m.trEstimator;
     int nconst = 0, npoint = 0;

@@ -115,6 +115,7 @@ public:
     int strategy = MER_STRATEGY_BALANCE, channel = -1; float samplingDensity = 0, mediumSamplingWeight = -1;
     float scale = 1.0f;                        // heterogeneous `scale`
     float stepsize = 1e-3f;                    // heterogeneousrefractive `stepsize`
+    bool aggressiveTracing = false;            // heterogeneousrefractive `aggressivetracing` (needs the `sdf` child)
     int stepper = MER_STEP_VERLET, trEstimator = MER_TR_WOODCOCK2;
     Spectrum emission{};
     std::shared_ptr<VolumeDataSource> density, albedo, rif, sdf;

@@ -8,7 +8,7 @@
 int main(int argc, char **argv) {
     std::map<std::string, std::string> defines;
     std::string out = "out.npy", scenePath;
-    int spp = 0, device = 0, layout = MER_LAYOUT_BRICK27; unsigned long long seed = 0; bool raw = false;
+    int spp = 0, device = 0, layout = MER_LAYOUT_AUTO; unsigned long long seed = 0; bool raw = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "-D" && i + 1 < argc) { std::string kv = argv[++i]; size_t q = kv.find('='); if (q == std::string::npos) { std::fprintf(stderr, "-D expects key=value\n"); return 2; } defines[kv.substr(0, q)] = kv.substr(q + 1); }

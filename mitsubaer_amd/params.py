@@ -55,6 +55,8 @@ class SceneParams:
         self.bmin = [-1.0, -1.0, -1.0]; self.bmax = [1.0, 1.0, 1.0]
         self.sph_center = [0.0, 0.0, 0.0]; self.sph_radius = 1.0
         self.sdf = None; self.sdf_aabb = ([-1, -1, -1], [1, 1, 1])    # BOUNDARY_SDF: signed-distance grid, negative inside
+        self.aggressive_tracing = False; self.sdf_max_error = None    # `aggressivetracing`: untested legs while deep inside the SDF shape;
+        #                                                               None = the volume's maxSDFError(): one voxel diagonal (splinevolume.cpp:282)
         # medium
         self.sigma_mode = SIGMA_GRID
         self.sigma_a = [0.05, 0.05, 0.05]; self.sigma_s = [0.5, 3.5, 7.5]
@@ -90,3 +92,16 @@ class SceneParams:
                 raise AttributeError("unknown scene parameter '%s'" % k)
             setattr(q, k, v)
         return q
+
+
+def sdf_max_error(p):
+    """maxSDFError() of the scene's signed-distance volume: the diagonal of one voxel (src/volume/splinevolume.cpp:282), unless given."""
+    if p.sdf_max_error is not None:
+        return float(p.sdf_max_error)
+    if p.sdf is None:
+        return 0.0
+    import numpy as np
+    nz, ny, nx = np.asarray(p.sdf).shape[:3]
+    lo, hi = np.asarray(p.sdf_aabb[0], np.float64), np.asarray(p.sdf_aabb[1], np.float64)
+    st = (hi - lo) / np.array([nx - 1, ny - 1, nz - 1], np.float64)
+    return float(np.sqrt((st * st).sum()))

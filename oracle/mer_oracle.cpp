@@ -785,6 +785,34 @@ template <typename FLOAT> struct Tracer {
         opt += h * n;
     }
     /* heterogeneousrefractive.cpp:671-691 */
+    /* aggressive_trace (:697-704): same as trace but no inside / outside tests */
+    inline void aggressiveTrace(V3<FLOAT> &p, V3<FLOAT> &v, FLOAT sampledDistance, FLOAT &opt) const {
+        const FLOAT h = (FLOAT) S.s.stepsize;
+        FLOAT distance = sampledDistance;
+        int steps = (int) (distance / h);
+        distance = distance - steps * h;
+        for (int i = 0; i < steps; i++) er_step(p, v, h, opt);
+        er_step(p, v, distance, opt);
+    }
+    /* sampleDistance's `aggressivetracing` branch (:476-493), applied to every finite trace of a free flight or of a
+       transmittance walk (the connection transmittance keeps the plain trace): legs of min(depth below the surface, distance left)
+       without tests while that depth is >= Epsilon, then the tested trace of the rest */
+    inline bool traceMaybeAggressive(V3<FLOAT> &p, V3<FLOAT> &v, FLOAT sampledDistance, FLOAT &distSurf, FLOAT &opt) const {
+        if (!(S.s.aggressive_tracing && S.s.boundary == ORC_BOUNDARY_SDF)) return trace(p, v, sampledDistance, distSurf, opt);
+        FLOAT dist_left = sampledDistance, dist_traced = 0;
+        while (dist_left > (FLOAT) Epsilon) {
+            FLOAT sdf = -(FLOAT) S.sdfValue(Vec(p));
+            sdf -= (FLOAT) S.s.sdf_max_error;
+            if (sdf < (FLOAT) Epsilon) break;
+            const FLOAT traceDist = std::min(sdf, dist_left);
+            aggressiveTrace(p, v, traceDist, opt);
+            dist_left -= traceDist;
+            dist_traced += traceDist;
+        }
+        const bool success = trace(p, v, dist_left, distSurf, opt);
+        distSurf += dist_traced;
+        return success;
+    }
     inline bool trace(V3<FLOAT> &p, V3<FLOAT> &v, FLOAT sampledDistance, FLOAT &distSurf, FLOAT &opt) const {
         const FLOAT h = (FLOAT) S.s.stepsize;
         FLOAT distance = sampledDistance;
@@ -1213,7 +1241,7 @@ struct Walker {
         FLOAT refStart = T.R.value(tempP, C);
         FLOAT refRatioSq = (FLOAT) 1.0 / (refStart * refStart);
         tempV *= refStart;
-        if (std::isfinite(sampledDistance)) success = T.trace(tempP, tempV, sampledDistance, distSurf, opticalDistance);
+        if (std::isfinite(sampledDistance)) success = T.traceMaybeAggressive(tempP, tempV, sampledDistance, distSurf, opticalDistance);
         else { T.traceTillBoundary(tempP, tempV, distSurf, opticalDistance); success = false; }
         Float refEnd = (Float) T.R.value(tempP, C);
         refRatioSq *= refEnd * refEnd;
@@ -1240,7 +1268,7 @@ struct Walker {
         bool success = false;
         while (true) {
             FLOAT s = (FLOAT) (-std::log(1 - rng.next1D()) * S.invMaxDensity);
-            bool inside = T.trace(tempP, tempV, s, distSurf, opt);
+            bool inside = T.traceMaybeAggressive(tempP, tempV, s, distSurf, opt);
             total += distSurf;
             if (!inside) break;
             Vec p(tempP);
@@ -1284,7 +1312,7 @@ struct Walker {
             Float Tr = 1.0f;
             while (true) {
                 FLOAT s = (FLOAT) (-std::log(1 - rng.next1D()) * S.invMaxDensity);
-                if (!T.trace(p, v, s, distSurf, opt)) { lastTrOpt = (Float) opt; break; }
+                if (!T.traceMaybeAggressive(p, v, s, distSurf, opt)) { lastTrOpt = (Float) opt; break; }
                 Float density = sigmaTAt(Vec(p));
                 if (S.s.tr_estimator == ORC_TR_RATIO) { Tr *= 1.0f - density * S.invMaxDensity; if (Tr == 0.0f) break; }
                 else if (density * S.invMaxDensity > rng.next1D()) { Tr = 0.0f; break; }

@@ -88,6 +88,9 @@ typedef struct {
     /* boundary = ORC_BOUNDARY_SDF: the shape is the negative region of a signed-distance grid (the reference's `sdf` child,
        src/medium/heterogeneousrefractive.cpp:366-375; negative inside, :481) */
     orc_grid sdf;
+    /* `aggressivetracing` (src/medium/heterogeneousrefractive.cpp:230,473-493,697-704) and the volume's maxSDFError() */
+    int32_t aggressive_tracing;
+    float   sdf_max_error;
 } orc_scene;
 enum { ORC_BSDF_NULL = 0, ORC_BSDF_HDIELECTRIC = 1 };
 

@@ -55,6 +55,8 @@ class Scene(C.Structure):
         ("modulation", C.c_int32), ("mod_lambda", C.c_float), ("mod_phase_deg", C.c_float), ("mod_P", C.c_int32), ("mod_neighbors", C.c_int32),
         ("boundary_bsdf", C.c_int32),
         ("sdf", Grid),
+        ("aggressive_tracing", C.c_int32),
+        ("sdf_max_error", C.c_float),
     ]
 
 
@@ -102,6 +104,19 @@ def make_grid(data, aabb_min, aabb_max, keep):
     return g
 
 
+def _sdf_max_error(p):
+    """maxSDFError() of the signed-distance volume: one voxel diagonal (src/volume/splinevolume.cpp:282), unless the scene gives it"""
+    e = getattr(p, "sdf_max_error", None)
+    if e is not None:
+        return float(e)
+    if getattr(p, "sdf", None) is None:
+        return 0.0
+    nz, ny, nx = np.asarray(p.sdf).shape[:3]
+    lo, hi = np.asarray(p.sdf_aabb[0], np.float64), np.asarray(p.sdf_aabb[1], np.float64)
+    st = (hi - lo) / np.array([nx - 1, ny - 1, nz - 1], np.float64)
+    return float(np.sqrt((st * st).sum()))
+
+
 def make_scene(p):
     """p: mitsubaer_amd.scene.SceneParams (plain attribute bag).  Returns (Scene, keepalive list)."""
     keep = []
@@ -136,6 +151,7 @@ def make_scene(p):
     s.calibrated_transient = int(p.calibrated_transient)
     s.modulation = p.modulation; s.mod_lambda = p.mod_lambda; s.mod_phase_deg = p.mod_phase_deg; s.mod_P = p.mod_P; s.mod_neighbors = p.mod_neighbors
     s.boundary_bsdf = p.boundary_bsdf
+    s.aggressive_tracing = int(getattr(p, "aggressive_tracing", False)); s.sdf_max_error = _sdf_max_error(p)
     return s, keep
 
 

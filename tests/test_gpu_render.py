@@ -150,6 +150,24 @@ def test_brick_layouts_are_bit_identical(ctx, shape, stepper, layout):
         v.destroy()
 
 
+def test_auto_layout_and_list_sorting_change_nothing_per_path(ctx, monkeypatch):
+    """MER_LAYOUT_AUTO picks a record layout by grid size, and the work lists are sorted by event class / estimated exit time:
+    both are scheduling choices, the per-path radiance stays bit-identical to the dense layout with unsorted march lists."""
+    p = scenes.curved_scene(N=24, w=48, h=40)
+    sc, vols = ctx.upload_scene(p, layout=capi.LAYOUT_DENSE)
+    sc2, vols2 = ctx.upload_scene(p, layout=capi.LAYOUT_AUTO)
+    monkeypatch.setenv("MER_MQ_SORT", "0")
+    a = [ctx.render_paths(sc, s, seed=2) for s in (0, 1)]
+    monkeypatch.setenv("MER_MQ_SORT", "1")
+    b = [ctx.render_paths(sc2, s, seed=2) for s in (0, 1)]
+    monkeypatch.delenv("MER_MQ_SORT")
+    c = [ctx.render_paths(sc2, s, seed=2) for s in (0, 1)]
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    for v in vols + vols2:
+        v.destroy()
+
+
 def test_brick27_is_for_the_rif_only(ctx):
     p = scenes.straight_scene(N=16)
     with pytest.raises(RuntimeError, match="refractive-index field only"):

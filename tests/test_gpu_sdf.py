@@ -21,6 +21,12 @@ CASES = {
     "curved_null_rk4": lambda: scenes.curved_scene(N=24, rif="radial", sdf=_sdf(), **SD),
     "curved_dielectric_verlet": lambda: scenes.curved_scene(N=24, rif="radial", stepper=P.STEP_VERLET, sdf=_sdf(), boundary_bsdf=P.BSDF_HDIELECTRIC, **SD),
     "curved_bspline_dielectric": lambda: scenes.bspline_scene(N=24, sdf=_sdf(), boundary_bsdf=P.BSDF_HDIELECTRIC, **SD),
+    # `aggressivetracing` (heterogeneousrefractive.cpp:473-493): untested legs of min(depth, distance left) while deep inside the shape
+    "aggressive_curved_rk4": lambda: scenes.curved_scene(N=24, rif="radial", sdf=_sdf(), aggressive_tracing=True, **SD),
+    "aggressive_dielectric_verlet": lambda: scenes.curved_scene(N=24, rif="radial", stepper=P.STEP_VERLET, sdf=_sdf(), boundary_bsdf=P.BSDF_HDIELECTRIC,
+                                                                 aggressive_tracing=True, **SD),
+    "aggressive_homogeneous_sigma": lambda: scenes.curved_scene(N=24, rif="radial", sigma_mode=P.SIGMA_HOMOGENEOUS, phase=P.PHASE_ISOTROPIC, sdf=_sdf(),
+                                                                 aggressive_tracing=True, sdf_max_error=0.01, **SD),
     "point_curved_sdf": lambda: scenes.curved_scene(N=24, w=32, h=24, rif="radial", sdf=_sdf(), env_radiance=[0, 0, 0], point_position=[0.2, 0.3, -0.1],
                                                    point_intensity=[1.0, 0.8, 0.5], **SD),
 }
@@ -49,6 +55,29 @@ def test_sdf_sphere_reproduces_the_analytic_sphere(ctx):
     ma = fa[..., :3].sum() / fa[..., 4].sum(); mb = fb[..., :3].sum() / fb[..., 4].sum()
     assert abs(mb / ma - 1.0) < 5e-3, (ma, mb)
     for v in va + vb:
+        v.destroy()
+
+
+def test_aggressive_tracing_changes_the_step_partition_not_the_image(ctx):
+    """legs without inside tests re-partition the steps of a segment (each leg ends with its own remainder step), so paths differ in
+    the last bits but the image is the same; an error bound larger than the shape switches the legs off: bit-identical to plain tracing"""
+    kw = dict(N=24, w=32, h=24, rif="radial", fov_x_deg=40.0, rfilter=P.FILTER_BOX, rfilter_param=0.5, sdf=_sdf(), **SD)
+    pa = scenes.curved_scene(**kw)
+    pb = scenes.curved_scene(aggressive_tracing=True, **kw)
+    pc = scenes.curved_scene(aggressive_tracing=True, sdf_max_error=10.0, **kw)
+    sa, va = ctx.upload_scene(pa); sb, vb = ctx.upload_scene(pb); sc, vc = ctx.upload_scene(pc)
+    a = ctx.render_paths(sa, 0, seed=4); b = ctx.render_paths(sb, 0, seed=4); c = ctx.render_paths(sc, 0, seed=4)
+    assert np.array_equal(a, c) and not np.array_equal(a, b)
+    fa = ctx.render_to_host(sa, 0, 256, seed=1); fb = ctx.render_to_host(sb, 0, 256, seed=1)
+    ma = fa[..., :3].sum() / fa[..., 4].sum(); mb = fb[..., :3].sum() / fb[..., 4].sum()
+    assert abs(mb / ma - 1.0) < 5e-3, (ma, mb)
+    for v in va + vb + vc:
+        v.destroy()
+    pd = scenes.curved_scene(N=24, aggressive_tracing=True)                       # no sdf volume
+    sd, vd = ctx.upload_scene(pd)
+    with pytest.raises(RuntimeError, match="aggressivetracing needs"):
+        ctx.render_paths(sd, 0)
+    for v in vd:
         v.destroy()
 
 

@@ -174,5 +174,13 @@ def test_sdf_child_selects_the_signed_distance_boundary(tmp_path):
     body = '<integrator type="volpath"/>' + CAM + med + '<shape type="cube"><bsdf type="hdielectric"/><ref name="interior" id="m"/></shape>'
     d, _ = host.flatten_xml(_scene(tmp_path, body))
     assert d.boundary == P.BOUNDARY_SDF and d.boundary_bsdf == P.BSDF_HDIELECTRIC
-    d, _ = host.flatten_xml(_scene(tmp_path, body.replace('<volume name="sdf" type="gridvolume"><string name="filename" value="%s"/></volume>' % sdf, '')))
+    assert d.aggressive_tracing == 0
+    # `aggressivetracing` (heterogeneousrefractive.cpp:230): needs the sdf child; maxSDFError() = one voxel diagonal (splinevolume.cpp:282)
+    agg = body.replace('<medium type="heterogeneousrefractive" id="m">', '<medium type="heterogeneousrefractive" id="m"><boolean name="aggressivetracing" value="true"/>')
+    d, _ = host.flatten_xml(_scene(tmp_path, agg))
+    assert d.aggressive_tracing == 1 and abs(d.sdf_max_error - np.sqrt(3.0) * 2.0 / 15.0) < 1e-6
+    nosdf = '<volume name="sdf" type="gridvolume"><string name="filename" value="%s"/></volume>' % sdf
+    with pytest.raises(host.HostError, match="aggressivetracing needs"):
+        host.flatten_xml(_scene(tmp_path, agg.replace(nosdf, '')))
+    d, _ = host.flatten_xml(_scene(tmp_path, body.replace(nosdf, '')))
     assert d.boundary == P.BOUNDARY_AABB

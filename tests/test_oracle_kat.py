@@ -482,3 +482,30 @@ def test_dielectric_index_one_is_the_null_boundary_in_expectation(orc):
     b, _ = orc.render(scenes.straight_scene(boundary_bsdf=P.BSDF_HDIELECTRIC, rif_const=1.0, **kw), 0, 4000, 2)
     ma = a[..., :3].sum((0, 1)) / a[..., 4].sum(); mb = b[..., :3].sum((0, 1)) / b[..., 4].sum()
     np.testing.assert_allclose(mb, ma, rtol=0.02)
+
+
+# ----------------------------------------------------------------------------- N2: aggressivetracing
+def test_aggressive_tracing_same_image_and_off_switch(orc):
+    """`aggressivetracing` (heterogeneousrefractive.cpp:473-493,697-704) walks legs of min(depth below the SDF surface - maxSDFError,
+    distance left) without inside tests.  It only re-partitions the steps of a segment: same image in expectation, more
+    steps (every leg ends with its own remainder step); with an error bound larger than the shape no leg is ever taken and the
+    render is bit-identical to plain tracing."""
+    from mitsubaer_amd import synth
+    box = ([-1.2] * 3, [1.2] * 3)
+    sdf = -synth.sphere_sdf(48, radius=0.9, aabb_min=box[0], aabb_max=box[1])
+    kw = dict(N=16, w=8, h=8, rif="radial", fov_x_deg=35.0, rfilter=P.FILTER_BOX, rfilter_param=0.5, boundary=P.BOUNDARY_SDF, sdf=sdf, sdf_aabb=box)
+    plain, c0 = orc.render(scenes.curved_scene(**kw), 0, 600, 5)
+    aggr, c1 = orc.render(scenes.curved_scene(aggressive_tracing=True, **kw), 0, 600, 5)
+    off, c2 = orc.render(scenes.curved_scene(aggressive_tracing=True, sdf_max_error=10.0, **kw), 0, 600, 5)
+    assert np.array_equal(plain, off) and np.array_equal(c0, c2)
+    assert not np.array_equal(plain, aggr)
+    m0 = plain[..., :3].sum() / plain[..., 4].sum(); m1 = aggr[..., :3].sum() / aggr[..., 4].sum()
+    assert abs(m1 / m0 - 1.0) < 0.01, (m0, m1)
+    # one more (remainder) step per leg, and the tested trace of what is left -- often of length 0 -- still takes its remainder step
+    assert c0[orc.C_STEPS] < c1[orc.C_STEPS] < 2 * c0[orc.C_STEPS]
+    # homogeneous sigma along curved rays: the reference's own sampleDistance
+    kw2 = dict(kw, sigma_mode=P.SIGMA_HOMOGENEOUS, phase=P.PHASE_ISOTROPIC)
+    a, _ = orc.render(scenes.curved_scene(**kw2), 0, 600, 6)
+    b, _ = orc.render(scenes.curved_scene(aggressive_tracing=True, **kw2), 0, 600, 6)
+    ma = a[..., :3].sum() / a[..., 4].sum(); mb = b[..., :3].sum() / b[..., 4].sum()
+    assert abs(mb / ma - 1.0) < 0.01, (ma, mb)
