@@ -139,14 +139,16 @@ struct Walk {
 
     // One unit of marching work.  Curved: one er_step + insideShape test (trace(): :676-689).
     // Straight: one tentative-collision jump (heterogeneous.cpp:633-636).
+    // COUNT = false: the caller keeps one trip counter and adds steps / rif_evals / marched itself (K_march's hot loop)
+    template <bool COUNT = true>
     __device__ __forceinline__ int advance(const Params &P, Rng &rng, LaneCounters &C) {
-        C.marched++;
+        if (COUNT) C.marched++;
         if (CURVED) {
             // one er_step call site: the step back after an exit is one more trip through here with -h
             const bool full = steps_left > 0;
             const float h = backstep ? -hprev : (full ? P.sc.stepsize : rem);
             er_step<RIF, STEPPER>(P.rif, cc, p, v, h, opt);
-            C.steps++; C.rif_evals += evals_per_step<STEPPER>();
+            if (COUNT) { C.steps++; C.rif_evals += evals_per_step<STEPPER>(); }
             if (backstep) {
                 backstep = 0;
                 if (seg_inf) dist -= hprev;                                   // traceTillBoundary :757-759 (as shipped)

@@ -254,6 +254,9 @@ __device__ __forceinline__ void queue_clear_row(const SegQueue &q, uint32_t row,
 #ifndef MER_MARCH_WAVES
 #define MER_MARCH_WAVES 4
 #endif
+#ifndef MER_ARRIVE_BATCH
+#define MER_ARRIVE_BATCH 4        // power of two
+#endif
 template <bool CURVED, int RIF, int STEPPER, int SIGMA, int BND = 0>
 __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const Params P, uint32_t pass) {
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
@@ -275,6 +278,23 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
         W.cc.reset(); W.n0 = 1.0f; W.tmin = 0.0f; W.trsum = 0.0f; W.sdens = 0.0f;
         int ev = EV_NONE; sigma = 0.0f;
         const int K = P.ksteps;
+        if (CURVED) {
+            // A lane reaches a tentative collision about once in 65 steps, so at nearly every trip ONE lane of the wave would drag all
+            // 64 through the collision code (sigma_t fetch, ratio / Woodcock test, next exponential segment: ~125 VALU against ~320 for
+            // the step itself).  Arrived lanes wait instead, and the wave resolves them together every MER_ARRIVE_BATCH trips: ~2 % of
+            // the lane-steps idle for 1/MER_ARRIVE_BATCH of the collision code.  Per lane the sequence of operations is unchanged.
+            bool pend = false; uint32_t nadv = 0;
+            for (int k = 0; k < K; ++k) {
+                if (!pend) {
+                    ev = W.template advance<false>(P, rng, C); nadv++;
+                    if (ev == EV_ARRIVED) { pend = true; ev = EV_NONE; }
+                }
+                if (((k & (MER_ARRIVE_BATCH - 1)) == MER_ARRIVE_BATCH - 1 || k == K - 1) && pend) { ev = W.on_arrived(P, rng, C, sigma); pend = false; }
+                iters++;
+                if (ev != EV_NONE) break;
+            }
+            C.marched += nadv; C.steps += nadv; C.rif_evals += nadv * evals_per_step<STEPPER>();
+        } else
         for (int k = 0; k < K; ++k) {
             ev = W.advance(P, rng, C);
             if (ev == EV_ARRIVED) ev = W.on_arrived(P, rng, C, sigma);
