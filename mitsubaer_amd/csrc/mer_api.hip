@@ -634,6 +634,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
             q->segcap = 2u * (want / MER_NSEG) + 256u;          // two producer kernels may feed one segment
             if (q == &ctx->eq) q->segcap = 2u * (want / (MER_NSEG / MER_EV_CLASSES)) + 256u;   // every lane may be of one event class
             if (q == &ctx->mq[0] || q == &ctx->mq[1]) q->segcap = 2u * (want / (MER_NSEG / MER_MQ_CLASSES)) + 256u;   // ... or of one march class
+            if (q == &ctx->cq) q->segcap = want + 256u;   // requests gather over several passes: a segment may see every slot once
             HIP_CHECK(ctx, hipMalloc((void **) &q->items, (size_t) q->segcap * MER_NSEG * sizeof(uint32_t)));
             if (!q->counts) HIP_CHECK(ctx, hipMalloc((void **) &q->counts, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t)));
         }
@@ -680,6 +681,15 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         const uint32_t check_every = 8;
         const int k0 = P.ksteps; const bool adaptive = getenv("MER_FIXED_K") == nullptr;
         uint32_t pass = 0;
+        // Connection requests gather in one row of cq over connect_every passes (the parked slots wait, the others keep marching) and
+        // K_connect drains the row at the end of the group: fuller launches, 5-8 % on configs[4]; in the tail it runs every pass.
+        // (The stage is throughput-bound -- ~14 k sensitivity steps per connection, 22 G steps/s -- not launch-latency-bound: gathering
+        // 16 passes gains no more than gathering 4.)
+        int connect_every = 4;
+        { const char *e = getenv("MER_CONNECT_EVERY"); if (e && atoi(e) > 0) connect_every = atoi(e); }
+        const int connect_every0 = connect_every;
+        uint32_t since_connect = 0;
+        P.cq_row = 0;
         for (;;) {
             while (ctx->pass_events.size() < (size_t) (pass + 1) * 3) {
                 hipEvent_t e; HIP_CHECK(ctx, hipEventCreate(&e)); ctx->pass_events.push_back(e);
@@ -687,7 +697,10 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
             HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 0], ctx->stream));
             for (int g = 0; work_left && g < (pass == 0 ? 6 : 1); g++) hipLaunchKernelGGL(kge, dim3(gen_blocks), dim3(MER_BLOCK), 0, ctx->stream, P);
             hipLaunchKernelGGL(kev, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
-            if (connect_stage) hipLaunchKernelGGL(kco, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
+            if (connect_stage && ++since_connect >= (uint32_t) connect_every) {
+                hipLaunchKernelGGL(kco, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
+                since_connect = 0; P.cq_row++;
+            }
             HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 1], ctx->stream));
             hipLaunchKernelGGL(kma, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
             HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 2], ctx->stream));
@@ -702,6 +715,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
                 if (adaptive) {          // tail: few lanes left => longer passes, fewer launches
                     const uint32_t alive = nslots - *ctx->host_live;
                     P.ksteps = alive < nslots / 64 ? k0 * 32 : (alive < nslots / 16 ? k0 * 8 : (alive < nslots / 4 ? k0 * 2 : k0));
+                    connect_every = alive < nslots / 4 ? 1 : connect_every0;
                 }
                 if (pass > (1u << 24)) return fail(ctx, "mer_render: pass limit exceeded");
             }

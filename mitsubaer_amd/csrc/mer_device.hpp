@@ -463,6 +463,7 @@ struct Params {
     unsigned long long *hitq; unsigned long long hitq_cap;     // ring of work ids that will march (power-of-two capacity)
     unsigned long long *hitq_ctr;       // [0] produced (tail), [1] consumed (head)
     int32_t gen_iters, gen_all;
+    uint32_t cq_row;                    // row of the connection-request list that K_event appends to and the next K_connect drains
     int32_t mq_sort;                    // 1: march lists sorted by estimated steps to the boundary (MER_MQ_SORT=0 turns it off for A/B runs)
 };
 #define MER_LIVE_SLOTS 4096

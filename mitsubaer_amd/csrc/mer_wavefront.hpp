@@ -226,7 +226,8 @@ __device__ __forceinline__ int march_class(const Params &P, const WalkT &W) {
         }
         r = dist * __builtin_amdgcn_rcpf(S.stepsize);
     } else r = (W.tmax - W.t) * __builtin_amdgcn_rcpf(P.inv_max_density);
-    const float f = r * ((float) (MER_MQ_CLASSES - 1) * __builtin_amdgcn_rcpf((float) P.ksteps));
+    // straight rays never come near ksteps trips (a crossing is ~8 tentative collisions): classes of two expected collisions each
+    const float f = CURVED ? r * ((float) (MER_MQ_CLASSES - 1) * __builtin_amdgcn_rcpf((float) P.ksteps)) : 0.5f * r;
     return f >= (float) (MER_MQ_CLASSES - 1) ? 0 : (MER_MQ_CLASSES - 1) - (int) fmaxf(f, 0.0f);
 }
 __device__ __forceinline__ uint32_t queue_total(const SegQueue &q, uint32_t row) {
@@ -339,7 +340,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
     const uint32_t count = nq + ns;
     // ring hygiene: the rows K_march / K_event of pass+1 will add to
     queue_clear_row(P.eq, pass + 2, j); queue_clear_row(P.mq[pass & 1u], pass + 2, j); queue_clear_row(P.sq[pass & 1u], pass + 2, j);
-    if (EXTRA && CURVED) queue_clear_row(P.cq, pass + 2, j);
+    if (EXTRA && CURVED) queue_clear_row(P.cq, P.cq_row + 2, j);
     LaneCounters C; C.clear();
     bool marching = false, starved_out = false, connecting = false; uint32_t i = 0; int mq_class = 0;
     if (j < count) {
@@ -642,9 +643,12 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
         SLOT(CO_PLEN) = __float_as_uint(plen); SLOT(CO_TROPT) = __float_as_uint(trOpt); if (EXTRA) SLOT(CO_ETA) = __float_as_uint(etaPath);
         marching = !connecting;
         mq_class = march_class<CURVED, BND>(P, W);
+
     }
     }   // j < count
-    if (EXTRA && CURVED) queue_push(P.cq, pass, connecting, i);
+    // requests of several passes gather in one row (launch_render).  Sorting them by distance to the emitter (the length of the ray
+    // every iterate of the shooting solver traces) was measured and changes nothing: the solves differ in their iteration counts
+    if (EXTRA && CURVED) queue_push(P.cq, P.cq_row, connecting, i);
     queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class);
     queue_push(P.sq[(pass + 1) & 1u], pass + 1, starved_out, i);
     flush_counters(P, C, 0);
@@ -659,12 +663,12 @@ __global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P
     constexpr bool EXTRA = true;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
-    const uint32_t count = queue_total(P.cq, pass);
+    const uint32_t count = queue_total(P.cq, P.cq_row);
     LaneCounters C; C.clear();
     uint32_t i = 0;
     const bool mine = j < count;
     if (mine) {
-        i = queue_item(P.cq, pass, j);
+        i = queue_item(P.cq, P.cq_row, j);
         Rng rng;
         const uint32_t pixel = SLOT(H_PIXEL), sample = SLOT(H_SAMPLE);
         rng.state = (uint64_t) SLOT(H_RNG_LO) | ((uint64_t) SLOT(H_RNG_HI) << 32);
