@@ -78,3 +78,61 @@ def test_device_synthetic_fields_match_host_generators(ctx):
         ok = ii[:, 3] >= 0
         assert np.abs(v[ok] - want[ok]).max() < 2e-3          # value at (almost) the node; device sin() vs numpy
         vol.destroy()
+
+
+def test_cfg3_linearity_sorting_and_pass_length_change_no_path(ctx, fields, monkeypatch):
+    """the bench workload itself (bench.build_workload): scaling the emitter by a power of two scales every path bit-exactly (the same
+    paths are walked); record layout, work-list sorting and the pass length K are scheduling choices that change no bit of any path"""
+    import bench
+    p, _ = bench.build_workload("cfg3", N, SIZE, 256)
+    sc, vols = ctx.upload_scene(p, layout=capi.LAYOUT_AUTO)
+    a = ctx.render_paths(sc, 3, seed=7)
+    assert np.isfinite(a).all() and (a >= 0).all() and a.max() > 0
+    sc.env_radiance[:] = [2.0, 2.0, 2.0]
+    assert np.array_equal(ctx.render_paths(sc, 3, seed=7), 2.0 * a)
+    sc.env_radiance[:] = [1.0, 1.0, 1.0]
+    assert np.array_equal(ctx.render_paths(sc, 3, seed=7), a)                       # determinism
+    assert not np.array_equal(ctx.render_paths(sc, 4, seed=7), a)                   # another sample index: other paths
+    monkeypatch.setenv("MER_MQ_SORT", "0")
+    assert np.array_equal(ctx.render_paths(sc, 3, seed=7), a)
+    monkeypatch.setenv("MER_KSTEPS", "37")
+    assert np.array_equal(ctx.render_paths(sc, 3, seed=7), a)
+    monkeypatch.delenv("MER_MQ_SORT"); monkeypatch.delenv("MER_KSTEPS")
+    sd, vd = ctx.upload_scene(p, layout=capi.LAYOUT_DENSE)
+    assert np.array_equal(ctx.render_paths(sd, 3, seed=7), a)
+    for v in vols + vd:
+        v.destroy()
+
+
+def test_constant_index_through_the_eikonal_kernels_at_full_size(ctx, fields):
+    """n == 1 through K_march's curved-ray code = the straight-ray estimator of configs[1] (same expectation, different paths)"""
+    pa = _params(fields, tr_estimator=P.TR_RATIO, phase=P.PHASE_HG, g=0.8, density_scale=4.0, albedo=[0.9, 0.9, 0.9])
+    pb = _params(fields, tr_estimator=P.TR_RATIO, phase=P.PHASE_HG, g=0.8, density_scale=4.0, albedo=[0.9, 0.9, 0.9],
+                 rif_mode=P.RIF_TRILINEAR, rif=np.ones((N, N, N), np.float32), stepper=P.STEP_RK4, stepsize=0.5 * 2.0 / (N - 1))
+    sa, va = ctx.upload_scene(pa, layout=capi.LAYOUT_AUTO); sb, vb = ctx.upload_scene(pb, layout=capi.LAYOUT_AUTO)
+    fa = ctx.render_to_host(sa, 0, 8, seed=2); fb = ctx.render_to_host(sb, 0, 8, seed=2)
+    ma = fa[..., :3].sum((0, 1)) / fa[..., 4].sum(); mb = fb[..., :3].sum((0, 1)) / fb[..., 4].sum()
+    assert np.all(np.abs(mb / ma - 1.0) < 3e-3), (ma, mb)
+    for v in va + vb:
+        v.destroy()
+
+
+def test_cfg3_at_512_cubed(ctx):
+    """the north star's target volume: 512^3 sigma_t + 512^3 RIF (BRICK27 records: 2 GiB; CELL8: 4 GiB)"""
+    import bench
+    p, _ = bench.build_workload("cfg3", 512, SIZE, 256)
+    sc, vols = ctx.upload_scene(p, layout=capi.LAYOUT_AUTO)
+    a = ctx.render_paths(sc, 1, seed=9)
+    assert np.isfinite(a).all() and a.max() > 0 and np.array_equal(a[0, 0], [1, 1, 1])
+    sc.env_radiance[:] = [0.5, 0.5, 0.5]
+    assert np.array_equal(ctx.render_paths(sc, 1, seed=9), 0.5 * a)
+    sc.env_radiance[:] = [1.0, 1.0, 1.0]
+    full = ctx.render_to_host(sc, 0, 2, seed=1)
+    parts = sum(ctx.render_to_host(sc, r, 1, seed=1, spp_stride=2) for r in range(2))
+    assert np.allclose(full, parts, rtol=1e-4, atol=1e-4)
+    for v in vols:
+        v.destroy()
+    sd, vd = ctx.upload_scene(p, layout=capi.LAYOUT_CELL8)
+    assert np.array_equal(ctx.render_paths(sd, 1, seed=9), a)
+    for v in vd:
+        v.destroy()
