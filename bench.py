@@ -193,7 +193,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"cfg2": "configs[1]: ", "cfg3": "configs[2]: ", "cfg4": "configs[3]: ", "cfg5": "configs[4]: "}[args.workload] + desc, "grid": args.res, "film": [p.width, p.height], "spp_per_gpu": args.spp,
+            "config": {"workload": {"cfg2": "configs[1]: ", "cfg3": "configs[2]: ", "cfg4": "configs[3]: ", "cfg5": "configs[4]: "}[args.workload] + desc, "grid": args.res, "film": [p.width, p.height], "spp_per_gpu": args.spp, "pipelines_per_gpu": int(os.environ.get("MER_PIPES", "4")),
                        "stepper": "rk4", "rif_interp": "trilinear", "layout": args.layout, "shard": args.shard,
                        "stepsize": p.stepsize, "estimator": "volpath + delta tracking on eikonal rays, ratio-tracking NEE",
                        "device": name, "cus": cus},
@@ -204,7 +204,12 @@ def main():
                          "whole_step": {"ms": k_ms, "algorithmic_bytes": b_alg, "achieved": achieved_step, "frac": achieved_step / HBM_PEAK_GBS},
                          "counters_per_launch": {"paths": paths_rank / args.steps, "steps": counters[capi.C_STEPS] / args.steps,
                                                  "tentative": counters[capi.C_TENTATIVE] / args.steps, "real": counters[capi.C_REAL] / args.steps},
-                         "active_lane_fraction": lane_eff},
+                         "active_lane_fraction": lane_eff,
+                         # the render runs as several independent pipelines on their own streams (launch_render): launches of different
+                         # pipelines execute side by side, so one launch's duration is stretched by its neighbours and `achieved` (bytes of
+                         # ONE launch / its duration, the rocprofv3 figure) understates the chip's rate by up to that factor;
+                         # whole_step is the aggregate: all algorithmic bytes of the step / its wall time
+                         "concurrent_pipelines": int(os.environ.get("MER_PIPES", "4"))},
         }
         # HBM traffic cannot be counted inside this process: it comes from separate `rocprofv3 --pmc` passes of this very
         # command (FETCH_SIZE / WRITE_SIZE, gfx950 read correction applied), committed under profiles/

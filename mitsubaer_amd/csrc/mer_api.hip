@@ -27,6 +27,16 @@ struct Volume {
 };
 }  // namespace
 
+#define MER_MAX_PIPES 4
+struct Pipe {
+    hipStream_t stream = nullptr, own_stream = nullptr;      // pipeline 0 runs on the context stream
+    uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
+    SegQueue eq{}, mq[2]{}, sq[2]{}, cq{};
+    unsigned long long *hitq = nullptr, *hitq_ctr = nullptr; unsigned long long hitq_cap = 0;
+    hipEvent_t readback = nullptr, finished = nullptr;
+    std::vector<hipEvent_t> pass_events;          // 3 per pass: before K_event, between, after K_march
+};
+
 struct mer_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -37,13 +47,10 @@ struct mer_context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     hipDeviceProp_t prop;
-    // wavefront path-state slots
-    uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
-    SegQueue eq{}, mq[2]{}, sq[2]{}, cq{};
-    unsigned long long *hitq = nullptr, *hitq_ctr = nullptr; unsigned long long hitq_cap = 0;
-    int last_passes = 0;
+    // wavefront pipelines: path-state slots, work lists, hit ring, work counter and stream of each (launch_render)
+    Pipe pipes[MER_MAX_PIPES];
+    int last_passes = 0, last_pipes = 1;
     float last_march_ms = 0, last_event_ms = 0;
-    std::vector<hipEvent_t> pass_events;          // 3 per pass: before K_event, between, after K_march
 };
 
 #define HIP_CHECK(ctx, call)                                                                              \
@@ -375,15 +382,20 @@ void mer_context_destroy(mer_context *ctx) {
         if (kv.second.coeff) (void) hipFree(kv.second.coeff);
     }
     if (ctx->counters) (void) hipFree(ctx->counters);
-    if (ctx->slots) (void) hipFree(ctx->slots);
-    if (ctx->live) (void) hipFree(ctx->live);
-    for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1], &ctx->cq}) { if (q->items) (void) hipFree(q->items); if (q->counts) (void) hipFree(q->counts); }
-    if (ctx->hitq) (void) hipFree(ctx->hitq);
-    if (ctx->hitq_ctr) (void) hipFree(ctx->hitq_ctr);
-    if (ctx->host_live) (void) hipHostFree(ctx->host_live);
+    for (Pipe &pp : ctx->pipes) {
+        if (pp.slots) (void) hipFree(pp.slots);
+        if (pp.live) (void) hipFree(pp.live);
+        for (SegQueue *q : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq}) { if (q->items) (void) hipFree(q->items); if (q->counts) (void) hipFree(q->counts); }
+        if (pp.hitq) (void) hipFree(pp.hitq);
+        if (pp.hitq_ctr) (void) hipFree(pp.hitq_ctr);
+        if (pp.host_live) (void) hipHostFree(pp.host_live);
+        if (pp.readback) (void) hipEventDestroy(pp.readback);
+        if (pp.finished) (void) hipEventDestroy(pp.finished);
+        for (hipEvent_t e : pp.pass_events) (void) hipEventDestroy(e);
+        if (pp.own_stream) (void) hipStreamDestroy(pp.own_stream);
+    }
     if (ctx->ev0) (void) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void) hipEventDestroy(ctx->ev1);
-    for (hipEvent_t e : ctx->pass_events) (void) hipEventDestroy(e);
     delete ctx;
 }
 
@@ -619,50 +631,90 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
             return 0;
         });
     }
-    // ---- wavefront: K_event / K_march passes over the path-state slots until no lane is alive
-    uint32_t want = (uint32_t) ctx->prop.multiProcessorCount * 2048u * 4u;          // 4 x the resident lanes of the chip
+    // ---- wavefront: K_event / K_march passes over the path-state slots until no lane is alive.
+    // The passes of ONE pipeline are a chain of dependent launches (K_gen -> K_event -> K_march), and K_event -- fat, latency-bound,
+    // 2 waves per SIMD -- leaves most of the chip idle while it runs.  So the render is cut into `npipes` independent pipelines: pipeline
+    // q takes the sample indices q, q + npipes, ... of the shard (the sharding contract of section 8e, applied inside one GPU), has its
+    // own slots, lists, hit ring and work counter, and runs on its own stream; the film is shared (atomics).  One pipeline's K_event then
+    // overlaps the others' K_march.  Per-path results do not depend on npipes.  Measured on the bench line: 1 pipeline 260, 2: 277, 3: 282,
+    // 4: 283 Mpaths/s (two PROCESSES on one GPU: 298); more slots per pipeline change nothing.
+    int npipes = 4;
+    { const char *e = getenv("MER_PIPES"); if (e && atoi(e) > 0) npipes = std::min(atoi(e), MER_MAX_PIPES); }
+    if (shard->spp_count < npipes) npipes = std::max(1, shard->spp_count);
+    uint32_t want = (uint32_t) ctx->prop.multiProcessorCount * 2048u * 4u;          // 4 x the resident lanes of the chip, over all pipelines
     { const char *e = getenv("MER_NSLOTS"); if (e && atoi(e) > 0) want = (uint32_t) atoi(e); }
-    want = (want + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
-    if (ctx->nslots != want) {
-        if (ctx->slots) (void) hipFree(ctx->slots);
-        if (ctx->hitq) (void) hipFree(ctx->hitq);
-        ctx->slots = nullptr; ctx->hitq = nullptr; ctx->nslots = 0;
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->slots, (size_t) want * MER_SLOT_WORDS * sizeof(uint32_t)));
-        for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1], &ctx->cq}) {
-            if (q->items) (void) hipFree(q->items);
-            q->items = nullptr;
-            q->segcap = 2u * (want / MER_NSEG) + 256u;          // two producer kernels may feed one segment
-            if (q == &ctx->eq) q->segcap = 2u * (want / (MER_NSEG / MER_EV_CLASSES)) + 256u;   // every lane may be of one event class
-            if (q == &ctx->mq[0] || q == &ctx->mq[1]) q->segcap = 2u * (want / (MER_NSEG / MER_MQ_CLASSES)) + 256u;   // ... or of one march class
-            if (q == &ctx->cq) q->segcap = want + 256u;   // requests gather over several passes: a segment may see every slot once
-            HIP_CHECK(ctx, hipMalloc((void **) &q->items, (size_t) q->segcap * MER_NSEG * sizeof(uint32_t)));
-            if (!q->counts) HIP_CHECK(ctx, hipMalloc((void **) &q->counts, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t)));
-        }
-        ctx->hitq_cap = 1; while (ctx->hitq_cap < (unsigned long long) want * 2) ctx->hitq_cap <<= 1;
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->hitq, (size_t) ctx->hitq_cap * sizeof(unsigned long long)));
-        ctx->nslots = want;
-    }
-    if (!ctx->live) {
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->live, MER_LIVE_SLOTS * sizeof(uint32_t)));
-        HIP_CHECK(ctx, hipHostMalloc((void **) &ctx->host_live, 4 * sizeof(uint32_t)));
-        HIP_CHECK(ctx, hipMalloc((void **) &ctx->hitq_ctr, 64 * sizeof(unsigned long long)));
-    }
-    uint32_t nslots = ctx->nslots;
-    const uint64_t need_slots = (P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
-    if (need_slots < nslots) nslots = (uint32_t) need_slots;
-    P.slots = ctx->slots; P.nslots = nslots; P.live = ctx->live; P.eq = ctx->eq; P.mq[0] = ctx->mq[0]; P.mq[1] = ctx->mq[1]; P.sq[0] = ctx->sq[0]; P.sq[1] = ctx->sq[1]; P.cq = ctx->cq;
-    P.hitq = ctx->hitq; P.hitq_cap = ctx->hitq_cap; P.hitq_ctr = ctx->hitq_ctr; P.gen_iters = 8; P.gen_all = getenv("MER_GEN_ALL") ? 1 : 0;
-    P.ksteps = 128;           // eikonal steps per lane per pass (64..256 measured with class-sorted march lists: 128 is the flat optimum at 256^3 and 512^3)
-    { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) P.ksteps = atoi(e); }
+    want = (want / (uint32_t) npipes + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;       // per pipeline
+    int ksteps0 = 128;        // eikonal steps per lane per pass (64..256 measured with class-sorted march lists: 128 is the flat optimum at 256^3 and 512^3)
+    { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) ksteps0 = atoi(e); }
     // sorting the march lists by exit time scatters the lanes of a wave over the volume: a gain while the RIF sits near the caches
     // (256^3: +8 %, 512^3: +3 %), a loss once every fetch goes to HBM (1024^3: -4 %)
     P.mq_sort = (int64_t) P.rif.res[0] * P.rif.res[1] * P.rif.res[2] <= ((int64_t) 1 << 28) ? 1 : 0;
     { const char *e = getenv("MER_MQ_SORT"); if (e) P.mq_sort = atoi(e) != 0; }
-    HIP_CHECK(ctx, hipMemsetAsync(ctx->slots, 0, (size_t) nslots * MER_SLOT_WORDS * sizeof(uint32_t), ctx->stream));
-    HIP_CHECK(ctx, hipMemsetAsync(ctx->live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), ctx->stream));
-    for (SegQueue *q : {&ctx->eq, &ctx->mq[0], &ctx->mq[1], &ctx->sq[0], &ctx->sq[1], &ctx->cq})
-        HIP_CHECK(ctx, hipMemsetAsync(q->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), ctx->stream));
-    HIP_CHECK(ctx, hipMemsetAsync(ctx->hitq_ctr, 0, 64 * sizeof(unsigned long long), ctx->stream));
+    P.gen_iters = 8; P.gen_all = getenv("MER_GEN_ALL") ? 1 : 0;
+    // Connection requests gather in one row of cq over connect_every passes (the parked slots wait, the others keep marching) and
+    // K_connect drains the row at the end of the group: fuller launches, 5-8 % on configs[4]; in the tail it runs every pass.
+    // (The stage is throughput-bound -- ~14 k sensitivity steps per connection, 22 G steps/s -- not launch-latency-bound: gathering
+    // 16 passes gains no more than gathering 4.)
+    int connect_every0 = 4;
+    { const char *e = getenv("MER_CONNECT_EVERY"); if (e && atoi(e) > 0) connect_every0 = atoi(e); }
+
+    struct Run { Params P; uint32_t nslots = 0, pass = 0, since_connect = 0; unsigned blocks = 0, gen_blocks = 0; int connect_every = 1; bool work_left = true, done = false, pending = false; };
+    Run runs[MER_MAX_PIPES];
+    HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int q = 0; q < npipes; q++) {
+        Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
+        if (q == 0) pp.stream = ctx->stream;
+        else if (!pp.own_stream) { HIP_CHECK(ctx, hipStreamCreateWithFlags(&pp.own_stream, hipStreamNonBlocking)); }
+        if (q > 0) { pp.stream = pp.own_stream; HIP_CHECK(ctx, hipStreamWaitEvent(pp.stream, ctx->ev0, 0)); }   // after what the caller queued (film zeroing ...)
+        if (pp.nslots < want) {                 // capacity: grows, never shrinks (render_paths runs one pipeline, mer_render two)
+            if (pp.slots) (void) hipFree(pp.slots);
+            if (pp.hitq) (void) hipFree(pp.hitq);
+            pp.slots = nullptr; pp.hitq = nullptr; pp.nslots = 0;
+            HIP_CHECK(ctx, hipMalloc((void **) &pp.slots, (size_t) want * MER_SLOT_WORDS * sizeof(uint32_t)));
+            for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq}) {
+                if (sq->items) (void) hipFree(sq->items);
+                sq->items = nullptr;
+                sq->segcap = 2u * (want / MER_NSEG) + 256u;          // two producer kernels may feed one segment
+                if (sq == &pp.eq) sq->segcap = 2u * (want / (MER_NSEG / MER_EV_CLASSES)) + 256u;   // every lane may be of one event class
+                if (sq == &pp.mq[0] || sq == &pp.mq[1]) sq->segcap = 2u * (want / (MER_NSEG / MER_MQ_CLASSES)) + 256u;   // ... or of one march class
+                if (sq == &pp.cq) sq->segcap = want + 256u;   // requests gather over several passes: a segment may see every slot once
+                HIP_CHECK(ctx, hipMalloc((void **) &sq->items, (size_t) sq->segcap * MER_NSEG * sizeof(uint32_t)));
+                if (!sq->counts) HIP_CHECK(ctx, hipMalloc((void **) &sq->counts, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t)));
+            }
+            pp.hitq_cap = 1; while (pp.hitq_cap < (unsigned long long) want * 2) pp.hitq_cap <<= 1;
+            HIP_CHECK(ctx, hipMalloc((void **) &pp.hitq, (size_t) pp.hitq_cap * sizeof(unsigned long long)));
+            pp.nslots = want;
+        }
+        if (!pp.live) {
+            HIP_CHECK(ctx, hipMalloc((void **) &pp.live, MER_LIVE_SLOTS * sizeof(uint32_t)));
+            HIP_CHECK(ctx, hipHostMalloc((void **) &pp.host_live, 4 * sizeof(uint32_t)));
+            HIP_CHECK(ctx, hipMalloc((void **) &pp.hitq_ctr, 64 * sizeof(unsigned long long)));       // [0] tail, [32] head, [48] this pipeline's work counter
+            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.readback, hipEventDisableTiming));
+            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.finished, hipEventDisableTiming));
+        }
+        // pipeline q's part of the shard: sample indices spp_begin + (q + k npipes) spp_stride
+        R.P = P;
+        R.P.spp_begin = shard->spp_begin + q * shard->spp_stride; R.P.spp_stride = shard->spp_stride * npipes;
+        R.P.spp_count = (shard->spp_count - q + npipes - 1) / npipes;
+        R.P.total_work = (uint64_t) P.ntiles_mine * MER_TILE * MER_TILE * (uint64_t) R.P.spp_count;
+        R.nslots = want;
+        const uint64_t need_slots = (R.P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
+        if (need_slots < R.nslots) R.nslots = (uint32_t) need_slots;
+        R.P.slots = pp.slots; R.P.nslots = R.nslots; R.P.live = pp.live; R.P.eq = pp.eq; R.P.mq[0] = pp.mq[0]; R.P.mq[1] = pp.mq[1];
+        R.P.sq[0] = pp.sq[0]; R.P.sq[1] = pp.sq[1]; R.P.cq = pp.cq;
+        R.P.hitq = pp.hitq; R.P.hitq_cap = pp.hitq_cap; R.P.hitq_ctr = pp.hitq_ctr; R.P.work_counter = pp.hitq_ctr + 48;
+        R.P.ksteps = ksteps0; R.P.cq_row = 0;
+        R.connect_every = connect_every0;
+        R.done = R.P.total_work == 0;
+        if (R.done) continue;
+        R.blocks = R.nslots / MER_BLOCK;
+        R.gen_blocks = std::max(1u, std::min(R.nslots / MER_BLOCK, 1024u));      // 4096 waves x 512 ids per launch
+        HIP_CHECK(ctx, hipMemsetAsync(pp.slots, 0, (size_t) R.nslots * MER_SLOT_WORDS * sizeof(uint32_t), pp.stream));
+        HIP_CHECK(ctx, hipMemsetAsync(pp.live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), pp.stream));
+        for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq})
+            HIP_CHECK(ctx, hipMemsetAsync(sq->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), pp.stream));
+        HIP_CHECK(ctx, hipMemsetAsync(pp.hitq_ctr, 0, 64 * sizeof(unsigned long long), pp.stream));
+    }
     auto body = [&](auto curved, auto rif, auto stepper, auto sigma, auto bnd) -> int {
         constexpr int BND = decltype(bnd)::value;
         const bool has_point = scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0;
@@ -674,66 +726,80 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         auto kco = connect_stage_kernel<decltype(curved)::value ? decltype(rif)::value : MER_RIF_TRILINEAR, decltype(stepper)::value, decltype(sigma)::value, BND>;
         const bool connect_stage = has_point && decltype(curved)::value;
         auto kge = (extra || BND != 0) ? gen_kernel<decltype(curved)::value, true, BND> : gen_kernel<decltype(curved)::value, BND != 0, BND>;
-        const unsigned gen_blocks = std::max(1u, std::min(nslots / MER_BLOCK, 1024u));      // 4096 waves x 512 ids per launch
-        bool work_left = true;
-        const unsigned blocks = nslots / MER_BLOCK;
-        HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         const uint32_t check_every = 8;
-        const int k0 = P.ksteps; const bool adaptive = getenv("MER_FIXED_K") == nullptr;
-        uint32_t pass = 0;
-        // Connection requests gather in one row of cq over connect_every passes (the parked slots wait, the others keep marching) and
-        // K_connect drains the row at the end of the group: fuller launches, 5-8 % on configs[4]; in the tail it runs every pass.
-        // (The stage is throughput-bound -- ~14 k sensitivity steps per connection, 22 G steps/s -- not launch-latency-bound: gathering
-        // 16 passes gains no more than gathering 4.)
-        int connect_every = 4;
-        { const char *e = getenv("MER_CONNECT_EVERY"); if (e && atoi(e) > 0) connect_every = atoi(e); }
-        const int connect_every0 = connect_every;
-        uint32_t since_connect = 0;
-        P.cq_row = 0;
-        for (;;) {
-            while (ctx->pass_events.size() < (size_t) (pass + 1) * 3) {
-                hipEvent_t e; HIP_CHECK(ctx, hipEventCreate(&e)); ctx->pass_events.push_back(e);
-            }
-            HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 0], ctx->stream));
-            for (int g = 0; work_left && g < (pass == 0 ? 6 : 1); g++) hipLaunchKernelGGL(kge, dim3(gen_blocks), dim3(MER_BLOCK), 0, ctx->stream, P);
-            hipLaunchKernelGGL(kev, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
-            if (connect_stage && ++since_connect >= (uint32_t) connect_every) {
-                hipLaunchKernelGGL(kco, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
-                since_connect = 0; P.cq_row++;
-            }
-            HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 1], ctx->stream));
-            hipLaunchKernelGGL(kma, dim3(blocks), dim3(MER_BLOCK), 0, ctx->stream, P, pass);
-            HIP_CHECK(ctx, hipEventRecord(ctx->pass_events[pass * 3 + 2], ctx->stream));
-            pass++;
-            if (pass % check_every == 0) {
-                HIP_CHECK(ctx, hipGetLastError());
-                HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_live, ctx->live, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-                HIP_CHECK(ctx, hipMemcpyAsync(ctx->host_live + 2, P.work_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-                HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-                if (*ctx->host_live >= nslots) break;
-                work_left = *(unsigned long long *) (ctx->host_live + 2) < P.total_work;
-                if (adaptive) {          // tail: few lanes left => longer passes, fewer launches
-                    const uint32_t alive = nslots - *ctx->host_live;
-                    P.ksteps = alive < nslots / 64 ? k0 * 32 : (alive < nslots / 16 ? k0 * 8 : (alive < nslots / 4 ? k0 * 2 : k0));
-                    connect_every = alive < nslots / 4 ? 1 : connect_every0;
+        const bool adaptive = getenv("MER_FIXED_K") == nullptr;
+        // one batch = check_every passes of a pipeline followed by the read-back of its finished-slot count
+        auto enqueue_batch = [&](int q) -> int {
+            Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
+            for (uint32_t b = 0; b < check_every; b++) {
+                const uint32_t pass = R.pass;
+                while (pp.pass_events.size() < (size_t) (pass + 1) * 3) {
+                    hipEvent_t e; HIP_CHECK(ctx, hipEventCreate(&e)); pp.pass_events.push_back(e);
                 }
-                if (pass > (1u << 24)) return fail(ctx, "mer_render: pass limit exceeded");
+                HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 0], pp.stream));
+                for (int g = 0; R.work_left && g < (pass == 0 ? 6 : 1); g++) hipLaunchKernelGGL(kge, dim3(R.gen_blocks), dim3(MER_BLOCK), 0, pp.stream, R.P);
+                hipLaunchKernelGGL(kev, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+                if (connect_stage && ++R.since_connect >= (uint32_t) R.connect_every) {
+                    hipLaunchKernelGGL(kco, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+                    R.since_connect = 0; R.P.cq_row++;
+                }
+                HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 1], pp.stream));
+                hipLaunchKernelGGL(kma, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+                HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 2], pp.stream));
+                R.pass++;
             }
+            HIP_CHECK(ctx, hipGetLastError());
+            HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live, pp.live, sizeof(uint32_t), hipMemcpyDeviceToHost, pp.stream));
+            HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 2, R.P.work_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, pp.stream));
+            HIP_CHECK(ctx, hipEventRecord(pp.readback, pp.stream));
+            R.pending = true;
+            return 0;
+        };
+        for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q)) return 1;
+        for (;;) {
+            bool any = false;
+            for (int q = 0; q < npipes; q++) {
+                Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
+                if (R.done) continue;
+                any = true;
+                HIP_CHECK(ctx, hipEventSynchronize(pp.readback));
+                R.pending = false;
+                if (*pp.host_live >= R.nslots) { R.done = true; continue; }
+                R.work_left = *(unsigned long long *) (pp.host_live + 2) < R.P.total_work;
+                if (adaptive) {          // tail: few lanes left => longer passes, fewer launches
+                    const uint32_t alive = R.nslots - *pp.host_live;
+                    R.P.ksteps = alive < R.nslots / 64 ? ksteps0 * 32 : (alive < R.nslots / 16 ? ksteps0 * 8 : (alive < R.nslots / 4 ? ksteps0 * 2 : ksteps0));
+                    R.connect_every = alive < R.nslots / 4 ? 1 : connect_every0;
+                }
+                if (R.pass > (1u << 24)) return fail(ctx, "mer_render: pass limit exceeded");
+                if (enqueue_batch(q)) return 1;
+            }
+            if (!any) break;
+        }
+        // join: the caller's stream continues after every pipeline
+        for (int q = 1; q < npipes; q++) {
+            if (runs[q].pass == 0) continue;
+            HIP_CHECK(ctx, hipEventRecord(ctx->pipes[q].finished, ctx->pipes[q].stream));
+            HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipes[q].finished, 0));
         }
         HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        ctx->timed = true; ctx->last_passes = (int) pass;
-        {   // per-kernel device time of this render, from HIP events on the launch stream
+        ctx->timed = true;
+        {   // per-kernel device time of this render, from HIP events on the launch streams (summed over the pipelines: with two of
+            // them running side by side the sum exceeds the wall time)
             HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
-            double em = 0, mm = 0;
-            for (uint32_t q = 0; q < pass; q++) {
-                float a = 0, b = 0;
-                (void) hipEventElapsedTime(&a, ctx->pass_events[q * 3 + 0], ctx->pass_events[q * 3 + 1]);
-                (void) hipEventElapsedTime(&b, ctx->pass_events[q * 3 + 1], ctx->pass_events[q * 3 + 2]);
-                em += a; mm += b;
+            double em = 0, mm = 0; uint32_t passes = 0;
+            for (int q = 0; q < npipes; q++) {
+                for (uint32_t k = 0; k < runs[q].pass; k++) {
+                    float a = 0, b = 0;
+                    (void) hipEventElapsedTime(&a, ctx->pipes[q].pass_events[k * 3 + 0], ctx->pipes[q].pass_events[k * 3 + 1]);
+                    (void) hipEventElapsedTime(&b, ctx->pipes[q].pass_events[k * 3 + 1], ctx->pipes[q].pass_events[k * 3 + 2]);
+                    em += a; mm += b;
+                }
+                passes += runs[q].pass;
             }
-            ctx->last_event_ms = (float) em; ctx->last_march_ms = (float) mm;
+            ctx->last_event_ms = (float) em; ctx->last_march_ms = (float) mm; ctx->last_passes = (int) passes; ctx->last_pipes = npipes;
         }
-        if (getenv("MER_VERBOSE")) { float ms = 0; (void) hipEventSynchronize(ctx->ev1); (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); fprintf(stderr, "[mer] wavefront: %u passes, K=%d, nslots=%u, %.3f ms\n", pass, P.ksteps, nslots, ms); }
+        if (getenv("MER_VERBOSE")) { float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); fprintf(stderr, "[mer] wavefront: %d pipelines, %u + %u passes, K=%d, nslots=%u each, %.3f ms\n", npipes, runs[0].pass, npipes > 1 ? runs[1].pass : 0u, ksteps0, runs[0].nslots, ms); }
         return 0;
     };
     return scene->boundary == MER_BOUNDARY_SDF ? dispatch_modes_sdf(ctx, scene, body) : dispatch_modes(ctx, scene, body);

@@ -168,6 +168,31 @@ def test_auto_layout_and_list_sorting_change_nothing_per_path(ctx, monkeypatch):
         v.destroy()
 
 
+@pytest.mark.parametrize("name", ["curved", "straight", "point_curved"])
+def test_concurrent_pipelines_render_the_same_film(ctx, monkeypatch, name):
+    """mer_render cuts a shard into MER_PIPES independent pipelines (own slots, lists, stream; shared film): same samples, same paths --
+    the film differs by float summation order only, the counters not at all; a pipeline without samples is skipped"""
+    p = {"curved": lambda: scenes.curved_scene(N=24, w=70, h=45), "straight": lambda: scenes.straight_scene(N=24, w=70, h=45),
+         "point_curved": lambda: scenes.curved_scene(N=16, w=24, h=20, rif="radial", env_radiance=[0, 0, 0], point_position=[0.2, 0.3, -0.1],
+                                                     point_intensity=[1.0, 0.8, 0.5])}[name]()
+    sc, vols = ctx.upload_scene(p)
+    films, counts = [], []
+    for n in ("1", "2", "3", "4"):
+        monkeypatch.setenv("MER_PIPES", n)
+        ctx.counters_reset()
+        films.append(ctx.render_to_host(sc, 1, 7, seed=3, spp_stride=2))
+        counts.append(np.array(ctx.counters()[:7]))
+    monkeypatch.delenv("MER_PIPES")
+    for f, c in zip(films[1:], counts[1:]):
+        assert np.allclose(f, films[0], rtol=1e-4, atol=1e-5)
+        assert np.array_equal(c, counts[0])
+    one = ctx.render_to_host(sc, 5, 1, seed=3)                      # a single sample per pixel: one pipeline has all the work
+    monkeypatch.setenv("MER_PIPES", "1")
+    assert np.allclose(one, ctx.render_to_host(sc, 5, 1, seed=3), rtol=1e-4, atol=1e-5)
+    for v in vols:
+        v.destroy()
+
+
 def test_brick27_is_for_the_rif_only(ctx):
     p = scenes.straight_scene(N=16)
     with pytest.raises(RuntimeError, match="refractive-index field only"):
