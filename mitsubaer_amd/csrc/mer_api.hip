@@ -33,7 +33,7 @@ struct Pipe {
     uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
     SegQueue eq{}, mq[2]{}, sq[2]{}, cq{};
     unsigned long long *hitq = nullptr, *hitq_ctr = nullptr; unsigned long long hitq_cap = 0;
-    hipEvent_t readback = nullptr, finished = nullptr;
+    hipEvent_t readback[2] = {nullptr, nullptr}, finished = nullptr;     // two batches in flight per pipeline
     std::vector<hipEvent_t> pass_events;          // 3 per pass: before K_event, between, after K_march
 };
 
@@ -389,7 +389,7 @@ void mer_context_destroy(mer_context *ctx) {
         if (pp.hitq) (void) hipFree(pp.hitq);
         if (pp.hitq_ctr) (void) hipFree(pp.hitq_ctr);
         if (pp.host_live) (void) hipHostFree(pp.host_live);
-        if (pp.readback) (void) hipEventDestroy(pp.readback);
+        for (hipEvent_t e : pp.readback) if (e) (void) hipEventDestroy(e);
         if (pp.finished) (void) hipEventDestroy(pp.finished);
         for (hipEvent_t e : pp.pass_events) (void) hipEventDestroy(e);
         if (pp.own_stream) (void) hipStreamDestroy(pp.own_stream);
@@ -658,7 +658,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
     int connect_every0 = 4;
     { const char *e = getenv("MER_CONNECT_EVERY"); if (e && atoi(e) > 0) connect_every0 = atoi(e); }
 
-    struct Run { Params P; uint32_t nslots = 0, pass = 0, since_connect = 0; unsigned blocks = 0, gen_blocks = 0; int connect_every = 1; bool work_left = true, done = false, pending = false; };
+    struct Run { Params P; uint32_t nslots = 0, pass = 0, since_connect = 0; unsigned blocks = 0, gen_blocks = 0; int connect_every = 1, cur = 0; bool work_left = true, done = false; };
     Run runs[MER_MAX_PIPES];
     HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int q = 0; q < npipes; q++) {
@@ -687,9 +687,10 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         }
         if (!pp.live) {
             HIP_CHECK(ctx, hipMalloc((void **) &pp.live, MER_LIVE_SLOTS * sizeof(uint32_t)));
-            HIP_CHECK(ctx, hipHostMalloc((void **) &pp.host_live, 4 * sizeof(uint32_t)));
+            HIP_CHECK(ctx, hipHostMalloc((void **) &pp.host_live, 8 * sizeof(uint32_t)));
             HIP_CHECK(ctx, hipMalloc((void **) &pp.hitq_ctr, 64 * sizeof(unsigned long long)));       // [0] tail, [32] head, [48] this pipeline's work counter
-            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.readback, hipEventDisableTiming));
+            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.readback[0], hipEventDisableTiming));
+            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.readback[1], hipEventDisableTiming));
             HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.finished, hipEventDisableTiming));
         }
         // pipeline q's part of the shard: sample indices spp_begin + (q + k npipes) spp_stride
@@ -728,8 +729,10 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         auto kge = (extra || BND != 0) ? gen_kernel<decltype(curved)::value, true, BND> : gen_kernel<decltype(curved)::value, BND != 0, BND>;
         const uint32_t check_every = 8;
         const bool adaptive = getenv("MER_FIXED_K") == nullptr;
-        // one batch = check_every passes of a pipeline followed by the read-back of its finished-slot count
-        auto enqueue_batch = [&](int q) -> int {
+        // one batch = check_every passes of a pipeline followed by the read-back of its finished-slot count into slot `rb`.  Two batches
+        // are kept in flight per pipeline, so that a pipeline never runs dry while the host waits for another one's read-back (a
+        // finished render thus carries one batch of empty passes: ~0.5 ms)
+        auto enqueue_batch = [&](int q, int rb) -> int {
             Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
             for (uint32_t b = 0; b < check_every; b++) {
                 const uint32_t pass = R.pass;
@@ -749,30 +752,31 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
                 R.pass++;
             }
             HIP_CHECK(ctx, hipGetLastError());
-            HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live, pp.live, sizeof(uint32_t), hipMemcpyDeviceToHost, pp.stream));
-            HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 2, R.P.work_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, pp.stream));
-            HIP_CHECK(ctx, hipEventRecord(pp.readback, pp.stream));
-            R.pending = true;
+            HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 4 * rb, pp.live, sizeof(uint32_t), hipMemcpyDeviceToHost, pp.stream));
+            HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 4 * rb + 2, R.P.work_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, pp.stream));
+            HIP_CHECK(ctx, hipEventRecord(pp.readback[rb], pp.stream));
             return 0;
         };
-        for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q)) return 1;
+        for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q, 0)) return 1;
+        for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q, 1)) return 1;
         for (;;) {
             bool any = false;
             for (int q = 0; q < npipes; q++) {
                 Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
                 if (R.done) continue;
                 any = true;
-                HIP_CHECK(ctx, hipEventSynchronize(pp.readback));
-                R.pending = false;
-                if (*pp.host_live >= R.nslots) { R.done = true; continue; }
-                R.work_left = *(unsigned long long *) (pp.host_live + 2) < R.P.total_work;
+                const int rb = R.cur; R.cur ^= 1;
+                HIP_CHECK(ctx, hipEventSynchronize(pp.readback[rb]));
+                const uint32_t finished_slots = pp.host_live[4 * rb];
+                if (finished_slots >= R.nslots) { R.done = true; continue; }
+                R.work_left = *(unsigned long long *) (pp.host_live + 4 * rb + 2) < R.P.total_work;
                 if (adaptive) {          // tail: few lanes left => longer passes, fewer launches
-                    const uint32_t alive = R.nslots - *pp.host_live;
+                    const uint32_t alive = R.nslots - finished_slots;
                     R.P.ksteps = alive < R.nslots / 64 ? ksteps0 * 32 : (alive < R.nslots / 16 ? ksteps0 * 8 : (alive < R.nslots / 4 ? ksteps0 * 2 : ksteps0));
                     R.connect_every = alive < R.nslots / 4 ? 1 : connect_every0;
                 }
                 if (R.pass > (1u << 24)) return fail(ctx, "mer_render: pass limit exceeded");
-                if (enqueue_batch(q)) return 1;
+                if (enqueue_batch(q, rb)) return 1;
             }
             if (!any) break;
         }
