@@ -183,7 +183,7 @@ def main():
         b_march = (b_alg - 40.0 * paths_rank / max(args.steps, 1))
         per_launch_bytes = b_march / max(n_pass, 1.0)
         per_launch_ms = m_ms / max(n_pass, 1.0)
-        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0     # 0: MER_NO_PASS_EVENTS A/B runs
         achieved_step = b_alg / (k_ms * 1e-3) / 1e9
         lane_eff = float(counters[capi.C_ACTIVE_LANES] / max(counters[capi.C_LOOP_ITERS], 1.0))
         name, cus, hbm = ctx.device_info()

@@ -133,7 +133,9 @@ int  mer_abi_version(void);
 int  mer_context_create(int32_t device_id, mer_context **out);
 void mer_context_destroy(mer_context *ctx);
 const char *mer_last_error(mer_context *ctx);       /* ctx may be NULL: error of a failed create */
-/* run kernels on this hipStream_t (NULL = default stream) */
+/* run kernels on this hipStream_t (NULL = default stream).  mer_render cuts its shard into a few independent pipelines: the first runs on
+   this stream, the others on internal non-blocking streams that start after the work already queued on this stream (an event) and
+   are joined into it before mer_render returns -- the caller sees one stream. */
 int  mer_context_set_stream(mer_context *ctx, void *hip_stream);
 int  mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu_count, int64_t *hbm_bytes);
 
@@ -170,7 +172,8 @@ int  mer_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *
 int  mer_synchronize(mer_context *ctx);
 /* HIP-event time of the last mer_render kernel in ms (synchronizes) */
 int  mer_last_kernel_ms(mer_context *ctx, float *ms);
-/* wavefront passes of the last mer_render and the summed HIP-event device time of its K_march / K_event launches */
+/* wavefront passes of the last mer_render and the summed HIP-event device time of its K_march / K_event launches (summed over the
+   concurrent pipelines: the sums can exceed the wall time) */
 int  mer_last_render_stats(mer_context *ctx, int32_t *passes, float *march_ms, float *event_ms);
 int  mer_counters_read(mer_context *ctx, uint64_t out[MER_C_COUNT]);    /* StatsCounter analogue */
 int  mer_counters_reset(mer_context *ctx);

@@ -729,6 +729,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
         auto kge = (extra || BND != 0) ? gen_kernel<decltype(curved)::value, true, BND> : gen_kernel<decltype(curved)::value, BND != 0, BND>;
         const uint32_t check_every = 8;
         const bool adaptive = getenv("MER_FIXED_K") == nullptr;
+        const bool pass_events = getenv("MER_NO_PASS_EVENTS") == nullptr;          // per-kernel timing of every pass (mer_last_render_stats)
         // one batch = check_every passes of a pipeline followed by the read-back of its finished-slot count into slot `rb`.  Two batches
         // are kept in flight per pipeline, so that a pipeline never runs dry while the host waits for another one's read-back (a
         // finished render thus carries one batch of empty passes: ~0.5 ms)
@@ -739,16 +740,16 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
                 while (pp.pass_events.size() < (size_t) (pass + 1) * 3) {
                     hipEvent_t e; HIP_CHECK(ctx, hipEventCreate(&e)); pp.pass_events.push_back(e);
                 }
-                HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 0], pp.stream));
+                if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 0], pp.stream));
                 for (int g = 0; R.work_left && g < (pass == 0 ? 6 : 1); g++) hipLaunchKernelGGL(kge, dim3(R.gen_blocks), dim3(MER_BLOCK), 0, pp.stream, R.P);
                 hipLaunchKernelGGL(kev, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
                 if (connect_stage && ++R.since_connect >= (uint32_t) R.connect_every) {
                     hipLaunchKernelGGL(kco, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
                     R.since_connect = 0; R.P.cq_row++;
                 }
-                HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 1], pp.stream));
+                if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 1], pp.stream));
                 hipLaunchKernelGGL(kma, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
-                HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 2], pp.stream));
+                if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 2], pp.stream));
                 R.pass++;
             }
             HIP_CHECK(ctx, hipGetLastError());
@@ -793,7 +794,7 @@ static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const me
             HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
             double em = 0, mm = 0; uint32_t passes = 0;
             for (int q = 0; q < npipes; q++) {
-                for (uint32_t k = 0; k < runs[q].pass; k++) {
+                for (uint32_t k = 0; pass_events && k < runs[q].pass; k++) {
                     float a = 0, b = 0;
                     (void) hipEventElapsedTime(&a, ctx->pipes[q].pass_events[k * 3 + 0], ctx->pipes[q].pass_events[k * 3 + 1]);
                     (void) hipEventElapsedTime(&b, ctx->pipes[q].pass_events[k * 3 + 1], ctx->pipes[q].pass_events[k * 3 + 2]);
