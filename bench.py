@@ -171,6 +171,21 @@ def main():
     elapsed = float(tmax.item())
     counters = ctx.counters().astype(np.float64)
     paths_rank = float(counters[capi.C_PATHS])
+    # one more step OUTSIDE the timed region with a single pipeline: the dominant kernel's launch duration when its launches do not
+    # share the chip with those of other pipelines (reported as roofline.single_pipeline, next to the figures of the timed region)
+    solo = None
+    if int(os.environ.get("MER_PIPES", "4")) > 1 and not os.environ.get("BENCH_NO_SOLO_STEP"):
+        keep = os.environ.get("MER_PIPES")
+        os.environ["MER_PIPES"] = "1"
+        ctx.counters_reset()
+        t1 = time.perf_counter(); step(args.steps); torch.cuda.synchronize(); solo_wall = time.perf_counter() - t1
+        n1, m1, e1 = ctx.last_render_stats()
+        c1 = ctx.counters().astype(np.float64)
+        solo = (n1, m1, e1, c1, solo_wall)
+        if keep is None:
+            del os.environ["MER_PIPES"]
+        else:
+            os.environ["MER_PIPES"] = keep
     ct = torch.tensor(counters, dtype=torch.float64, device=dev)
     mdist.reduce_counters(ct)
     total_paths = float(ct[capi.C_PATHS].item())
@@ -211,6 +226,16 @@ def main():
                          # whole_step is the aggregate: all algorithmic bytes of the step / its wall time
                          "concurrent_pipelines": int(os.environ.get("MER_PIPES", "4"))},
         }
+        if solo is not None:
+            n1, m1, e1, c1, solo_wall = solo
+            b1 = algorithmic_bytes(c1, p) - 40.0 * float(c1[capi.C_PATHS])
+            out["roofline"]["single_pipeline"] = {
+                "what": "one extra untimed step with MER_PIPES=1: K_march launches that have the chip to themselves",
+                "kernel_avg_launch_ms": m1 / max(n1, 1), "launches_per_step": n1, "algorithmic_bytes_per_launch": b1 / max(n1, 1),
+                "achieved": b1 / max(n1, 1) / (m1 / max(n1, 1) * 1e-3) / 1e9 if m1 > 0 else 0.0,
+                "frac": (b1 / max(n1, 1) / (m1 / max(n1, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if m1 > 0 else 0.0,
+                "kernel_ms_per_step": m1, "event_kernel_ms_per_step": e1, "step_wall_ms": solo_wall * 1e3,
+                "active_lane_fraction": float(c1[capi.C_ACTIVE_LANES] / max(c1[capi.C_LOOP_ITERS], 1.0))}
         # HBM traffic cannot be counted inside this process: it comes from separate `rocprofv3 --pmc` passes of this very
         # command (FETCH_SIZE / WRITE_SIZE, gfx950 read correction applied), committed under profiles/
         tf = os.path.join(ROOT, "profiles", "round1", "pmc_traffic_cfg3_n1.json")
