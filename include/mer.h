@@ -28,7 +28,8 @@ typedef int32_t mer_volume;            /* handle, > 0; 0 = none */
 /* VOL v3 type codes (src/volume/gridvolume.cpp:54-89) */
 enum { MER_VOL_F32 = 1, MER_VOL_U8 = 3 };
 enum { MER_SIGMA_HOMOGENEOUS = 0, MER_SIGMA_GRID = 1 };       /* medium `homogeneous` | `heterogeneous` */
-enum { MER_RIF_CONST = 0, MER_RIF_TRILINEAR = 1, MER_RIF_BSPLINE3 = 2 };  /* none | gridvolume | splinevolume */
+enum { MER_RIF_CONST = 0, MER_RIF_TRILINEAR = 1, MER_RIF_BSPLINE3 = 2,   /* none | gridvolume | splinevolume */
+       MER_RIF_ACOUSTIC = 8 };   /* acousticrifvolume: analytic, no grid (values 3..7 are internal fetch kinds of the trilinear RIF) */
 enum { MER_STEP_VERLET = 0, MER_STEP_RK4 = 1 };
 enum { MER_BOUNDARY_AABB = 0, MER_BOUNDARY_SPHERE = 1, MER_BOUNDARY_SDF = 2 };
 enum { MER_PHASE_ISOTROPIC = 0, MER_PHASE_HG = 1 };
@@ -108,6 +109,11 @@ typedef struct {
        the remainder step, and walks what is left with the ordinary tested trace.  sdf_max_error = the volume's maxSDFError(). */
     int32_t aggressive_tracing;
     float   sdf_max_error;
+    /* rif_mode = MER_RIF_ACOUSTIC: the ultrasound-modulated index of `acousticrifvolume` (src/volume/acousticrifvolume.cpp:101-106,
+       224-342), evaluated analytically: n = n_o + n_max J_m(k_r r) cos(m phi), r = sqrt(y^2 + z^2), phi = atan2(y, z),
+       k_r = 2 pi freq / speed; gradient and Hessian as written there (r clamped at 1e-8).  No `rif` volume. */
+    float   ac_n_o, ac_n_max, ac_k_r;
+    int32_t ac_mode;
 } mer_scene_desc;
 enum { MER_BSDF_NULL = 0, MER_BSDF_HDIELECTRIC = 1 };
 enum { MER_MODULATION_NONE = 0, MER_MODULATION_SINE, MER_MODULATION_SQUARE, MER_MODULATION_HAMILTONIAN, MER_MODULATION_MSEQ,

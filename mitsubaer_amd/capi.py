@@ -58,6 +58,7 @@ class SceneDesc(C.Structure):
         ("sdf", C.c_int32),
         ("aggressive_tracing", C.c_int32),
         ("sdf_max_error", C.c_float),
+        ("ac_n_o", C.c_float), ("ac_n_max", C.c_float), ("ac_k_r", C.c_float), ("ac_mode", C.c_int32),
     ]
 
 
@@ -204,6 +205,7 @@ class Context:
         s.albedo_grid = albedo_grid.handle if albedo_grid is not None else 0
         s.rif_mode, s.rif_const = p.rif_mode, p.rif_const
         s.rif = rif.handle if rif is not None else 0
+        s.ac_n_o, s.ac_n_max, s.ac_k_r, s.ac_mode = float(p.ac_n_o), float(p.ac_n_max), float(p.ac_k_r), int(p.ac_mode)
         s.stepper, s.stepsize = p.stepper, p.stepsize
         s.phase, s.g = p.phase, p.g
         s.tr_estimator = p.tr_estimator
@@ -229,7 +231,7 @@ class Context:
         if p.albedo_mode == P.ALBEDO_GRID and p.albedo_grid is not None:
             alb = self.upload_volume(p.albedo_grid, p.albedo_aabb[0], p.albedo_aabb[1])
             vols.append(alb)
-        if p.rif_mode != P.RIF_CONST and p.rif is not None:
+        if p.rif_mode not in (P.RIF_CONST, P.RIF_ACOUSTIC) and p.rif is not None:
             rl = layout if rif_layout is None else rif_layout
             rif = self.upload_volume(p.rif, p.rif_aabb[0], p.rif_aabb[1], rl if p.rif_mode == P.RIF_TRILINEAR else LAYOUT_DENSE)
             if p.rif_mode == P.RIF_BSPLINE3:

@@ -161,7 +161,15 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bo
         Volume tmp = it->second; tmp.cell8 = nullptr;
         fill_dgrid(tmp, P.albedo);
     }
-    if (sc->rif_mode != MER_RIF_CONST) {
+    if (sc->rif_mode == MER_RIF_ACOUSTIC) {
+        // acousticrifvolume: analytic, no grid (src/volume/acousticrifvolume.cpp:101-106)
+        if (!(sc->stepsize > 0)) return fail(ctx, "heterogeneousrefractive: 'stepsize' must be positive");
+        if (!(sc->ac_k_r > 0) || !(sc->ac_n_o > 0) || sc->ac_mode < 0 || !std::isfinite(sc->ac_n_max)) return fail(ctx, "acousticrifvolume: n_o and k_r = 2 pi freq / speed must be positive, mode non-negative");
+        std::memset(&P.rif, 0, sizeof(P.rif));
+        P.rif.ac_n_o = sc->ac_n_o; P.rif.ac_n_max = sc->ac_n_max; P.rif.ac_k_r = sc->ac_k_r; P.rif.ac_mode = sc->ac_mode;
+        P.rif.res[0] = P.rif.res[1] = P.rif.res[2] = 2;
+    } else if (sc->rif_mode != MER_RIF_CONST) {
+        if (sc->rif_mode != MER_RIF_TRILINEAR && sc->rif_mode != MER_RIF_BSPLINE3) return fail(ctx, "unknown rif_mode");
         auto it = ctx->volumes.find(sc->rif);
         if (it == ctx->volumes.end()) return fail(ctx, "No RIF specified!");                                        // heterogeneousrefractive.cpp:368-369
         if (it->second.desc.channels != 1 || it->second.desc.dtype != MER_VOL_F32)
@@ -275,6 +283,8 @@ template <typename F> static int dispatch_modes(mer_context *ctx, const mer_scen
     if (rifk == R && sc->stepper == S && (int) grid == G)                                                         \
         return f(std::integral_constant<bool, true>(), std::integral_constant<int, R>(), std::integral_constant<int, S>(), \
                  std::integral_constant<int, G>(), std::integral_constant<int, 0>());
+    MER_CASE(RIFK_ACOUSTIC, MER_STEP_VERLET, 1) MER_CASE(RIFK_ACOUSTIC, MER_STEP_RK4, 1)
+    MER_CASE(RIFK_ACOUSTIC, MER_STEP_VERLET, 0) MER_CASE(RIFK_ACOUSTIC, MER_STEP_RK4, 0)
     MER_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET, 1) MER_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4, 1)
     MER_CASE(RIFK_DENSE_BUF, MER_STEP_VERLET, 1) MER_CASE(RIFK_DENSE_BUF, MER_STEP_RK4, 1)
     MER_CASE(RIFK_CELL8, MER_STEP_VERLET, 1) MER_CASE(RIFK_CELL8, MER_STEP_RK4, 1)
@@ -923,6 +933,7 @@ int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0,
     MER_TRACE_CASE(RIFK_CELL8, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_CELL8, MER_STEP_RK4)
     MER_TRACE_CASE(RIFK_CELL8_BUF, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_CELL8_BUF, MER_STEP_RK4)
     MER_TRACE_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET) MER_TRACE_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4)
+    MER_TRACE_CASE(RIFK_ACOUSTIC, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_ACOUSTIC, MER_STEP_RK4)
 #undef MER_TRACE_CASE
     HIP_CHECK(ctx, hipGetLastError());
     if (op.download(out_p, n * 12) || ov.download(out_v, n * 12) || od.download(out_dist_surf, n * 4) || oo.download(out_opt, n * 4) ||

@@ -65,7 +65,28 @@ __device__ __forceinline__ void bspline_weights2(float t, float d2[4]) {
 // Spline<3>::valueGradientAndHessian (basisspline.h:539-606) / Hessian of the trilinear interpolant (mixed terms only)
 template <int RIF>
 __device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, CellCache &cc, f3 p, float &val, f3 &grad, m33 &H) {
-    if (RIF == MER_RIF_BSPLINE3) {
+    if (RIF == RIFK_ACOUSTIC) {
+        // AcousticRIFVolume::hessian (src/volume/acousticrifvolume.cpp:254-308); its "x" is our z (cos phi = z / r), its "y" our y
+        acoustic_value_grad(g, p, val, grad);
+        float py = p.y, pz = p.z;
+        float r = sqrtf(py * py + pz * pz);
+        const float phi = atan2f(py, pz);
+        if (r < MER_EPSILON_RIF) { py = MER_EPSILON_RIF; pz = MER_EPSILON_RIF; r = MER_EPSILON_RIF; }
+        const float kr = g.ac_k_r, krr = kr * r, m = (float) g.ac_mode, nmax = g.ac_n_max;
+        const float j0 = jnf(g.ac_mode, krr), j1 = jnf(g.ac_mode + 1, krr), j2 = jnf(g.ac_mode + 2, krr);
+        const float d0 = m / krr * j0 - j1, d1 = (m + 1.0f) / krr * j1 - j2;
+        const float invr = 1.0f / r, invr2 = invr * invr;
+        const float cosp = cosf(phi), sinp = sinf(phi), cosmp = cosf(m * phi), sinmp = sinf(m * phi);
+        const float cosm1p = cosf((m - 1.0f) * phi), sinm1p = sinf((m - 1.0f) * phi), cosm2p = cosf((m - 2.0f) * phi), sinm2p = sinf((m - 2.0f) * phi);
+        const float Hxx = nmax * (j0 * m * invr2 * (-cosm2p + m * sinm1p * sinp) + d0 * m * invr * kr * cosm1p * cosp
+                                  - j1 * kr * py * invr2 * (sinp * cosmp + m * cosp * sinmp) - d1 * kr * kr * cosp * cosp * cosmp);
+        const float Hxy = nmax * (-j0 * m * invr2 * (-sinm2p + m * sinm1p * cosp) + d0 * m * invr * kr * cosm1p * sinp
+                                  + j1 * kr * pz * invr2 * (sinp * cosmp + m * cosp * sinmp) - d1 * kr * kr * cosp * sinp * cosmp);
+        const float Hyy = -nmax * (j0 * m * invr2 * (-cosm2p + m * cosm1p * cosp) + d0 * m * invr * kr * sinm1p * sinp
+                                   + j1 * kr * pz * invr2 * (cosp * cosmp - m * sinp * sinmp) + d1 * kr * kr * sinp * sinp * cosmp);
+        H = m33(0.0f);
+        H.m[1][1] = Hyy; H.m[1][2] = H.m[2][1] = Hxy; H.m[2][2] = Hxx;
+    } else if (RIF == MER_RIF_BSPLINE3) {
         const float px = (p.x - g.bmin[0]) * g.s[0], py = (p.y - g.bmin[1]) * g.s[1], pz = (p.z - g.bmin[2]) * g.s[2];
         const float flx = floorf(px), fly = floorf(py), flz = floorf(pz);
         float wx[4], dx[4], ex[4], wy[4], dy[4], ey[4], wz[4], dz[4], ez[4];

@@ -76,6 +76,7 @@ struct DGrid {
     float   bmin[3], bmax[3];
     float   lim_min[3], lim_max[3];   // spline interpolatable limits (splinevolume.cpp:280-281)
     uint32_t buf_bytes;               // byte size of data / cell8 when it fits a buffer descriptor (< 4 GiB), else 0
+    float   ac_n_o, ac_n_max, ac_k_r; int32_t ac_mode;   // RIFK_ACOUSTIC: the analytic field of acousticrifvolume (no data)
 };
 
 // include/mitsuba/core/aabb.h:308-339 (dRcp = 1/d as Ray::setDirection)
@@ -172,6 +173,7 @@ struct CellCache {
 //   RIFK_CELL8 (4): cell-major grid, global loads                   RIFK_CELL8_BUF (5): cell-major, buffer loads
 // Buffer loads take a 32-bit byte offset against a wave-uniform descriptor: one VGPR of address arithmetic per
 // fetch instead of eight 64-bit adds, and the +row / +slice strides ride in the scalar offset operand.
+#define RIFK_ACOUSTIC 8          // == MER_RIF_ACOUSTIC: analytic Bessel-mode field, no fetch
 #define RIFK_BRICK27_BUF 6
 #define RIFK_BRICK27 7
 #define RIFK_DENSE_BUF 3
@@ -325,8 +327,25 @@ __device__ __forceinline__ bool inside_volume_limits(const DGrid &g, f3 p) {   /
            p.z > g.lim_min[2] && p.z < g.lim_max[2];
 }
 
+// AcousticRIFVolume::valueAndGradient / gradientAndHessian (src/volume/acousticrifvolume.cpp:224-342): n = n_o + n_max J_m(k_r r) cos(m phi)
+// in the (y, z) plane, r clamped at EpsilonRIF = 1e-8 (:15, :235-239); single precision, jnf / atan2f of the device library.
+#define MER_EPSILON_RIF 1e-8f
+__device__ __forceinline__ void acoustic_value_grad(const DGrid &g, f3 pc, float &n, f3 &gr) {
+    float py = pc.y, pz = pc.z;
+    float r = sqrtf(py * py + pz * pz);
+    const float phi = atan2f(py, pz);
+    if (r < MER_EPSILON_RIF) { py = MER_EPSILON_RIF; pz = MER_EPSILON_RIF; r = MER_EPSILON_RIF; }
+    const float kr = g.ac_k_r, krr = kr * r, m = (float) g.ac_mode;
+    const float bj = jnf(g.ac_mode, krr), dbj = m / krr * bj - jnf(g.ac_mode + 1, krr);
+    const float invr = 1.0f / r, invr2 = invr * invr;
+    const float cosmp = cosf(m * phi), sinmp = sinf(m * phi);
+    n = g.ac_n_o + g.ac_n_max * bj * cosmp;
+    gr = f3(0.0f, g.ac_n_max * (dbj * kr * py * invr * cosmp - bj * m * sinmp * pz * invr2),
+            g.ac_n_max * (dbj * kr * pz * invr * cosmp + bj * m * sinmp * py * invr2));
+}
 template <int RIF> __device__ __forceinline__ void rif_value_grad(const DGrid &g, CellCache &cc, f3 p, float &n, f3 &gr) {
-    if (RIF != MER_RIF_BSPLINE3) trilinear_value_grad<RIF>(g, cc, p, n, gr);
+    if (RIF == RIFK_ACOUSTIC) acoustic_value_grad(g, p, n, gr);
+    else if (RIF != MER_RIF_BSPLINE3) trilinear_value_grad<RIF>(g, cc, p, n, gr);
     else bspline_value_grad(g, p, n, gr);
 }
 
@@ -601,8 +620,10 @@ __device__ __forceinline__ bool dielectric_event(const Params &P, Rng &rng, f3 r
     float etaB = S.rif_const;
     if (CURVED) {
         f3 q = x; f3 g; CellCache cc; cc.reset();
-        q.x = fminf(fmaxf(q.x, P.rif.bmin[0]), P.rif.bmax[0]); q.y = fminf(fmaxf(q.y, P.rif.bmin[1]), P.rif.bmax[1]);
-        q.z = fminf(fmaxf(q.z, P.rif.bmin[2]), P.rif.bmax[2]);
+        if (RIF != RIFK_ACOUSTIC) {                              // the analytic field has no grid to stay inside of
+            q.x = fminf(fmaxf(q.x, P.rif.bmin[0]), P.rif.bmax[0]); q.y = fminf(fmaxf(q.y, P.rif.bmin[1]), P.rif.bmax[1]);
+            q.z = fminf(fmaxf(q.z, P.rif.bmin[2]), P.rif.bmax[2]);
+        }
         rif_value_grad<RIF>(P.rif, cc, q, etaB, g);
     }
     const float invEtaB = 1 / etaB;

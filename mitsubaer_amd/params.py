@@ -11,6 +11,7 @@ import numpy as np
 VOL_F32, VOL_U8 = 1, 3
 SIGMA_HOMOGENEOUS, SIGMA_GRID = 0, 1
 RIF_CONST, RIF_TRILINEAR, RIF_BSPLINE3 = 0, 1, 2
+RIF_ACOUSTIC = 8          # acousticrifvolume, evaluated analytically: n_o + n_max J_m(k_r r) cos(m phi) in the (y, z) plane
 STEP_VERLET, STEP_RK4 = 0, 1
 BOUNDARY_AABB, BOUNDARY_SPHERE, BOUNDARY_SDF = 0, 1, 2
 PHASE_ISOTROPIC, PHASE_HG = 0, 1
@@ -66,6 +67,8 @@ class SceneParams:
         self.albedo_mode = ALBEDO_CONST; self.albedo = [0.9, 0.9, 0.9]
         self.albedo_grid = None; self.albedo_aabb = ([-1, -1, -1], [1, 1, 1])
         self.rif_mode = RIF_CONST; self.rif_const = 1.0
+        # RIF_ACOUSTIC (src/volume/acousticrifvolume.cpp:101-106): n_o, n_max, k_r = 2 pi freq / speed, mode
+        self.ac_n_o = 1.3333; self.ac_n_max = 0.0; self.ac_k_r = 2.0 * 3.14159265358979323846 * 832000.0 / 1500.0; self.ac_mode = 0
         self.rif = None; self.rif_aabb = ([-1, -1, -1], [1, 1, 1])
         self.stepper = STEP_RK4; self.stepsize = 1e-3
         self.rif_double = 0

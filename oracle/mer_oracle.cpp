@@ -420,14 +420,60 @@ struct MediumRec {   /* include/mitsuba/render/medium.h:40-98 (fields used on th
     Float pdfSuccess, pdfFailure, refRatioSq, opticalLength;
 };
 
+/* AcousticRIFVolume (src/volume/acousticrifvolume.cpp:15,224-342): the ultrasound-modulated index in the (y, z) plane, evaluated in
+   FLOAT with the C library's Bessel functions (jnf for float, as the GPU's device library; jn for double) */
+template <typename FLOAT> struct AcousticRif {
+    FLOAT n_o, n_max, k_r; int mode;
+    static inline float bessel(int n, float x) { return ::jnf(n, x); }
+    static inline double bessel(int n, double x) { return ::jn(n, x); }
+    inline void polar(const V3<FLOAT> &pc, FLOAT &py, FLOAT &pz, FLOAT &r, FLOAT &phi) const {
+        const FLOAT eps = (FLOAT) 1e-8f;                                     /* EpsilonRIF (:15) */
+        py = pc.y; pz = pc.z;
+        r = std::sqrt(py * py + pz * pz);
+        phi = std::atan2(py, pz);
+        if (r < eps) { py = eps; pz = eps; r = eps; }                        /* :235-239 */
+    }
+    /* valueAndGradient (:312-342) */
+    inline void valueAndGradient(const V3<FLOAT> &pc, FLOAT &f, V3<FLOAT> &v) const {
+        FLOAT py, pz, r, phi; polar(pc, py, pz, r, phi);
+        const FLOAT krr = k_r * r, m = (FLOAT) mode;
+        const FLOAT bj = bessel(mode, krr), dbj = m / krr * bj - bessel(mode + 1, krr);
+        const FLOAT invr = (FLOAT) 1 / r, invr2 = invr * invr;
+        const FLOAT cosmp = std::cos(m * phi), sinmp = std::sin(m * phi);
+        f = n_o + n_max * bj * cosmp;
+        v = V3<FLOAT>(0, n_max * (dbj * k_r * py * invr * cosmp - bj * m * sinmp * pz * invr2),
+                      n_max * (dbj * k_r * pz * invr * cosmp + bj * m * sinmp * py * invr2));
+    }
+    /* hessian (:254-308); the reference's "x" is the z axis here (cos phi = z / r), its "y" the y axis; H row-major over (x, y, z) */
+    inline void hessian(const V3<FLOAT> &pc, FLOAT H[9]) const {
+        FLOAT py, pz, r, phi; polar(pc, py, pz, r, phi);
+        const FLOAT krr = k_r * r, m = (FLOAT) mode;
+        const FLOAT j0 = bessel(mode, krr), j1 = bessel(mode + 1, krr), j2 = bessel(mode + 2, krr);
+        const FLOAT d0 = m / krr * j0 - j1, d1 = (m + 1) / krr * j1 - j2;
+        const FLOAT invr = (FLOAT) 1 / r, invr2 = invr * invr;
+        const FLOAT cosp = std::cos(phi), sinp = std::sin(phi), cosmp = std::cos(m * phi), sinmp = std::sin(m * phi);
+        const FLOAT cosm1p = std::cos((m - 1) * phi), sinm1p = std::sin((m - 1) * phi), cosm2p = std::cos((m - 2) * phi), sinm2p = std::sin((m - 2) * phi);
+        const FLOAT Hxx = n_max * (j0 * m * invr2 * (-cosm2p + m * sinm1p * sinp) + d0 * m * invr * k_r * cosm1p * cosp
+                                   - j1 * k_r * py * invr2 * (sinp * cosmp + m * cosp * sinmp) - d1 * k_r * k_r * cosp * cosp * cosmp);
+        const FLOAT Hxy = n_max * (-j0 * m * invr2 * (-sinm2p + m * sinm1p * cosp) + d0 * m * invr * k_r * cosm1p * sinp
+                                   + j1 * k_r * pz * invr2 * (sinp * cosmp + m * cosp * sinmp) - d1 * k_r * k_r * cosp * sinp * cosmp);
+        const FLOAT Hyy = -n_max * (j0 * m * invr2 * (-cosm2p + m * cosm1p * cosp) + d0 * m * invr * k_r * sinm1p * sinp
+                                    + j1 * k_r * pz * invr2 * (cosp * cosmp - m * sinp * sinmp) + d1 * k_r * k_r * sinp * sinp * cosmp);
+        for (int i = 0; i < 9; i++) H[i] = 0;
+        H[4] = Hyy; H[5] = H[7] = Hxy; H[8] = Hxx;
+    }
+};
+
 template <typename FLOAT> struct Rif {
     int mode; FLOAT cst;
+    AcousticRif<FLOAT> ac;
     Grid grid;
     Spline3<FLOAT> spline;
     FLOAT limMin[3], limMax[3];   /* splinevolume.cpp:280-281 interpolatable limits */
     void configure(const orc_scene &s) {
         mode = s.rif_mode; cst = (FLOAT) s.rif_const;
-        if (mode != ORC_RIF_CONST) {
+        if (mode == ORC_RIF_ACOUSTIC) { ac.n_o = (FLOAT) s.ac_n_o; ac.n_max = (FLOAT) s.ac_n_max; ac.k_r = (FLOAT) s.ac_k_r; ac.mode = s.ac_mode; }
+        else if (mode != ORC_RIF_CONST) {
             grid.configure(s.rif);
             if (mode == ORC_RIF_BSPLINE3) {
                 FLOAT mn[3], mx[3];
@@ -449,6 +495,7 @@ template <typename FLOAT> struct Rif {
     inline FLOAT value(const V3<FLOAT> &p, Counters &C) const {
         C.c[ORC_C_RIF_EVALS]++;
         if (mode == ORC_RIF_CONST) return cst;
+        if (mode == ORC_RIF_ACOUSTIC) { FLOAT v; V3<FLOAT> g; ac.valueAndGradient(p, v, g); return v; }
         if (mode == ORC_RIF_TRILINEAR) { FLOAT v; V3<FLOAT> g; trilinearValueGrad<FLOAT>(grid, p, v, g); return v; }
         FLOAT x[3] = {p.x, p.y, p.z};
         return spline.value(x);              /* splinevolume.cpp:330-337 */
@@ -456,6 +503,7 @@ template <typename FLOAT> struct Rif {
     inline void valueAndGradient(const V3<FLOAT> &p, FLOAT &n, V3<FLOAT> &g, Counters &C) const {
         C.c[ORC_C_RIF_EVALS]++;
         if (mode == ORC_RIF_CONST) { n = cst; g = V3<FLOAT>(0, 0, 0); return; }
+        if (mode == ORC_RIF_ACOUSTIC) { ac.valueAndGradient(p, n, g); return; }
         if (mode == ORC_RIF_TRILINEAR) { trilinearValueGrad<FLOAT>(grid, p, n, g); return; }
         FLOAT x[3] = {p.x, p.y, p.z};
         spline.valueAndGradient(x, n, g);    /* splinevolume.cpp:354-360 (rotation = identity) */
@@ -463,6 +511,7 @@ template <typename FLOAT> struct Rif {
     inline V3<FLOAT> gradient(const V3<FLOAT> &p, Counters &C) const {
         C.c[ORC_C_RIF_EVALS]++;
         if (mode == ORC_RIF_CONST) return V3<FLOAT>(0, 0, 0);
+        if (mode == ORC_RIF_ACOUSTIC) { FLOAT v; V3<FLOAT> g; ac.valueAndGradient(p, v, g); return g; }
         if (mode == ORC_RIF_TRILINEAR) { FLOAT v; V3<FLOAT> g; trilinearValueGrad<FLOAT>(grid, p, v, g); return g; }
         FLOAT x[3] = {p.x, p.y, p.z};
         return spline.gradient(x);           /* splinevolume.cpp:338-344 */
@@ -473,6 +522,7 @@ template <typename FLOAT> struct Rif {
         C.c[ORC_C_RIF_EVALS]++;
         for (int i = 0; i < 9; i++) H[i] = 0;
         if (mode == ORC_RIF_CONST) { n = cst; g = V3<FLOAT>(0, 0, 0); return; }
+        if (mode == ORC_RIF_ACOUSTIC) { ac.valueAndGradient(p, n, g); ac.hessian(p, H); return; }
         if (mode == ORC_RIF_BSPLINE3) { FLOAT x[3] = {p.x, p.y, p.z}; spline.valueGradientAndHessian(x, n, g, H); return; }
         trilinearValueGrad<FLOAT>(grid, p, n, g);
         const Grid &G = grid;
@@ -719,7 +769,9 @@ struct Scene {
         if (s.rif_mode == ORC_RIF_CONST) return s.rif_const;
         Counters dummy; Vec q = x;
         const Float *mn = s.rif.aabb_min, *mx = s.rif.aabb_max;
-        q.x = std::min(std::max(q.x, mn[0]), mx[0]); q.y = std::min(std::max(q.y, mn[1]), mx[1]); q.z = std::min(std::max(q.z, mn[2]), mx[2]);
+        if (s.rif_mode != ORC_RIF_ACOUSTIC) {                    /* the analytic field has no grid to stay inside of */
+            q.x = std::min(std::max(q.x, mn[0]), mx[0]); q.y = std::min(std::max(q.y, mn[1]), mx[1]); q.z = std::min(std::max(q.z, mn[2]), mx[2]);
+        }
         return s.rif_double ? (Float) rifD.value(V3<double>(q), dummy) : rifF.value(V3<float>(q), dummy);
     }
     inline Spec albedoAt(const Vec &p) const {
@@ -1686,6 +1738,24 @@ void orc_bspline_eval_f32(const float *coeff, const int32_t N[3], const float xm
 void orc_bspline_eval_f64(const double *coeff, const int32_t N[3], const float xmin[3], const float xmax[3],
                           const double *pts, int64_t n, double *val, double *grad, double *hess) {
     bsplineEval<double>(coeff, N, xmin, xmax, pts, n, val, grad, hess);
+}
+
+/* the scene's RIF (any rif_mode) at n points: value, gradient[3], Hessian[9] row-major; fp64 when rif_double */
+void orc_rif_eval(const orc_scene *s, const float *pts, int64_t n, double *val, double *grad, double *hess) {
+    SceneHolder H(s); Counters C;
+    for (int64_t i = 0; i < n; i++) {
+        if (s->rif_double) {
+            V3<double> p(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), g; double f, M[9];
+            H.S.rifD.valueGradientAndHessian(p, f, g, M, C);
+            val[i] = f; grad[3 * i] = g.x; grad[3 * i + 1] = g.y; grad[3 * i + 2] = g.z;
+            for (int k = 0; k < 9; k++) hess[9 * i + k] = M[k];
+        } else {
+            V3<float> p(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]), g; float f, M[9];
+            H.S.rifF.valueGradientAndHessian(p, f, g, M, C);
+            val[i] = f; grad[3 * i] = g.x; grad[3 * i + 1] = g.y; grad[3 * i + 2] = g.z;
+            for (int k = 0; k < 9; k++) hess[9 * i + k] = M[k];
+        }
+    }
 }
 
 void orc_er_trace(const orc_scene *s, const float *p0, const float *d0, const float *dist, int64_t n,

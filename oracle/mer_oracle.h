@@ -34,7 +34,7 @@ typedef struct {
 } orc_grid;
 
 enum { ORC_SIGMA_HOMOGENEOUS = 0, ORC_SIGMA_GRID = 1 };
-enum { ORC_RIF_CONST = 0, ORC_RIF_TRILINEAR = 1, ORC_RIF_BSPLINE3 = 2 };
+enum { ORC_RIF_CONST = 0, ORC_RIF_TRILINEAR = 1, ORC_RIF_BSPLINE3 = 2, ORC_RIF_ACOUSTIC = 8 /* acousticrifvolume: analytic */ };
 enum { ORC_STEP_VERLET = 0, ORC_STEP_RK4 = 1 };
 enum { ORC_BOUNDARY_AABB = 0, ORC_BOUNDARY_SPHERE = 1, ORC_BOUNDARY_SDF = 2 };
 enum { ORC_PHASE_ISOTROPIC = 0, ORC_PHASE_HG = 1 };
@@ -91,6 +91,9 @@ typedef struct {
     /* `aggressivetracing` (src/medium/heterogeneousrefractive.cpp:230,473-493,697-704) and the volume's maxSDFError() */
     int32_t aggressive_tracing;
     float   sdf_max_error;
+    /* rif_mode = ORC_RIF_ACOUSTIC (src/volume/acousticrifvolume.cpp:101-106,224-342): n = n_o + n_max J_m(k_r r) cos(m phi) */
+    float   ac_n_o, ac_n_max, ac_k_r;
+    int32_t ac_mode;
 } orc_scene;
 enum { ORC_BSDF_NULL = 0, ORC_BSDF_HDIELECTRIC = 1 };
 
@@ -114,6 +117,7 @@ void orc_bspline_eval_f32(const float *coeff, const int32_t N[3], const float xm
 void orc_bspline_eval_f64(const double *coeff, const int32_t N[3], const float xmin[3], const float xmax[3],
                           const double *pts, int64_t n, double *val, double *grad, double *hess);
 /* A6/A7: trace(p, v, dist) over a RIF; out per ray: p(3) v(3) distSurf opt success */
+void orc_rif_eval(const orc_scene *s, const float *pts, int64_t n, double *val, double *grad, double *hess);
 void orc_er_trace(const orc_scene *s, const float *p0, const float *d0, const float *dist, int64_t n,
                   float *out_p, float *out_v, float *out_dist_surf, float *out_opt, int32_t *out_success);
 /* A3/A8: sampleDistance for one ray per (seed,index) stream; outputs

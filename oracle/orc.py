@@ -57,6 +57,7 @@ class Scene(C.Structure):
         ("sdf", Grid),
         ("aggressive_tracing", C.c_int32),
         ("sdf_max_error", C.c_float),
+        ("ac_n_o", C.c_float), ("ac_n_max", C.c_float), ("ac_k_r", C.c_float), ("ac_mode", C.c_int32),
     ]
 
 
@@ -139,7 +140,9 @@ def make_scene(p):
     s.albedo[:] = p.albedo
     s.albedo_grid = make_grid(p.albedo_grid, p.albedo_aabb[0], p.albedo_aabb[1], keep) if p.albedo_grid is not None else Grid()
     s.rif_mode, s.rif_const = p.rif_mode, p.rif_const
-    s.rif = make_grid(p.rif, p.rif_aabb[0], p.rif_aabb[1], keep) if p.rif is not None else Grid()
+    s.rif = make_grid(p.rif, p.rif_aabb[0], p.rif_aabb[1], keep) if (p.rif is not None and p.rif_mode != 8) else Grid()
+    s.ac_n_o, s.ac_n_max, s.ac_k_r, s.ac_mode = (float(getattr(p, "ac_n_o", 1.0)), float(getattr(p, "ac_n_max", 0.0)),
+                                                 float(getattr(p, "ac_k_r", 1.0)), int(getattr(p, "ac_mode", 0)))
     s.sdf = make_grid(p.sdf, p.sdf_aabb[0], p.sdf_aabb[1], keep) if p.sdf is not None else Grid()
     s.stepper, s.stepsize, s.rif_double = p.stepper, p.stepsize, int(getattr(p, "rif_double", 0))
     s.phase, s.g = p.phase, p.g
@@ -209,6 +212,16 @@ def bspline_eval(coeff, xmin, xmax, pts, hessian=False):
     fn = lib().orc_bspline_eval_f64 if double else lib().orc_bspline_eval_f32
     fn(_fp(c), N, mn, mx, _fp(pts), C.c_int64(n), _fp(val), _fp(grad), _fp(hess) if hessian else None)
     return (val, grad, hess) if hessian else (val, grad)
+
+
+def rif_eval(p, pts):
+    """the scene's RIF (any rif_mode) at pts: value[n], gradient[n][3], Hessian[n][3][3] (float64 arrays; fp64 arithmetic when p.rif_double)"""
+    s, keep = make_scene(p)
+    pts = np.ascontiguousarray(pts, np.float32); n = pts.shape[0]
+    val = np.empty(n, np.float64); grad = np.empty((n, 3), np.float64); hess = np.empty((n, 3, 3), np.float64)
+    f = lib().orc_rif_eval; f.restype = None
+    f(C.byref(s), _fp(pts), C.c_int64(n), val.ctypes.data_as(C.c_void_p), grad.ctypes.data_as(C.c_void_p), hess.ctypes.data_as(C.c_void_p))
+    return val, grad, hess
 
 
 def er_trace(p, p0, d0, dist):
