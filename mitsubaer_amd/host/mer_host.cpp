@@ -80,6 +80,10 @@ struct ConstVolume : VolumeDataSource {
     bool supportsSpectrumLookups() const override { return isSpec; }
     bool isConstant() const override { return true; }
 };
+struct AcousticRIFVolume : VolumeDataSource {                  // src/volume/acousticrifvolume.cpp:101-106
+    bool supportsFloatLookups() const override { return true; }
+    bool isAcoustic() const override { return true; }
+};
 struct GridVolume : VolumeDataSource {
     bool spline = false;
     bool supportsFloatLookups() const override { return channels == 1; }
@@ -248,7 +252,18 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
             (void) props.getBoolean("sendData", false);
             loadVol(*o, resolve(props.getString("filename")), given);
             out = o;
-        } else Log_EError("volume \"" + type + "\" is not supported on the GPU path (gridvolume, splinevolume, constvolume)");
+        } else if (type == "acousticrifvolume") {                                                          // acousticrifvolume.cpp:101-106
+            auto o = std::make_shared<AcousticRIFVolume>();
+            requireIdentity(props, type.c_str());
+            if (props.hasProperty("min")) (void) props.getPoint("min");
+            if (props.hasProperty("max")) (void) props.getPoint("max");
+            const float f_u = props.getFloat("freq", 832000.0f), speed_u = props.getFloat("speed", 1500.0f);
+            o->ac_n_o = props.getFloat("n_o", 1.3333f); o->ac_n_max = props.getFloat("n_max", 0.0f); o->ac_mode = props.getInteger("mode", 0);
+            const float wavelength_u = speed_u / f_u;
+            o->ac_k_r = (float) ((2 * 3.14159265358979323846) / wavelength_u);
+            o->channels = 1;
+            out = o;
+        } else Log_EError("volume \"" + type + "\" is not supported on the GPU path (gridvolume, splinevolume, constvolume, acousticrifvolume)");
     } else if (tag == "medium") {
         auto o = std::make_shared<Medium>();
         o->kind = type;
@@ -638,7 +653,9 @@ void Integrator::flatten(const Scene &scene, mer_scene_desc &d) const {
         else d.albedo_mode = MER_ALBEDO_GRID;
     }
     d.rif_mode = MER_RIF_CONST; d.rif_const = 1.0f;
-    if (m.rif) d.rif_mode = m.rif->isSpline() ? MER_RIF_BSPLINE3 : MER_RIF_TRILINEAR;
+    if (m.rif) d.rif_mode = m.rif->isAcoustic() ? MER_RIF_ACOUSTIC : (m.rif->isSpline() ? MER_RIF_BSPLINE3 : MER_RIF_TRILINEAR);
+    d.ac_n_o = 1.0f; d.ac_n_max = 0.0f; d.ac_k_r = 1.0f; d.ac_mode = 0;
+    if (m.rif && m.rif->isAcoustic()) { d.ac_n_o = m.rif->ac_n_o; d.ac_n_max = m.rif->ac_n_max; d.ac_k_r = m.rif->ac_k_r; d.ac_mode = m.rif->ac_mode; }
     d.stepper = m.stepper; d.stepsize = m.stepsize;
     d.aggressive_tracing = 0; d.sdf_max_error = 0.0f;
     if (m.aggressiveTracing) {
@@ -681,7 +698,7 @@ std::vector<float> Integrator::render(const Scene &scene, int device, int spp, u
     };
     if (m.density) d.density = upload(*m.density, MER_LAYOUT_DENSE);
     if (m.albedo && !m.albedo->isConstant()) d.albedo_grid = upload(*m.albedo, MER_LAYOUT_DENSE);
-    if (m.rif) {
+    if (m.rif && !m.rif->isAcoustic()) {
         d.rif = upload(*m.rif, m.rif->isSpline() ? MER_LAYOUT_DENSE : layout);
         if (m.rif->isSpline() && mer_volume_build_spline(ctx, d.rif)) fail();
     }

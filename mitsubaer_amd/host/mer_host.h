@@ -87,6 +87,8 @@ public:
     virtual bool supportsSpectrumLookups() const { return false; }
     virtual bool isConstant() const { return false; }
     virtual bool isSpline() const { return false; }
+    virtual bool isAcoustic() const { return false; }           // acousticrifvolume: analytic, no payload
+    float ac_n_o = 1.3333f, ac_n_max = 0.0f, ac_k_r = 0.0f; int ac_mode = 0;
     float aabb_min[3] = {0, 0, 0}, aabb_max[3] = {0, 0, 0};
     int res[3] = {0, 0, 0}, channels = 0, dtype = MER_VOL_F32;
     std::vector<unsigned char> data;          // dense payload (gridvolume / splinevolume)

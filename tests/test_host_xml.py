@@ -164,6 +164,22 @@ def test_hdielectric_boundary_flattens(tmp_path):
         host.flatten_xml(_scene(tmp_path, ok.replace('type="hdielectric"', 'type="diffuse"')))
 
 
+def test_acousticrifvolume_is_evaluated_analytically(tmp_path):
+    """`acousticrifvolume` (src/volume/acousticrifvolume.cpp:101-106) as the medium's rif: no payload, rif_mode = MER_RIF_ACOUSTIC,
+    k_r = 2 pi freq / speed"""
+    med = ('<medium type="heterogeneousrefractive" id="m"><spectrum name="sigmaS" value="1"/><spectrum name="sigmaA" value="0.1"/>'
+           '<float name="stepsize" value="0.01"/>'
+           '<volume name="rif" type="acousticrifvolume"><float name="freq" value="1500"/><float name="speed" value="1500"/>'
+           '<float name="n_o" value="1.33"/><float name="n_max" value="0.02"/><integer name="mode" value="2"/></volume></medium>')
+    body = '<integrator type="volpath"/>' + CAM + med + '<shape type="cube"><ref name="interior" id="m"/></shape>'
+    d, _ = host.flatten_xml(_scene(tmp_path, body))
+    assert d.rif_mode == P.RIF_ACOUSTIC and d.ac_mode == 2 and abs(d.ac_n_o - 1.33) < 1e-6 and abs(d.ac_n_max - 0.02) < 1e-7
+    assert abs(d.ac_k_r - 2 * np.pi) < 1e-5 and d.rif == 0
+    dflt = body.replace('<float name="freq" value="1500"/><float name="speed" value="1500"/>', '')
+    d, _ = host.flatten_xml(_scene(tmp_path, dflt))
+    assert abs(d.ac_k_r - 2 * np.pi * 832000.0 / 1500.0) < 1e-2
+
+
 def test_sdf_child_selects_the_signed_distance_boundary(tmp_path):
     dens, rif = _vols(tmp_path)
     sdf = str(tmp_path / "sdf.vol")
