@@ -28,6 +28,15 @@ def scene_set():
         "curved_radial_sphere": scenes.curved_scene(N=16, w=16, h=12, rif="radial", boundary=P.BOUNDARY_SPHERE, sph_radius=0.9),
         "curved_point_emissive": scenes.curved_scene(N=16, w=16, h=12, emission=[0.2, 0.12, 0.06], **pt),
         "straight_point": scenes.straight_scene(N=16, w=16, h=12, **pt),
+        # rows added at the end of round 1: signed-distance boundary (+ hdielectric, + aggressivetracing), analytic acoustic RIF
+        "sdf_dielectric_verlet": scenes.curved_scene(N=16, w=16, h=12, rif="radial", stepper=P.STEP_VERLET, boundary=P.BOUNDARY_SDF,
+                                                     sdf=-synth.sphere_sdf(32, radius=0.9, aabb_min=[-1.2] * 3, aabb_max=[1.2] * 3),
+                                                     sdf_aabb=([-1.2] * 3, [1.2] * 3), boundary_bsdf=P.BSDF_HDIELECTRIC),
+        "sdf_aggressive_rk4": scenes.curved_scene(N=16, w=16, h=12, rif="radial", boundary=P.BOUNDARY_SDF, aggressive_tracing=True,
+                                                  sdf=-synth.sphere_sdf(32, radius=0.9, aabb_min=[-1.2] * 3, aabb_max=[1.2] * 3),
+                                                  sdf_aabb=([-1.2] * 3, [1.2] * 3)),
+        "acoustic_rk4_m1": scenes.straight_scene(N=16, w=16, h=12, rif_mode=P.RIF_ACOUSTIC, ac_n_o=1.33, ac_n_max=0.08, ac_k_r=4.0, ac_mode=1,
+                                                 stepper=P.STEP_RK4, stepsize=0.5 * 2.0 / 15),
     }
 
 
