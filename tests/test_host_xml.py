@@ -105,6 +105,30 @@ def test_xml_render_equals_direct_c_abi_render(tmp_path, ctx):
     assert np.linalg.norm(film1 - ref1) / np.linalg.norm(ref1) < 2e-2
 
 
+@pytest.mark.gpu
+def test_xml_render_with_acousticrifvolume_equals_direct_render(tmp_path, ctx):
+    """the cfg3 scene with its `rif` child replaced by an `acousticrifvolume`: host parse -> MER_RIF_ACOUSTIC -> same film as the direct C-ABI render"""
+    N = 16
+    dens, _ = _vols(tmp_path, N)
+    xml = open(os.path.join(SC, "cfg3_refractive.xml")).read()
+    old = '<volume name="rif" type="$riftype">\n\t\t\t<string name="filename" value="$rif"/>\n\t\t</volume>'
+    assert old in xml
+    xml = xml.replace(old, '<volume name="rif" type="acousticrifvolume"><float name="freq" value="3000"/><float name="speed" value="1500"/>'
+                           '<float name="n_o" value="1.33"/><float name="n_max" value="0.05"/><integer name="mode" value="1"/></volume>')
+    f = str(tmp_path / "acoustic.xml"); open(f, "w").write(xml)
+    defs = {"samples": 4, "size": 48, "density": dens, "stepper": "rk4", "stepsize": 0.5 * 2.0 / (N - 1)}
+    film = host.render_xml(f, defs, seed=3)
+    p = scenes.straight_scene(N=N, w=48, h=48, rfilter=P.FILTER_BOX, rfilter_param=0.5, stepper=P.STEP_RK4, tr_estimator=P.TR_RATIO,
+                              stepsize=0.5 * 2.0 / (N - 1), rif_mode=P.RIF_ACOUSTIC, ac_n_o=1.33, ac_n_max=0.05,
+                              ac_k_r=float(np.float32(2 * 3.14159265358979323846 / np.float32(np.float32(1500.0) / np.float32(3000.0)))), ac_mode=1,
+                              phase=P.PHASE_HG, g=0.8, density_scale=4.0, albedo=[0.9, 0.9, 0.9])
+    sc, vols = ctx.upload_scene(p)
+    ref = ctx.render_to_host(sc, 0, 4, seed=3)
+    assert np.allclose(film, ref, rtol=1e-5, atol=1e-6)
+    for v in vols:
+        v.destroy()
+
+
 def test_transient_film_and_point_emitter_flatten():
     """film decomposition parameters (src/librender/film.cpp:56-84) and the `point` emitter (src/emitters/point.cpp:57-69)"""
     d, spp = host.flatten_xml(os.path.join(SC, "cfg_transient_point.xml"), {"samples": 8, "tMin": 2, "tMax": 10, "tRes": 0.1})
