@@ -658,8 +658,12 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
 // K_connect: curved-ray luminaire sampling of the point emitter for the slots K_event parked on a scattering event
 // (Medium::eval -> makeDirectConnections, src/medium/heterogeneousrefractive.cpp:571-640,1087-1163).  One lane per
 // connection; the sampler stream continues where K_event left it, so the draw order is the oracle's.
+#ifndef MER_CONNECT_WAVES
+#define MER_CONNECT_WAVES 3       // measured on configs[4]: unconstrained (243 VGPR, 2 waves/SIMD) 5.2, 3 waves 5.7, 4 waves 5.0 Mpaths/s
+#endif
+#define MER_CONNECT_BOUNDS __launch_bounds__(MER_BLOCK, MER_CONNECT_WAVES)
 template <int RIF, int STEPPER, int SIGMA, int BND = 0>
-__global__ void __launch_bounds__(MER_BLOCK) connect_stage_kernel(const Params P, uint32_t pass) {
+__global__ void MER_CONNECT_BOUNDS connect_stage_kernel(const Params P, uint32_t pass) {
     constexpr bool EXTRA = true;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
