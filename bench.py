@@ -174,18 +174,13 @@ def main():
     # one more step OUTSIDE the timed region with a single pipeline: the dominant kernel's launch duration when its launches do not
     # share the chip with those of other pipelines (reported as roofline.single_pipeline, next to the figures of the timed region)
     solo = None
-    if int(os.environ.get("MER_PIPES", "4")) > 1 and not os.environ.get("BENCH_NO_SOLO_STEP"):
-        keep = os.environ.get("MER_PIPES")
-        os.environ["MER_PIPES"] = "1"
-        ctx.counters_reset()
-        t1 = time.perf_counter(); step(args.steps); torch.cuda.synchronize(); solo_wall = time.perf_counter() - t1
-        n1, m1, e1 = ctx.last_render_stats()
-        c1 = ctx.counters().astype(np.float64)
-        solo = (n1, m1, e1, c1, solo_wall)
-        if keep is None:
-            del os.environ["MER_PIPES"]
-        else:
-            os.environ["MER_PIPES"] = keep
+    if ctx.get_option("pipes") > 1 and not os.environ.get("BENCH_NO_SOLO_STEP"):
+        with ctx.options(pipes=1):
+            ctx.counters_reset()
+            t1 = time.perf_counter(); step(args.steps); torch.cuda.synchronize(); solo_wall = time.perf_counter() - t1
+            n1, m1, e1 = ctx.last_render_stats()
+            c1 = ctx.counters().astype(np.float64)
+            solo = (n1, m1, e1, c1, solo_wall)
     ct = torch.tensor(counters, dtype=torch.float64, device=dev)
     mdist.reduce_counters(ct)
     total_paths = float(ct[capi.C_PATHS].item())
@@ -208,7 +203,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"cfg2": "configs[1]: ", "cfg3": "configs[2]: ", "cfg4": "configs[3]: ", "cfg5": "configs[4]: "}[args.workload] + desc, "grid": args.res, "film": [p.width, p.height], "spp_per_gpu": args.spp, "pipelines_per_gpu": int(os.environ.get("MER_PIPES", "4")),
+            "config": {"workload": {"cfg2": "configs[1]: ", "cfg3": "configs[2]: ", "cfg4": "configs[3]: ", "cfg5": "configs[4]: "}[args.workload] + desc, "grid": args.res, "film": [p.width, p.height], "spp_per_gpu": args.spp, "pipelines_per_gpu": ctx.get_option("pipes"),
                        "stepper": "rk4", "rif_interp": "trilinear", "layout": args.layout, "shard": args.shard,
                        "stepsize": p.stepsize, "estimator": "volpath + delta tracking on eikonal rays, ratio-tracking NEE",
                        "device": name, "cus": cus},
@@ -224,7 +219,7 @@ def main():
                          # pipelines execute side by side, so one launch's duration is stretched by its neighbours and `achieved` (bytes of
                          # ONE launch / its duration, the rocprofv3 figure) understates the chip's rate by up to that factor;
                          # whole_step is the aggregate: all algorithmic bytes of the step / its wall time
-                         "concurrent_pipelines": int(os.environ.get("MER_PIPES", "4"))},
+                         "concurrent_pipelines": ctx.get_option("pipes")},
         }
         if solo is not None:
             n1, m1, e1, c1, solo_wall = solo

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MER_ABI_VERSION 1
+#define MER_ABI_VERSION 2
 
 typedef struct mer_context mer_context;
 typedef int32_t mer_volume;            /* handle, > 0; 0 = none */
@@ -144,6 +144,27 @@ const char *mer_last_error(mer_context *ctx);       /* ctx may be NULL: error of
    are joined into it before mer_render returns -- the caller sees one stream. */
 int  mer_context_set_stream(mer_context *ctx, void *hip_stream);
 int  mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu_count, int64_t *hbm_bytes);
+/* Scheduling / A-B options of a context -- the analogue of the reference's Scheduler / RenderJob settings (block size, worker count:
+   src/mitsuba/mitsuba.cpp:80-81,281).  None changes a per-path result (tested); they are NOT read from the process environment by the
+   render calls (one hook: MER_OPTIONS="name=value,..." gives initial values when a context is created).  Names:
+     pipes          concurrent pipelines a render is cut into (1..4, default 4)
+     nslots         path-state slots over all pipelines (0 = 4 x the resident lanes of the chip)
+     ksteps         eikonal steps / tentative collisions per lane per K_march launch (default 128)
+     mq_sort        march lists sorted by steps-to-boundary class: -1 by field size (default), 0 off, 1 on
+     cell_sort      march lists additionally ordered by coarse spatial cell: -1 by field size (default), 0 off, 1 on
+     connect_every  passes over which curved-ray connection requests gather before K_connect runs (default 4)
+     adaptive_k     longer passes in the tail of a render (default 1)
+     pass_events    per-pass HIP events feeding mer_last_render_stats (default 1)
+     buffer_loads   0 = read fields with global loads even below 4 GiB, i.e. run the kernels a >= 4 GiB field selects (default 1)
+     gen_all        K_gen hands every camera sample to K_event (A/B, default 0)
+     prefilter      K_prefilter form: 0 register windows (default), 1 one thread per line, 2 two kernels per axis, 3 strided x, 4 LDS x
+     verbose, debug_pixel */
+int  mer_context_set_option(mer_context *ctx, const char *name, int64_t value);
+int  mer_context_get_option(mer_context *ctx, const char *name, int64_t *value);
+/* libmer_check.so (the same sources built with -DMER_BOUNDS_CHECK): every index a kernel forms into a device buffer is compared with
+   the buffer's extent; out = {violations since the last call, kind, index, limit of the first}; *enabled = 0 in the product build
+   (which compiles the checks away and always reports zeros).  No reference analogue (the reference relies on host sanitizers). */
+int  mer_debug_bounds(mer_context *ctx, int32_t *enabled, uint64_t out[4]);
 
 /* ---- volumes: replaces GridDataSource / SplineDataSource construction
         (src/volume/gridvolume.cpp:108-198, src/volume/splinevolume.cpp:204-317) ------------------------- */
@@ -205,7 +226,7 @@ int  mer_sample_distance(mer_context *ctx, const mer_scene_desc *scene, const fl
 int  mer_eval_transmittance(mer_context *ctx, const mer_scene_desc *scene, const float *o, const float *d,
                             const float *maxt, int64_t n, uint64_t seed, float *out_tr);
 /* HeterogeneousRefractiveMedium::eval -> makeDirectConnections (heterogeneousrefractive.cpp:571-640,798-1163): connect p1 to p2
-   (both inside the medium shape) by a curved ray; out stride 12: ok, weight, dirToP2[3] (optical momentum at p1),
+   (both inside the medium shape: cube, sphere or signed-distance grid) by a curved ray; out stride 12: ok, weight, dirToP2[3] (optical momentum at p1),
    revDirToP1[3], distance, opticalLength, 0, 0; RNG stream of item i = (seed, pixel=i, sample=0) */
 int  mer_connect(mer_context *ctx, const mer_scene_desc *scene, const float *p1, const float *p2, int64_t n, uint64_t seed, float *out);
 /* PhaseFunction::sample / eval (src/phase/hg.cpp:74-110, src/phase/isotropic.cpp:62-78) */

@@ -7,7 +7,8 @@ from . import params as P
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MER_LIB", os.path.join(_HERE, "libmer.so"))
-_LIB = None
+CHECK_LIB_PATH = os.path.join(_HERE, "libmer_check.so")     # same sources, -DMER_BOUNDS_CHECK (Context(check=True))
+_LIBS = {}
 
 C_PATHS, C_STEPS, C_RIF_EVALS, C_TENTATIVE, C_REAL, C_SEGMENTS, C_NEE, C_LOOP_ITERS, C_ACTIVE_LANES = range(9)
 C_COUNT = 16
@@ -16,7 +17,7 @@ LAYOUT_DENSE, LAYOUT_CELL8, LAYOUT_BRICK27, LAYOUT_BRICK125, LAYOUT_AUTO = 0, 1,
 # every symbol include/mer.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = [
     "mer_abi_version", "mer_context_create", "mer_context_destroy", "mer_last_error", "mer_context_set_stream",
-    "mer_device_info", "mer_volume_upload", "mer_volume_upload_dev", "mer_volume_build_spline",
+    "mer_device_info", "mer_context_set_option", "mer_context_get_option", "mer_debug_bounds", "mer_volume_upload", "mer_volume_upload_dev", "mer_volume_build_spline",
     "mer_volume_download_spline", "mer_volume_destroy", "mer_film_channels", "mer_film_alloc_n", "mer_film_zero_n",
     "mer_film_download_n", "mer_film_alloc", "mer_film_zero", "mer_film_download",
     "mer_film_free", "mer_render", "mer_synchronize", "mer_last_kernel_ms", "mer_last_render_stats", "mer_counters_read",
@@ -71,20 +72,22 @@ class MerError(RuntimeError):
     """Mirrors the reference's Log(EError) -> std::runtime_error (src/libcore/logger.cpp:100-147)."""
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        if not os.path.exists(LIB_PATH):
-            raise MerError("libmer.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "-- there is no CPU fallback for the hot path" % LIB_PATH)
-        _LIB = C.CDLL(LIB_PATH)
-        _LIB.mer_last_error.restype = C.c_char_p
-        _LIB.mer_last_error.argtypes = [C.c_void_p]
+def lib(path=None):
+    """The C-ABI library (ctypes).  path = None: libmer.so; Context(check=True) loads libmer_check.so beside it."""
+    path = path or LIB_PATH
+    if path not in _LIBS:
+        if not os.path.exists(path):
+            raise MerError("%s is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "-- there is no CPU fallback for the hot path" % (os.path.basename(path), path))
+        L = C.CDLL(path)
+        L.mer_last_error.restype = C.c_char_p
+        L.mer_last_error.argtypes = [C.c_void_p]
         for s in SYMBOLS:
             if s not in ("mer_last_error", "mer_context_destroy"):
-                getattr(_LIB, s).restype = C.c_int
-        _LIB.mer_context_destroy.restype = None
-    return _LIB
+                getattr(L, s).restype = C.c_int
+        L.mer_context_destroy.restype = None
+        _LIBS[path] = L
+    return _LIBS[path]
 
 
 def _fp(a):
@@ -101,47 +104,81 @@ class Volume:
         self.has_spline = False
 
     def build_spline(self):
-        self.ctx._check(lib().mer_volume_build_spline(self.ctx.h, C.c_int32(self.handle)))
+        self.ctx._check(self.ctx.lib.mer_volume_build_spline(self.ctx.h, C.c_int32(self.handle)))
         self.has_spline = True
         return self
 
     def download_spline(self):
         out = np.empty((self.desc.res[2], self.desc.res[1], self.desc.res[0]), np.float32)
-        self.ctx._check(lib().mer_volume_download_spline(self.ctx.h, C.c_int32(self.handle), _fp(out)))
+        self.ctx._check(self.ctx.lib.mer_volume_download_spline(self.ctx.h, C.c_int32(self.handle), _fp(out)))
         return out
 
     def destroy(self):
         if self.handle:
-            lib().mer_volume_destroy(self.ctx.h, C.c_int32(self.handle))
+            self.ctx.lib.mer_volume_destroy(self.ctx.h, C.c_int32(self.handle))
             self.handle = 0
 
 
 class Context:
     """One context per (process, GPU)."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, check=False, **options):
+        """check=True: the bounds-checking build of the library (libmer_check.so); options: mer_context_set_option names."""
+        self.lib = lib(CHECK_LIB_PATH if check else None)
         self.h = C.c_void_p()
-        rc = lib().mer_context_create(C.c_int32(device_id), C.byref(self.h))
+        rc = self.lib.mer_context_create(C.c_int32(device_id), C.byref(self.h))
         if rc != 0:
-            raise MerError(lib().mer_last_error(None).decode())
+            raise MerError(self.lib.mer_last_error(None).decode())
         self.device_id = device_id
+        for k, v in options.items():
+            self.set_option(k, v)
 
     def _check(self, rc):
         if rc != 0:
-            raise MerError(lib().mer_last_error(self.h).decode())
+            raise MerError(self.lib.mer_last_error(self.h).decode())
 
     def close(self):
         if self.h:
-            lib().mer_context_destroy(self.h)
+            self.lib.mer_context_destroy(self.h)
             self.h = C.c_void_p()
 
+    def set_option(self, name, value):
+        self._check(self.lib.mer_context_set_option(self.h, name.encode(), C.c_int64(int(value))))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        self._check(self.lib.mer_context_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """context manager: set options for the duration of a `with` block, then restore them"""
+        ctx = self
+
+        class _Scope:
+            def __enter__(self_):
+                self_.old = {k: ctx.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    ctx.set_option(k, v)
+                return ctx
+
+            def __exit__(self_, *a):
+                for k, v in self_.old.items():
+                    ctx.set_option(k, v)
+        return _Scope()
+
+    def debug_bounds(self):
+        """-> (enabled, violations, kind, index, limit) of the bounds-checking build; resets the record"""
+        en = C.c_int32(); out = (C.c_uint64 * 4)()
+        self._check(self.lib.mer_debug_bounds(self.h, C.byref(en), out))
+        return bool(en.value), int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
     def set_stream(self, stream_ptr):
-        self._check(lib().mer_context_set_stream(self.h, C.c_void_p(stream_ptr)))
+        self._check(self.lib.mer_context_set_stream(self.h, C.c_void_p(stream_ptr)))
 
     def device_info(self):
         name = C.create_string_buffer(256)
         cu = C.c_int32(); hbm = C.c_int64()
-        self._check(lib().mer_device_info(self.h, name, C.c_int32(256), C.byref(cu), C.byref(hbm)))
+        self._check(self.lib.mer_device_info(self.h, name, C.c_int32(256), C.byref(cu), C.byref(hbm)))
         return name.value.decode(), cu.value, hbm.value
 
     # ---- volumes -------------------------------------------------------------------------------
@@ -163,23 +200,23 @@ class Context:
         ch = 1 if a.ndim == 3 else a.shape[3]
         d = self._desc(a.shape, ch, P.VOL_U8 if a.dtype == np.uint8 else P.VOL_F32, aabb_min, aabb_max)
         h = C.c_int32()
-        self._check(lib().mer_volume_upload(self.h, C.byref(d), _fp(a), C.c_int32(layout), C.byref(h)))
+        self._check(self.lib.mer_volume_upload(self.h, C.byref(d), _fp(a), C.c_int32(layout), C.byref(h)))
         return Volume(self, h.value, d, layout)
 
     def upload_volume_dev(self, dev_ptr, shape, aabb_min, aabb_max, layout=LAYOUT_DENSE):
         d = self._desc(shape, 1, P.VOL_F32, aabb_min, aabb_max)
         h = C.c_int32()
-        self._check(lib().mer_volume_upload_dev(self.h, C.byref(d), C.c_void_p(dev_ptr), C.c_int32(layout), C.byref(h)))
+        self._check(self.lib.mer_volume_upload_dev(self.h, C.byref(d), C.c_void_p(dev_ptr), C.c_int32(layout), C.byref(h)))
         return Volume(self, h.value, d, layout)
 
     def synth_volume(self, kind, N, layout=LAYOUT_DENSE, aabb_min=(-1, -1, -1), aabb_max=(1, 1, 1)):
         """Synthetic field generated in HBM (0 = sigma_t density, 1 = linear RIF, 2 = radial RIF)."""
         ptr = C.c_void_p()
-        self._check(lib().mer_synth_field_dev(self.h, C.c_int32(kind), C.c_int32(N), C.byref(ptr)))
+        self._check(self.lib.mer_synth_field_dev(self.h, C.c_int32(kind), C.c_int32(N), C.byref(ptr)))
         try:
             v = self.upload_volume_dev(ptr.value, (N, N, N), aabb_min, aabb_max, layout)
         finally:
-            lib().mer_device_free(self.h, ptr)
+            self.lib.mer_device_free(self.h, ptr)
         return v
 
     # ---- scene ---------------------------------------------------------------------------------
@@ -247,30 +284,30 @@ class Context:
     def film_channels(self, scene):
         """frames*3 + 2: RGB per frame, alpha, weight (5 in steady state)"""
         ch = C.c_int32()
-        self._check(lib().mer_film_channels(self.h, C.byref(scene), C.byref(ch)))
+        self._check(self.lib.mer_film_channels(self.h, C.byref(scene), C.byref(ch)))
         return ch.value
 
     def film_alloc(self, w, h, channels=5):
         ptr = C.c_void_p()
-        self._check(lib().mer_film_alloc_n(self.h, C.c_int32(w), C.c_int32(h), C.c_int32(channels), C.byref(ptr)))
+        self._check(self.lib.mer_film_alloc_n(self.h, C.c_int32(w), C.c_int32(h), C.c_int32(channels), C.byref(ptr)))
         return ptr
 
     def film_zero(self, ptr, w, h, channels=5):
-        self._check(lib().mer_film_zero_n(self.h, ptr, C.c_int32(w), C.c_int32(h), C.c_int32(channels)))
+        self._check(self.lib.mer_film_zero_n(self.h, ptr, C.c_int32(w), C.c_int32(h), C.c_int32(channels)))
 
     def film_download(self, ptr, w, h, channels=5):
         out = np.empty((h, w, channels), np.float32)
-        self._check(lib().mer_film_download_n(self.h, ptr, C.c_int32(w), C.c_int32(h), C.c_int32(channels), _fp(out)))
+        self._check(self.lib.mer_film_download_n(self.h, ptr, C.c_int32(w), C.c_int32(h), C.c_int32(channels), _fp(out)))
         return out
 
     def film_free(self, ptr):
-        self._check(lib().mer_film_free(self.h, ptr))
+        self._check(self.lib.mer_film_free(self.h, ptr))
 
     def render(self, scene, film_ptr, spp_begin, spp_count, seed=0, spp_stride=1, tile_rank=0, tile_count=1):
         """Asynchronous on the context stream.  film_ptr: c_void_p / int device pointer."""
         sh = Shard(spp_begin, spp_count, spp_stride, tile_rank, tile_count)
         fp = film_ptr if isinstance(film_ptr, C.c_void_p) else C.c_void_p(int(film_ptr))
-        self._check(lib().mer_render(self.h, C.byref(scene), C.byref(sh), C.c_uint64(seed), fp))
+        self._check(self.lib.mer_render(self.h, C.byref(scene), C.byref(sh), C.c_uint64(seed), fp))
 
     def render_to_host(self, scene, spp_begin, spp_count, seed=0, **kw):
         ch = self.film_channels(scene)
@@ -282,101 +319,101 @@ class Context:
             self.film_free(f)
 
     def synchronize(self):
-        self._check(lib().mer_synchronize(self.h))
+        self._check(self.lib.mer_synchronize(self.h))
 
     def last_kernel_ms(self):
         ms = C.c_float()
-        self._check(lib().mer_last_kernel_ms(self.h, C.byref(ms)))
+        self._check(self.lib.mer_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
     def last_render_stats(self):
         n = C.c_int32(); a = C.c_float(); b = C.c_float()
-        self._check(lib().mer_last_render_stats(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        self._check(self.lib.mer_last_render_stats(self.h, C.byref(n), C.byref(a), C.byref(b)))
         return n.value, a.value, b.value
 
     def counters(self):
         out = np.zeros(C_COUNT, np.uint64)
-        self._check(lib().mer_counters_read(self.h, _fp(out)))
+        self._check(self.lib.mer_counters_read(self.h, _fp(out)))
         return out
 
     def counters_reset(self):
-        self._check(lib().mer_counters_reset(self.h))
+        self._check(self.lib.mer_counters_reset(self.h))
 
     # ---- leaf entry points ---------------------------------------------------------------------
     def lookup_trilinear(self, vol, pts):
         pts = _f32(pts); n = pts.shape[0]
         val = np.empty(n, np.float32); idx = np.empty((n, 4), np.int32)
-        self._check(lib().mer_lookup_trilinear(self.h, C.c_int32(vol.handle), _fp(pts), C.c_int64(n), _fp(val), _fp(idx)))
+        self._check(self.lib.mer_lookup_trilinear(self.h, C.c_int32(vol.handle), _fp(pts), C.c_int64(n), _fp(val), _fp(idx)))
         return val, idx
 
     def lookup_trilinear_rgb(self, vol, pts):
         pts = _f32(pts); n = pts.shape[0]
         out = np.empty((n, 3), np.float32)
-        self._check(lib().mer_lookup_trilinear_rgb(self.h, C.c_int32(vol.handle), _fp(pts), C.c_int64(n), _fp(out)))
+        self._check(self.lib.mer_lookup_trilinear_rgb(self.h, C.c_int32(vol.handle), _fp(pts), C.c_int64(n), _fp(out)))
         return out
 
     def rif_value_grad(self, vol, interp, pts):
         pts = _f32(pts); n = pts.shape[0]
         val = np.empty(n, np.float32); grad = np.empty((n, 3), np.float32)
-        self._check(lib().mer_rif_value_grad(self.h, C.c_int32(vol.handle), C.c_int32(interp), _fp(pts), C.c_int64(n), _fp(val), _fp(grad)))
+        self._check(self.lib.mer_rif_value_grad(self.h, C.c_int32(vol.handle), C.c_int32(interp), _fp(pts), C.c_int64(n), _fp(val), _fp(grad)))
         return val, grad
 
     def er_trace(self, scene, p0, d0, dist):
         p0 = _f32(p0); d0 = _f32(d0); dist = _f32(dist); n = p0.shape[0]
         op = np.empty((n, 3), np.float32); ov = np.empty((n, 3), np.float32)
         ds = np.empty(n, np.float32); oo = np.empty(n, np.float32); ok = np.empty(n, np.int32)
-        self._check(lib().mer_er_trace(self.h, C.byref(scene), _fp(p0), _fp(d0), _fp(dist), C.c_int64(n),
+        self._check(self.lib.mer_er_trace(self.h, C.byref(scene), _fp(p0), _fp(d0), _fp(dist), C.c_int64(n),
                                        _fp(op), _fp(ov), _fp(ds), _fp(oo), _fp(ok)))
         return op, ov, ds, oo, ok
 
     def sample_distance(self, scene, o, d, maxt, seed):
         o = _f32(o); d = _f32(d); maxt = _f32(maxt); n = o.shape[0]
         rec = np.empty((n, 20), np.float32)
-        self._check(lib().mer_sample_distance(self.h, C.byref(scene), _fp(o), _fp(d), _fp(maxt), C.c_int64(n), C.c_uint64(seed), _fp(rec)))
+        self._check(self.lib.mer_sample_distance(self.h, C.byref(scene), _fp(o), _fp(d), _fp(maxt), C.c_int64(n), C.c_uint64(seed), _fp(rec)))
         return rec
 
     def connect(self, scene, p1, p2, seed):
         p1 = _f32(p1); p2 = _f32(p2); n = p1.shape[0]
         out = np.zeros((n, 12), np.float32)
-        self._check(lib().mer_connect(self.h, C.byref(scene), _fp(p1), _fp(p2), C.c_int64(n), C.c_uint64(seed), _fp(out)))
+        self._check(self.lib.mer_connect(self.h, C.byref(scene), _fp(p1), _fp(p2), C.c_int64(n), C.c_uint64(seed), _fp(out)))
         return out
 
     def eval_transmittance(self, scene, o, d, maxt, seed):
         o = _f32(o); d = _f32(d); maxt = _f32(maxt); n = o.shape[0]
         out = np.empty((n, 3), np.float32)
-        self._check(lib().mer_eval_transmittance(self.h, C.byref(scene), _fp(o), _fp(d), _fp(maxt), C.c_int64(n), C.c_uint64(seed), _fp(out)))
+        self._check(self.lib.mer_eval_transmittance(self.h, C.byref(scene), _fp(o), _fp(d), _fp(maxt), C.c_int64(n), C.c_uint64(seed), _fp(out)))
         return out
 
     def phase_sample(self, kind, g, wi, u2):
         wi = _f32(wi); u2 = _f32(u2); n = wi.shape[0]
         wo = np.empty((n, 3), np.float32); pdf = np.empty(n, np.float32)
-        self._check(lib().mer_phase_sample(self.h, C.c_int32(kind), C.c_float(g), _fp(wi), _fp(u2), C.c_int64(n), _fp(wo), _fp(pdf)))
+        self._check(self.lib.mer_phase_sample(self.h, C.c_int32(kind), C.c_float(g), _fp(wi), _fp(u2), C.c_int64(n), _fp(wo), _fp(pdf)))
         return wo, pdf
 
     def phase_eval(self, kind, g, wi, wo):
         wi = _f32(wi); wo = _f32(wo); n = wi.shape[0]
         val = np.empty(n, np.float32)
-        self._check(lib().mer_phase_eval(self.h, C.c_int32(kind), C.c_float(g), _fp(wi), _fp(wo), C.c_int64(n), _fp(val)))
+        self._check(self.lib.mer_phase_eval(self.h, C.c_int32(kind), C.c_float(g), _fp(wi), _fp(wo), C.c_int64(n), _fp(val)))
         return val
 
     def camera_rays(self, scene, pos2):
         pos2 = _f32(pos2); n = pos2.shape[0]
         o = np.empty((n, 3), np.float32); d = np.empty((n, 3), np.float32)
-        self._check(lib().mer_camera_rays(self.h, C.byref(scene), _fp(pos2), C.c_int64(n), _fp(o), _fp(d)))
+        self._check(self.lib.mer_camera_rays(self.h, C.byref(scene), _fp(pos2), C.c_int64(n), _fp(o), _fp(d)))
         return o, d
 
     def correlation(self, scene, path_length):
         t = _f32(path_length); n = t.shape[0]
         out = np.empty(n, np.float32)
-        self._check(lib().mer_correlation(self.h, C.byref(scene), _fp(t), C.c_int64(n), _fp(out)))
+        self._check(self.lib.mer_correlation(self.h, C.byref(scene), _fp(t), C.c_int64(n), _fp(out)))
         return out
 
     def render_paths(self, scene, sample_index, seed=0):
         out = np.zeros((scene.height, scene.width, 3), np.float32)
-        self._check(lib().mer_render_paths(self.h, C.byref(scene), C.c_int32(sample_index), C.c_uint64(seed), _fp(out)))
+        self._check(self.lib.mer_render_paths(self.h, C.byref(scene), C.c_int32(sample_index), C.c_uint64(seed), _fp(out)))
         return out
 
     def rng_floats(self, seed, pixel, sample, n):
         out = np.empty(n, np.float32)
-        self._check(lib().mer_rng_floats(self.h, C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_int32(n), _fp(out)))
+        self._check(self.lib.mer_rng_floats(self.h, C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_int32(n), _fp(out)))
         return out

@@ -1,72 +1,18 @@
 // mer_api.hip -- libmer.so: C-ABI (include/mer.h) over the gfx950 kernels in mer_kernels.hpp.
 // Host side is plain HIP runtime: device memory, one stream, HIP events.  No CPU compute path exists:
 // every entry point that computes launches a kernel, and fails loudly when no device is present.
+#include "mer_internal.hpp"
 #include "mer_kernels.hpp"
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <cmath>
-#include <string>
-#include <vector>
-#include <map>
-#include <limits>
 
 using namespace mer;
 
-namespace {
-thread_local std::string g_create_error;
+namespace { thread_local std::string g_create_error; }
 
-struct Volume {
-    mer_grid_desc desc;
-    void  *dense = nullptr;     // device, dense layout
-    float *cell8 = nullptr;     // device, CELL8 layout (optional)
-    float *coeff = nullptr;     // device, B-spline coefficients (optional)
-    int layout = MER_LAYOUT_DENSE;
-    bool owns_dense = true;
-    size_t bytes_dense = 0;
-};
-}  // namespace
-
-#define MER_MAX_PIPES 4
-struct Pipe {
-    hipStream_t stream = nullptr, own_stream = nullptr;      // pipeline 0 runs on the context stream
-    uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
-    SegQueue eq{}, mq[2]{}, sq[2]{}, cq{};
-    unsigned long long *hitq = nullptr, *hitq_ctr = nullptr; unsigned long long hitq_cap = 0;
-    hipEvent_t readback[2] = {nullptr, nullptr}, finished = nullptr;     // two batches in flight per pipeline
-    std::vector<hipEvent_t> pass_events;          // 3 per pass: before K_event, between, after K_march
-};
-
-struct mer_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string error;
-    std::map<int, Volume> volumes;
-    int next_handle = 1;
-    unsigned long long *counters = nullptr;      // MER_C_COUNT + 1 (work counter)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    hipDeviceProp_t prop;
-    // wavefront pipelines: path-state slots, work lists, hit ring, work counter and stream of each (launch_render)
-    Pipe pipes[MER_MAX_PIPES];
-    int last_passes = 0, last_pipes = 1;
-    float last_march_ms = 0, last_event_ms = 0;
-};
-
-#define HIP_CHECK(ctx, call)                                                                              \
-    do {                                                                                                  \
-        hipError_t e_ = (call);                                                                           \
-        if (e_ != hipSuccess) {                                                                           \
-            (ctx)->error = std::string(#call) + " failed: " + hipGetErrorString(e_);                      \
-            return 1;                                                                                     \
-        }                                                                                                 \
-    } while (0)
-
-static int fail(mer_context *ctx, const std::string &msg) { ctx->error = msg; return 1; }
+namespace mer {
 
 // worldToGrid = scale((res-1)/extents) * translate(-min) * toWorld^-1 with toWorld = identity
 // (GridDataSource::configure, src/volume/gridvolume.cpp:188-195).  Float arithmetic as in the reference.
-static void fill_dgrid(const Volume &v, DGrid &g) {
+void fill_dgrid(const mer_context *ctx, const Volume &v, DGrid &g) {
     std::memset(&g, 0, sizeof(g));
     g.data = v.dense; g.cell8 = v.cell8; g.coeff = v.coeff;
     g.layout = v.cell8 ? v.layout : MER_LAYOUT_DENSE;
@@ -79,7 +25,10 @@ static void fill_dgrid(const Volume &v, DGrid &g) {
         const uint64_t bytes = !v.cell8 ? (uint64_t) v.bytes_dense
                              : brick ? (uint64_t) g.nbx * g.nby * ((v.desc.res[2] - 2) / bc + 1) * (uint64_t) g.recw * 4ull
                              : (uint64_t) (v.desc.res[0] - 1) * (v.desc.res[1] - 1) * (v.desc.res[2] - 1) * 32ull;
-        g.buf_bytes = bytes < 0xFFFFFFFFull && !getenv("MER_NO_BUFFER_LOADS") ? (uint32_t) bytes : 0u;
+        g.buf_bytes = bytes < 0xFFFFFFFFull && ctx->opt.buffer_loads ? (uint32_t) bytes : 0u;
+        g.n_record = v.cell8 ? bytes / 4 : 0;
+        g.n_dense = (uint64_t) v.desc.res[0] * v.desc.res[1] * v.desc.res[2] * (uint64_t) v.desc.channels;
+        g.chk = ctx->chk;
     }
     for (int i = 0; i < 3; i++) {
         g.res[i] = v.desc.res[i];
@@ -135,7 +84,7 @@ static int film_frames(mer_context *ctx, const mer_scene_desc *sc, int &frames) 
     frames = (int) f;
     return 0;
 }
-static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bool allow_sdf = false) {
+int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bool allow_sdf) {
     std::memset(&P, 0, sizeof(P));
     P.sc = *sc;
     if (sc->width <= 0 || sc->height <= 0) return fail(ctx, "film: width/height must be positive");
@@ -149,7 +98,7 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bo
         if (it == ctx->volumes.end()) return fail(ctx, "No density specified!");                                    // heterogeneous.cpp:229-230
         if (it->second.desc.channels != 1) return fail(ctx, "density volume must support float lookups");           // :270
         if (it->second.layout == MER_LAYOUT_BRICK27 || it->second.layout == MER_LAYOUT_BRICK125) return fail(ctx, "the BRICK layouts are for the refractive-index field only");
-        fill_dgrid(it->second, P.density);
+        fill_dgrid(ctx, it->second, P.density);
         if (!(sc->density_scale > 0)) return fail(ctx, "heterogeneous medium: 'scale' must be positive");
         // m_maxDensity = m_scale * getMaximumFloatValue() (= 1.0 for gridvolume): heterogeneous.cpp:239-242
         P.inv_max_density = 1.0f / (sc->density_scale * 1.0f);
@@ -159,7 +108,7 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bo
         if (it == ctx->volumes.end()) return fail(ctx, "No albedo specified!");                                     // heterogeneous.cpp:231-232
         if (it->second.desc.channels != 3) return fail(ctx, "albedo volume must support spectrum lookups");
         Volume tmp = it->second; tmp.cell8 = nullptr;
-        fill_dgrid(tmp, P.albedo);
+        fill_dgrid(ctx, tmp, P.albedo);
     }
     if (sc->rif_mode == MER_RIF_ACOUSTIC) {
         // acousticrifvolume: analytic, no grid (src/volume/acousticrifvolume.cpp:101-106)
@@ -177,7 +126,10 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bo
         if (sc->rif_mode == MER_RIF_BSPLINE3 && !it->second.coeff)
             return fail(ctx, "RIF volume has no spline coefficients (call mer_volume_build_spline)");
         if (!(sc->stepsize > 0)) return fail(ctx, "heterogeneousrefractive: 'stepsize' must be positive");
-        fill_dgrid(it->second, P.rif);
+        fill_dgrid(ctx, it->second, P.rif);
+        // the fetch index (z * res_y + y) * res_x + x is formed with 24-bit multiplies (v_mul_u32_u24)
+        if ((int64_t) P.rif.res[1] * P.rif.res[2] > ((int64_t) 1 << 24) || P.rif.res[0] > (1 << 24))
+            return fail(ctx, "RIF volume: res_y * res_z must not exceed 2^24 (index arithmetic of the trilinear fetch)");
         if (sc->rif_mode == MER_RIF_BSPLINE3) {
             for (int i = 0; i < 3; i++) if (P.rif.res[i] < 5) return fail(ctx, "splinevolume needs at least 5 nodes per axis");
             // the medium must lie inside the spline-safe box (gate: heterogeneousrefractive.cpp:461-466)
@@ -235,7 +187,7 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bo
         if (it == ctx->volumes.end()) return fail(ctx, "heterogeneousrefractive: no sdf volume (boundary = sdf)");
         if (it->second.desc.channels != 1 || it->second.desc.dtype != MER_VOL_F32) return fail(ctx, "heterogeneousrefractive: the sdf must be a 1-channel float32 grid");
         if (it->second.layout == MER_LAYOUT_BRICK27 || it->second.layout == MER_LAYOUT_BRICK125) return fail(ctx, "the BRICK layouts are for the refractive-index field only");
-        fill_dgrid(it->second, P.sdf);
+        fill_dgrid(ctx, it->second, P.sdf);
         float d2 = 0; for (int i = 0; i < 3; i++) d2 += (P.sdf.bmax[i] - P.sdf.bmin[i]) * (P.sdf.bmax[i] - P.sdf.bmin[i]);
         P.sdf_eps = 1e-4f * std::sqrt(d2);
     } else return fail(ctx, "unknown medium boundary");
@@ -258,7 +210,18 @@ static int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bo
     }
     P.counters = ctx->counters;
     P.work_counter = ctx->counters + MER_C_COUNT * MER_COUNTER_REPLICAS;
+    P.chk = ctx->chk;
+    P.dbg_pixel = (int32_t) ctx->opt.debug_pixel;
     return 0;
+}
+
+int rif_fetch_kind(mer_context *ctx, const mer_scene_desc *sc) {
+    if (sc->rif_mode != MER_RIF_TRILINEAR) return sc->rif_mode;
+    const Volume &rv = ctx->volumes.find(sc->rif)->second;
+    DGrid tmp; fill_dgrid(ctx, rv, tmp);
+    if (tmp.layout == MER_LAYOUT_BRICK27 || tmp.layout == MER_LAYOUT_BRICK125) return tmp.buf_bytes ? RIFK_BRICK27_BUF : RIFK_BRICK27;
+    if (tmp.layout == MER_LAYOUT_CELL8) return tmp.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
+    return tmp.buf_bytes ? RIFK_DENSE_BUF : MER_RIF_TRILINEAR;
 }
 
 template <typename F> static int dispatch_modes(mer_context *ctx, const mer_scene_desc *sc, F &&f) {
@@ -271,14 +234,7 @@ template <typename F> static int dispatch_modes(mer_context *ctx, const mer_scen
                  std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_HOMOGENEOUS>(), std::integral_constant<int, 0>());
     }
     // internal fetch kind of the trilinear RIF (mer_device.hpp): layout x {global, buffer} loads
-    int rifk = sc->rif_mode;
-    if (sc->rif_mode == MER_RIF_TRILINEAR) {
-        const Volume &rv = ctx->volumes.find(sc->rif)->second;
-        DGrid tmp; fill_dgrid(rv, tmp);
-        if (tmp.layout == MER_LAYOUT_BRICK27 || tmp.layout == MER_LAYOUT_BRICK125) rifk = tmp.buf_bytes ? RIFK_BRICK27_BUF : RIFK_BRICK27;
-        else if (tmp.layout == MER_LAYOUT_CELL8) rifk = tmp.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
-        else rifk = tmp.buf_bytes ? RIFK_DENSE_BUF : MER_RIF_TRILINEAR;
-    }
+    const int rifk = rif_fetch_kind(ctx, sc);
 #define MER_CASE(R, S, G)                                                                                         \
     if (rifk == R && sc->stepper == S && (int) grid == G)                                                         \
         return f(std::integral_constant<bool, true>(), std::integral_constant<int, R>(), std::integral_constant<int, S>(), \
@@ -302,38 +258,7 @@ template <typename F> static int dispatch_modes(mer_context *ctx, const mer_scen
 #undef MER_CASE
     return fail(ctx, "unsupported rif_mode / stepper combination");
 }
-// boundary = MER_BOUNDARY_SDF: a reduced set of kernels (straight rays; dense-global / cell8-buffer trilinear and B-spline RIFs)
-template <typename F> static int dispatch_modes_sdf(mer_context *ctx, const mer_scene_desc *sc, F &&f) {
-    const bool curved = sc->rif_mode != MER_RIF_CONST;
-    const bool grid = sc->sigma_mode == MER_SIGMA_GRID;
-    typedef std::integral_constant<int, 1> B1;
-    if (!curved) {
-        if (grid) return f(std::integral_constant<bool, false>(), std::integral_constant<int, MER_RIF_TRILINEAR>(),
-                           std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_GRID>(), B1());
-        return f(std::integral_constant<bool, false>(), std::integral_constant<int, MER_RIF_TRILINEAR>(),
-                 std::integral_constant<int, MER_STEP_VERLET>(), std::integral_constant<int, MER_SIGMA_HOMOGENEOUS>(), B1());
-    }
-    int rifk = sc->rif_mode;
-    if (sc->rif_mode == MER_RIF_TRILINEAR) {
-        const Volume &rv = ctx->volumes.find(sc->rif)->second;
-        DGrid tmp; fill_dgrid(rv, tmp);
-        if (tmp.layout == MER_LAYOUT_BRICK27 || tmp.layout == MER_LAYOUT_BRICK125) return fail(ctx, "signed-distance boundary: upload the RIF dense or cell8 (the brick layouts are not instantiated for it)");
-        if (tmp.layout == MER_LAYOUT_CELL8) rifk = tmp.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
-        else rifk = MER_RIF_TRILINEAR;                        // dense: global loads
-    }
-#define MER_CASE(R, S, G)                                                                                         \
-    if (rifk == R && sc->stepper == S && (int) grid == G)                                                         \
-        return f(std::integral_constant<bool, true>(), std::integral_constant<int, R>(), std::integral_constant<int, S>(), \
-                 std::integral_constant<int, G>(), B1());
-    MER_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET, 1) MER_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4, 1)
-    MER_CASE(RIFK_CELL8_BUF, MER_STEP_VERLET, 1) MER_CASE(RIFK_CELL8_BUF, MER_STEP_RK4, 1)
-    MER_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET, 1) MER_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4, 1)
-    MER_CASE(MER_RIF_TRILINEAR, MER_STEP_VERLET, 0) MER_CASE(MER_RIF_TRILINEAR, MER_STEP_RK4, 0)
-    MER_CASE(RIFK_CELL8_BUF, MER_STEP_VERLET, 0) MER_CASE(RIFK_CELL8_BUF, MER_STEP_RK4, 0)
-    MER_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET, 0) MER_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4, 0)
-#undef MER_CASE
-    return fail(ctx, "signed-distance boundary: the RIF must be dense, cell8 below 4 GiB, or a B-spline volume");
-}
+}  // namespace mer
 
 // staging helpers for the leaf entry points -------------------------------------------------------------
 struct DevBuf {
@@ -353,7 +278,6 @@ struct DevBuf {
     }
     template <typename T> T *as() { return (T *) p; }
 };
-static inline unsigned nblocks(int64_t n, int bs = 256) { return (unsigned) std::max<int64_t>(1, (n + bs - 1) / bs); }
 
 extern "C" {
 
@@ -379,7 +303,64 @@ int mer_context_create(int32_t device_id, mer_context **out) {
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         g_create_error = "mer_context_create: device allocation failed"; delete ctx; return 1;
     }
+#ifdef MER_BOUNDS_CHECK
+    if (hipMalloc((void **) &ctx->chk, 4 * sizeof(unsigned long long)) != hipSuccess || hipMemset(ctx->chk, 0, 4 * sizeof(unsigned long long)) != hipSuccess) {
+        g_create_error = "mer_context_create: device allocation failed"; delete ctx; return 1;
+    }
+#endif
+    // MER_OPTIONS="name=value,name=value": initial option values for A/B scripts (read once, here; mer_context_set_option afterwards)
+    if (const char *e = getenv("MER_OPTIONS")) {
+        std::string all(e); size_t pos = 0;
+        while (pos < all.size()) {
+            size_t end = all.find(',', pos); if (end == std::string::npos) end = all.size();
+            const std::string kv = all.substr(pos, end - pos); const size_t eq = kv.find('=');
+            if (eq != std::string::npos && mer_context_set_option(ctx, kv.substr(0, eq).c_str(), atoll(kv.c_str() + eq + 1)) != 0) {
+                g_create_error = "mer_context_create: MER_OPTIONS: " + ctx->error; mer_context_destroy(ctx); return 1;
+            }
+            pos = end + 1;
+        }
+    }
     *out = ctx;
+    return 0;
+}
+
+static int64_t *option_slot(mer_context *ctx, const char *name) {
+    Options &o = ctx->opt;
+    const struct { const char *n; int64_t *p; } table[] = {
+        {"pipes", &o.pipes}, {"nslots", &o.nslots}, {"ksteps", &o.ksteps}, {"mq_sort", &o.mq_sort}, {"connect_every", &o.connect_every},
+        {"adaptive_k", &o.adaptive_k}, {"pass_events", &o.pass_events}, {"buffer_loads", &o.buffer_loads}, {"gen_all", &o.gen_all},
+        {"prefilter", &o.prefilter}, {"verbose", &o.verbose}, {"debug_pixel", &o.debug_pixel}, {"cell_sort", &o.cell_sort}};
+    for (const auto &t : table) if (std::strcmp(t.n, name) == 0) return t.p;
+    return nullptr;
+}
+int mer_context_set_option(mer_context *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return 1;
+    int64_t *p = option_slot(ctx, name);
+    if (!p) return fail(ctx, std::string("unknown option '") + name + "'");
+    const std::string n(name);
+    if ((n == "pipes" && (value < 1 || value > MER_MAX_PIPES)) || (n == "ksteps" && (value < 1 || value > (1 << 20))) ||
+        (n == "connect_every" && (value < 1 || value > 1024)) || (n == "nslots" && (value < 0 || value > ((int64_t) 1 << 28))) ||
+        (n == "prefilter" && (value < 0 || value > 4)))
+        return fail(ctx, std::string("option '") + name + "': value out of range");
+    *p = value;
+    return 0;
+}
+int mer_context_get_option(mer_context *ctx, const char *name, int64_t *value) {
+    if (!ctx || !name || !value) return 1;
+    int64_t *p = option_slot(ctx, name);
+    if (!p) return fail(ctx, std::string("unknown option '") + name + "'");
+    *value = *p;
+    return 0;
+}
+int mer_debug_bounds(mer_context *ctx, int32_t *enabled, uint64_t out[4]) {
+    if (!ctx || !enabled || !out) return 1;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    *enabled = ctx->chk != nullptr;
+    if (ctx->chk) {
+        HIP_CHECK(ctx, hipDeviceSynchronize());
+        HIP_CHECK(ctx, hipMemcpy(out, ctx->chk, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_CHECK(ctx, hipMemset(ctx->chk, 0, 4 * sizeof(uint64_t)));
+    }
     return 0;
 }
 
@@ -392,6 +373,7 @@ void mer_context_destroy(mer_context *ctx) {
         if (kv.second.coeff) (void) hipFree(kv.second.coeff);
     }
     if (ctx->counters) (void) hipFree(ctx->counters);
+    if (ctx->chk) (void) hipFree(ctx->chk);
     for (Pipe &pp : ctx->pipes) {
         if (pp.slots) (void) hipFree(pp.slots);
         if (pp.live) (void) hipFree(pp.live);
@@ -508,7 +490,8 @@ int mer_volume_build_spline(mer_context *ctx, mer_volume h) {
     HIP_CHECK(ctx, hipMalloc((void **) &a, n * 4));
     HIP_CHECK(ctx, hipMalloc((void **) &b, n * 4));
     // along y (lines indexed by x and z), then x (by y and z), then z (by x and y): basisspline.h:868-887
-    const bool seq = getenv("MER_PREFILTER_SEQ") != nullptr || std::min(nx, std::min(ny, nz)) < 16;
+    const int64_t form = ctx->opt.prefilter;
+    const bool seq = form == 1 || std::min(nx, std::min(ny, nz)) < 16;
     if (seq) {                 // one thread per line (reference order of operations; tiny grids)
         hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) nx * nz)), dim3(256), 0, ctx->stream,
                            (const float *) v.dense, a, nx, nz, (int64_t) 1, (int64_t) nx * ny, (int64_t) nx, ny);
@@ -517,7 +500,7 @@ int mer_volume_build_spline(mer_context *ctx, mer_volume h) {
         hipLaunchKernelGGL(bspline_pass_kernel, dim3(nblocks((int64_t) nx * ny)), dim3(256), 0, ctx->stream,
                            (const float *) b, a, nx, ny, (int64_t) 1, (int64_t) nx, (int64_t) nx * ny, nz);
     } else {
-        if (getenv("MER_PREFILTER_TWO_KERNEL") || getenv("MER_PREFILTER_NO_LDS")) HIP_CHECK(ctx, hipMalloc((void **) &t, n * 4));
+        if (form == 2 || form == 3) HIP_CHECK(ctx, hipMalloc((void **) &t, n * 4));
         auto pass = [&](const float *src, float *dst, int na, int nb, int64_t sa, int64_t sb, int64_t sl, int size) {
             const int64_t threads = (int64_t) na * nb * ((size + MER_PF_SEG - 1) / MER_PF_SEG);
             hipLaunchKernelGGL(bspline_causal_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, src, t, na, nb, sa, sb, sl, size);
@@ -527,13 +510,13 @@ int mer_volume_build_spline(mer_context *ctx, mer_volume h) {
             const int64_t threads = (int64_t) na * nb * ((size + MER_PF_SEG - 1) / MER_PF_SEG);
             hipLaunchKernelGGL(bspline_win_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, src, dst, na, nb, sb, sl, size);
         };
-        const bool two_kernel = getenv("MER_PREFILTER_TWO_KERNEL") != nullptr;
+        const bool two_kernel = form == 2;
         if (two_kernel) pass((const float *) v.dense, a, nx, nz, 1, (int64_t) nx * ny, nx, ny);          // y
         else win((const float *) v.dense, a, nx, nz, (int64_t) nx * ny, nx, ny);
-        if (getenv("MER_PREFILTER_NO_LDS")) pass(a, b, ny, nz, nx, (int64_t) nx * ny, 1, nx);           // x, strided form
+        if (form == 3) pass(a, b, ny, nz, nx, (int64_t) nx * ny, 1, nx);           // x, strided form
         else {                                                                                        // x: lines are contiguous -> LDS tiles
             const int64_t nlines = (int64_t) ny * nz;
-            if (nx % 4 == 0 && !getenv("MER_PREFILTER_LDS")) {
+            if (nx % 4 == 0 && form != 4) {
                 const int64_t threads = nlines * ((nx + MER_PF_SEG - 1) / MER_PF_SEG);
                 hipLaunchKernelGGL(bspline_x_reg_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, (const float *) a, b, nlines, nx);
             } else {
@@ -599,230 +582,11 @@ int mer_film_download(mer_context *ctx, const float *film_dev, int32_t width, in
 int mer_film_free(mer_context *ctx, float *film_dev) { HIP_CHECK(ctx, hipFree(film_dev)); return 0; }
 int mer_device_free(mer_context *ctx, void *p) { HIP_CHECK(ctx, hipFree(p)); return 0; }
 
-static int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed,
-                         float *film_dev, float *path_out_dev) {
-    Params P;
-    if (make_params(ctx, scene, P, true)) return 1;
-    if (!shard || shard->spp_count < 0 || shard->spp_stride <= 0 || shard->tile_count <= 0 || shard->tile_rank < 0 ||
-        shard->tile_rank >= shard->tile_count || shard->spp_begin < 0)
-        return fail(ctx, "invalid shard");
-    P.seed = seed;
-    P.spp_begin = shard->spp_begin; P.spp_count = shard->spp_count; P.spp_stride = shard->spp_stride;
-    P.tile_rank = shard->tile_rank; P.tile_count = shard->tile_count;
-    P.tiles_x = (scene->width + MER_TILE - 1) / MER_TILE; P.tiles_y = (scene->height + MER_TILE - 1) / MER_TILE;
-    const int ntiles = P.tiles_x * P.tiles_y;
-    P.ntiles_mine = (ntiles - shard->tile_rank + shard->tile_count - 1) / shard->tile_count;
-    P.total_work = (uint64_t) P.ntiles_mine * MER_TILE * MER_TILE * (uint64_t) shard->spp_count;
-    P.film = film_dev; P.path_out = path_out_dev;
-    { const char *e = getenv("MER_DEBUG_PIXEL"); P.dbg_pixel = e ? atoi(e) : -1; }
-    HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    HIP_CHECK(ctx, hipMemsetAsync(P.work_counter, 0, sizeof(unsigned long long), ctx->stream));
-    if (P.total_work == 0) return 0;
-    const char *mode = getenv("MER_MODE");
-    if (mode && std::strcmp(mode, "mega") == 0) {
-        if (scene->decomposition != MER_DECOMPOSITION_NONE) return fail(ctx, "MER_MODE=mega renders steady-state films only; use the default wavefront mode");
-        if (scene->boundary_bsdf != MER_BSDF_NULL) return fail(ctx, "MER_MODE=mega knows the index-matched boundary only; use the default wavefront mode");
-        if (scene->boundary == MER_BOUNDARY_SDF) return fail(ctx, "MER_MODE=mega knows the cube / sphere boundaries only; use the default wavefront mode");
-        if (scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0)
-            return fail(ctx, "MER_MODE=mega does not sample point emitters; use the default wavefront mode");
-        return dispatch_modes(ctx, scene, [&](auto curved, auto rif, auto stepper, auto sigma, auto bnd) -> int {
-            auto kern = render_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value>;
-            int per_cu = 0;
-            HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, MER_BLOCK, 0));
-            if (per_cu < 1) per_cu = 1;
-            int64_t blocks = (int64_t) per_cu * ctx->prop.multiProcessorCount;
-            const int64_t need = (int64_t) ((P.total_work + MER_BLOCK - 1) / MER_BLOCK);
-            if (blocks > need) blocks = need;
-            HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-            hipLaunchKernelGGL(kern, dim3((unsigned) blocks), dim3(MER_BLOCK), 0, ctx->stream, P);
-            HIP_CHECK(ctx, hipGetLastError());
-            HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-            ctx->timed = true;
-            return 0;
-        });
-    }
-    // ---- wavefront: K_event / K_march passes over the path-state slots until no lane is alive.
-    // The passes of ONE pipeline are a chain of dependent launches (K_gen -> K_event -> K_march), and K_event -- fat, latency-bound,
-    // 2 waves per SIMD -- leaves most of the chip idle while it runs.  So the render is cut into `npipes` independent pipelines: pipeline
-    // q takes the sample indices q, q + npipes, ... of the shard (the sharding contract of section 8e, applied inside one GPU), has its
-    // own slots, lists, hit ring and work counter, and runs on its own stream; the film is shared (atomics).  One pipeline's K_event then
-    // overlaps the others' K_march.  Per-path results do not depend on npipes.  Measured on the bench line: 1 pipeline 260, 2: 277, 3: 282,
-    // 4: 283 Mpaths/s (two PROCESSES on one GPU: 298); more slots per pipeline change nothing.
-    int npipes = 4;
-    { const char *e = getenv("MER_PIPES"); if (e && atoi(e) > 0) npipes = std::min(atoi(e), MER_MAX_PIPES); }
-    if (shard->spp_count < npipes) npipes = std::max(1, shard->spp_count);
-    uint32_t want = (uint32_t) ctx->prop.multiProcessorCount * 2048u * 4u;          // 4 x the resident lanes of the chip, over all pipelines
-    { const char *e = getenv("MER_NSLOTS"); if (e && atoi(e) > 0) want = (uint32_t) atoi(e); }
-    want = (want / (uint32_t) npipes + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;       // per pipeline
-    int ksteps0 = 128;        // eikonal steps per lane per pass (64..256 measured with class-sorted march lists: 128 is the flat optimum at 256^3 and 512^3)
-    { const char *e = getenv("MER_KSTEPS"); if (e && atoi(e) > 0) ksteps0 = atoi(e); }
-    // sorting the march lists by exit time scatters the lanes of a wave over the volume: a gain while the RIF sits near the caches
-    // (256^3: +8 %, 512^3: +3 %), a loss once every fetch goes to HBM (1024^3: -4 %)
-    P.mq_sort = (int64_t) P.rif.res[0] * P.rif.res[1] * P.rif.res[2] <= ((int64_t) 1 << 28) ? 1 : 0;
-    { const char *e = getenv("MER_MQ_SORT"); if (e) P.mq_sort = atoi(e) != 0; }
-    P.gen_iters = 8; P.gen_all = getenv("MER_GEN_ALL") ? 1 : 0;
-    // Connection requests gather in one row of cq over connect_every passes (the parked slots wait, the others keep marching) and
-    // K_connect drains the row at the end of the group: fuller launches, 5-8 % on configs[4]; in the tail it runs every pass.
-    // (The stage is throughput-bound -- ~14 k sensitivity steps per connection, 22 G steps/s -- not launch-latency-bound: gathering
-    // 16 passes gains no more than gathering 4.)
-    int connect_every0 = 4;
-    { const char *e = getenv("MER_CONNECT_EVERY"); if (e && atoi(e) > 0) connect_every0 = atoi(e); }
-
-    struct Run { Params P; uint32_t nslots = 0, pass = 0, since_connect = 0; unsigned blocks = 0, gen_blocks = 0; int connect_every = 1, cur = 0; bool work_left = true, done = false; };
-    Run runs[MER_MAX_PIPES];
-    HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int q = 0; q < npipes; q++) {
-        Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
-        if (q == 0) pp.stream = ctx->stream;
-        else if (!pp.own_stream) { HIP_CHECK(ctx, hipStreamCreateWithFlags(&pp.own_stream, hipStreamNonBlocking)); }
-        if (q > 0) { pp.stream = pp.own_stream; HIP_CHECK(ctx, hipStreamWaitEvent(pp.stream, ctx->ev0, 0)); }   // after what the caller queued (film zeroing ...)
-        if (pp.nslots < want) {                 // capacity: grows, never shrinks (render_paths runs one pipeline, mer_render two)
-            if (pp.slots) (void) hipFree(pp.slots);
-            if (pp.hitq) (void) hipFree(pp.hitq);
-            pp.slots = nullptr; pp.hitq = nullptr; pp.nslots = 0;
-            HIP_CHECK(ctx, hipMalloc((void **) &pp.slots, (size_t) want * MER_SLOT_WORDS * sizeof(uint32_t)));
-            for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq}) {
-                if (sq->items) (void) hipFree(sq->items);
-                sq->items = nullptr;
-                sq->segcap = 2u * (want / MER_NSEG) + 256u;          // two producer kernels may feed one segment
-                if (sq == &pp.eq) sq->segcap = 2u * (want / (MER_NSEG / MER_EV_CLASSES)) + 256u;   // every lane may be of one event class
-                if (sq == &pp.mq[0] || sq == &pp.mq[1]) sq->segcap = 2u * (want / (MER_NSEG / MER_MQ_CLASSES)) + 256u;   // ... or of one march class
-                if (sq == &pp.cq) sq->segcap = want + 256u;   // requests gather over several passes: a segment may see every slot once
-                HIP_CHECK(ctx, hipMalloc((void **) &sq->items, (size_t) sq->segcap * MER_NSEG * sizeof(uint32_t)));
-                if (!sq->counts) HIP_CHECK(ctx, hipMalloc((void **) &sq->counts, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t)));
-            }
-            pp.hitq_cap = 1; while (pp.hitq_cap < (unsigned long long) want * 2) pp.hitq_cap <<= 1;
-            HIP_CHECK(ctx, hipMalloc((void **) &pp.hitq, (size_t) pp.hitq_cap * sizeof(unsigned long long)));
-            pp.nslots = want;
-        }
-        if (!pp.live) {
-            HIP_CHECK(ctx, hipMalloc((void **) &pp.live, MER_LIVE_SLOTS * sizeof(uint32_t)));
-            HIP_CHECK(ctx, hipHostMalloc((void **) &pp.host_live, 8 * sizeof(uint32_t)));
-            HIP_CHECK(ctx, hipMalloc((void **) &pp.hitq_ctr, 64 * sizeof(unsigned long long)));       // [0] tail, [32] head, [48] this pipeline's work counter
-            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.readback[0], hipEventDisableTiming));
-            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.readback[1], hipEventDisableTiming));
-            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.finished, hipEventDisableTiming));
-        }
-        // pipeline q's part of the shard: sample indices spp_begin + (q + k npipes) spp_stride
-        R.P = P;
-        R.P.spp_begin = shard->spp_begin + q * shard->spp_stride; R.P.spp_stride = shard->spp_stride * npipes;
-        R.P.spp_count = (shard->spp_count - q + npipes - 1) / npipes;
-        R.P.total_work = (uint64_t) P.ntiles_mine * MER_TILE * MER_TILE * (uint64_t) R.P.spp_count;
-        R.nslots = want;
-        const uint64_t need_slots = (R.P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
-        if (need_slots < R.nslots) R.nslots = (uint32_t) need_slots;
-        R.P.slots = pp.slots; R.P.nslots = R.nslots; R.P.live = pp.live; R.P.eq = pp.eq; R.P.mq[0] = pp.mq[0]; R.P.mq[1] = pp.mq[1];
-        R.P.sq[0] = pp.sq[0]; R.P.sq[1] = pp.sq[1]; R.P.cq = pp.cq;
-        R.P.hitq = pp.hitq; R.P.hitq_cap = pp.hitq_cap; R.P.hitq_ctr = pp.hitq_ctr; R.P.work_counter = pp.hitq_ctr + 48;
-        R.P.ksteps = ksteps0; R.P.cq_row = 0;
-        R.connect_every = connect_every0;
-        R.done = R.P.total_work == 0;
-        if (R.done) continue;
-        R.blocks = R.nslots / MER_BLOCK;
-        R.gen_blocks = std::max(1u, std::min(R.nslots / MER_BLOCK, 1024u));      // 4096 waves x 512 ids per launch
-        HIP_CHECK(ctx, hipMemsetAsync(pp.slots, 0, (size_t) R.nslots * MER_SLOT_WORDS * sizeof(uint32_t), pp.stream));
-        HIP_CHECK(ctx, hipMemsetAsync(pp.live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), pp.stream));
-        for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq})
-            HIP_CHECK(ctx, hipMemsetAsync(sq->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), pp.stream));
-        HIP_CHECK(ctx, hipMemsetAsync(pp.hitq_ctr, 0, 64 * sizeof(unsigned long long), pp.stream));
-    }
-    auto body = [&](auto curved, auto rif, auto stepper, auto sigma, auto bnd) -> int {
-        constexpr int BND = decltype(bnd)::value;
-        const bool has_point = scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0;
-        // the signed-distance boundary exists in the EXTRA kernels only
-        const bool extra = BND != 0 || has_point || scene->modulation != MER_MODULATION_NONE || scene->boundary_bsdf != MER_BSDF_NULL;
-        auto kev = (extra || BND != 0) ? event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, true, BND>
-                                       : event_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, BND != 0, BND>;
-        auto kma = march_kernel<decltype(curved)::value, decltype(rif)::value, decltype(stepper)::value, decltype(sigma)::value, BND>;
-        auto kco = connect_stage_kernel<decltype(curved)::value ? decltype(rif)::value : MER_RIF_TRILINEAR, decltype(stepper)::value, decltype(sigma)::value, BND>;
-        const bool connect_stage = has_point && decltype(curved)::value;
-        auto kge = (extra || BND != 0) ? gen_kernel<decltype(curved)::value, true, BND> : gen_kernel<decltype(curved)::value, BND != 0, BND>;
-        const uint32_t check_every = 8;
-        const bool adaptive = getenv("MER_FIXED_K") == nullptr;
-        const bool pass_events = getenv("MER_NO_PASS_EVENTS") == nullptr;          // per-kernel timing of every pass (mer_last_render_stats)
-        // one batch = check_every passes of a pipeline followed by the read-back of its finished-slot count into slot `rb`.  Two batches
-        // are kept in flight per pipeline, so that a pipeline never runs dry while the host waits for another one's read-back (a
-        // finished render thus carries one batch of empty passes: ~0.5 ms)
-        auto enqueue_batch = [&](int q, int rb) -> int {
-            Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
-            for (uint32_t b = 0; b < check_every; b++) {
-                const uint32_t pass = R.pass;
-                while (pp.pass_events.size() < (size_t) (pass + 1) * 3) {
-                    hipEvent_t e; HIP_CHECK(ctx, hipEventCreate(&e)); pp.pass_events.push_back(e);
-                }
-                if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 0], pp.stream));
-                for (int g = 0; R.work_left && g < (pass == 0 ? 6 : 1); g++) hipLaunchKernelGGL(kge, dim3(R.gen_blocks), dim3(MER_BLOCK), 0, pp.stream, R.P);
-                hipLaunchKernelGGL(kev, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
-                if (connect_stage && ++R.since_connect >= (uint32_t) R.connect_every) {
-                    hipLaunchKernelGGL(kco, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
-                    R.since_connect = 0; R.P.cq_row++;
-                }
-                if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 1], pp.stream));
-                hipLaunchKernelGGL(kma, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
-                if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 2], pp.stream));
-                R.pass++;
-            }
-            HIP_CHECK(ctx, hipGetLastError());
-            HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 4 * rb, pp.live, sizeof(uint32_t), hipMemcpyDeviceToHost, pp.stream));
-            HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 4 * rb + 2, R.P.work_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, pp.stream));
-            HIP_CHECK(ctx, hipEventRecord(pp.readback[rb], pp.stream));
-            return 0;
-        };
-        for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q, 0)) return 1;
-        for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q, 1)) return 1;
-        for (;;) {
-            bool any = false;
-            for (int q = 0; q < npipes; q++) {
-                Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
-                if (R.done) continue;
-                any = true;
-                const int rb = R.cur; R.cur ^= 1;
-                HIP_CHECK(ctx, hipEventSynchronize(pp.readback[rb]));
-                const uint32_t finished_slots = pp.host_live[4 * rb];
-                if (finished_slots >= R.nslots) { R.done = true; continue; }
-                R.work_left = *(unsigned long long *) (pp.host_live + 4 * rb + 2) < R.P.total_work;
-                if (adaptive) {          // tail: few lanes left => longer passes, fewer launches
-                    const uint32_t alive = R.nslots - finished_slots;
-                    R.P.ksteps = alive < R.nslots / 64 ? ksteps0 * 32 : (alive < R.nslots / 16 ? ksteps0 * 8 : (alive < R.nslots / 4 ? ksteps0 * 2 : ksteps0));
-                    R.connect_every = alive < R.nslots / 4 ? 1 : connect_every0;
-                }
-                if (R.pass > (1u << 24)) return fail(ctx, "mer_render: pass limit exceeded");
-                if (enqueue_batch(q, rb)) return 1;
-            }
-            if (!any) break;
-        }
-        // join: the caller's stream continues after every pipeline
-        for (int q = 1; q < npipes; q++) {
-            if (runs[q].pass == 0) continue;
-            HIP_CHECK(ctx, hipEventRecord(ctx->pipes[q].finished, ctx->pipes[q].stream));
-            HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipes[q].finished, 0));
-        }
-        HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        ctx->timed = true;
-        {   // per-kernel device time of this render, from HIP events on the launch streams (summed over the pipelines: with two of
-            // them running side by side the sum exceeds the wall time)
-            HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
-            double em = 0, mm = 0; uint32_t passes = 0;
-            for (int q = 0; q < npipes; q++) {
-                for (uint32_t k = 0; pass_events && k < runs[q].pass; k++) {
-                    float a = 0, b = 0;
-                    (void) hipEventElapsedTime(&a, ctx->pipes[q].pass_events[k * 3 + 0], ctx->pipes[q].pass_events[k * 3 + 1]);
-                    (void) hipEventElapsedTime(&b, ctx->pipes[q].pass_events[k * 3 + 1], ctx->pipes[q].pass_events[k * 3 + 2]);
-                    em += a; mm += b;
-                }
-                passes += runs[q].pass;
-            }
-            ctx->last_event_ms = (float) em; ctx->last_march_ms = (float) mm; ctx->last_passes = (int) passes; ctx->last_pipes = npipes;
-        }
-        if (getenv("MER_VERBOSE")) { float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); fprintf(stderr, "[mer] wavefront: %d pipelines, %u + %u passes, K=%d, nslots=%u each, %.3f ms\n", npipes, runs[0].pass, npipes > 1 ? runs[1].pass : 0u, ksteps0, runs[0].nslots, ms); }
-        return 0;
-    };
-    return scene->boundary == MER_BOUNDARY_SDF ? dispatch_modes_sdf(ctx, scene, body) : dispatch_modes(ctx, scene, body);
-}
-
 int mer_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed, float *film_dev) {
     if (!ctx || !scene || !film_dev) return 1;
-    return launch_render(ctx, scene, shard, seed, film_dev, nullptr);
+    int32_t ch = 5;
+    if (mer_film_channels(ctx, scene, &ch)) return 1;
+    return launch_render(ctx, scene, shard, seed, film_dev, nullptr, (uint64_t) scene->width * scene->height * (uint64_t) ch, 0);
 }
 
 int mer_render_paths(mer_context *ctx, const mer_scene_desc *scene, int32_t sample_index, uint64_t seed, float *out_rgb) {
@@ -832,7 +596,7 @@ int mer_render_paths(mer_context *ctx, const mer_scene_desc *scene, int32_t samp
     if (buf.alloc(n * 4)) return 1;
     HIP_CHECK(ctx, hipMemsetAsync(buf.p, 0, n * 4, ctx->stream));
     mer_shard sh = {sample_index, 1, 1, 0, 1};
-    if (launch_render(ctx, scene, &sh, seed, buf.as<float>(), buf.as<float>())) return 1;
+    if (launch_render(ctx, scene, &sh, seed, buf.as<float>(), buf.as<float>(), n, n)) return 1;
     return buf.download(out_rgb, n * 4);
 }
 
@@ -873,7 +637,7 @@ int mer_lookup_trilinear(mer_context *ctx, mer_volume h, const float *pts, int64
     auto it = ctx->volumes.find(h);
     if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
     if (it->second.desc.channels != 1) return fail(ctx, "lookupFloat(): volume does not support float lookups");
-    DGrid g; fill_dgrid(it->second, g);
+    DGrid g; fill_dgrid(ctx, it->second, g);
     DevBuf dp(ctx), dv(ctx), di(ctx);
     if (dp.upload(pts, n * 12) || dv.alloc(n * 4) || di.alloc(n * 16)) return 1;
     hipLaunchKernelGGL(lookup_trilinear_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, g, dp.as<float>(), n, dv.as<float>(),
@@ -888,7 +652,7 @@ int mer_lookup_trilinear_rgb(mer_context *ctx, mer_volume h, const float *pts, i
     if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
     if (it->second.desc.channels != 3) return fail(ctx, "lookupSpectrum(): volume does not support spectrum lookups");
     Volume tmp = it->second; tmp.cell8 = nullptr;
-    DGrid g; fill_dgrid(tmp, g);
+    DGrid g; fill_dgrid(ctx, tmp, g);
     DevBuf dp(ctx), dv(ctx);
     if (dp.upload(pts, n * 12) || dv.alloc(n * 12)) return 1;
     hipLaunchKernelGGL(lookup_rgb_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, g, dp.as<float>(), n, dv.as<float>());
@@ -901,7 +665,7 @@ int mer_rif_value_grad(mer_context *ctx, mer_volume h, int32_t interp, const flo
     if (it->second.desc.channels != 1 || it->second.desc.dtype != MER_VOL_F32) return fail(ctx, "value(): not implemented for this volume type"); // volume.cpp:57-80
     if (interp != MER_RIF_TRILINEAR && interp != MER_RIF_BSPLINE3) return fail(ctx, "unknown rif_interp");
     if (interp == MER_RIF_BSPLINE3 && !it->second.coeff) return fail(ctx, "volume has no spline coefficients");
-    DGrid g; fill_dgrid(it->second, g);
+    DGrid g; fill_dgrid(ctx, it->second, g);
     DevBuf dp(ctx), dv(ctx), dg(ctx);
     if (dp.upload(pts, n * 12) || dv.alloc(n * 4) || dg.alloc(n * 12)) return 1;
     hipLaunchKernelGGL(rif_value_grad_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, g, interp, dp.as<float>(), n, dv.as<float>(), dg.as<float>());
@@ -918,12 +682,8 @@ int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0,
     DevBuf a(ctx), b(ctx), c(ctx), op(ctx), ov(ctx), od(ctx), oo(ctx), ok(ctx);
     if (a.upload(p0, n * 12) || b.upload(d0, n * 12) || c.upload(dist, n * 4) || op.alloc(n * 12) || ov.alloc(n * 12) ||
         od.alloc(n * 4) || oo.alloc(n * 4) || ok.alloc(n * 4)) return 1;
-    int rifk = scene->rif_mode;
-    if (scene->rif_mode == MER_RIF_TRILINEAR) {
-        if (P.rif.layout == MER_LAYOUT_BRICK27 || P.rif.layout == MER_LAYOUT_BRICK125) return fail(ctx, "this leaf entry point takes the RIF in the dense or cell8 layout");
-        if (P.rif.layout == MER_LAYOUT_CELL8) rifk = P.rif.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
-        else rifk = P.rif.buf_bytes ? RIFK_DENSE_BUF : MER_RIF_TRILINEAR;
-    }
+    const int rifk = rif_fetch_kind(ctx, scene);
+    if (rifk == RIFK_BRICK27 || rifk == RIFK_BRICK27_BUF) return fail(ctx, "this leaf entry point takes the RIF in the dense or cell8 layout");
 #define MER_TRACE_CASE(R, S)                                                                                       \
     if (rifk == R && scene->stepper == S)                                                                          \
         hipLaunchKernelGGL((er_trace_kernel<R, S>), dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), \
@@ -943,20 +703,27 @@ int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0,
 
 int mer_connect(mer_context *ctx, const mer_scene_desc *scene, const float *p1, const float *p2, int64_t n, uint64_t seed, float *out) {
     Params P;
-    if (make_params(ctx, scene, P)) return 1;
+    if (make_params(ctx, scene, P, true)) return 1;
     if (scene->rif_mode == MER_RIF_CONST) return fail(ctx, "mer_connect needs a RIF volume");
+    if (scene->rif_mode == MER_RIF_ACOUSTIC) return fail(ctx, "mer_connect: the analytic acoustic RIF is connected inside mer_render only");
     P.seed = seed;
     DevBuf a(ctx), b(ctx), r(ctx);
     if (a.upload(p1, n * 12) || b.upload(p2, n * 12) || r.alloc(n * 48)) return 1;
-    int rifk = scene->rif_mode;
-    if (scene->rif_mode == MER_RIF_TRILINEAR) {
-        if (P.rif.layout == MER_LAYOUT_BRICK27 || P.rif.layout == MER_LAYOUT_BRICK125) return fail(ctx, "this leaf entry point takes the RIF in the dense or cell8 layout");
-        if (P.rif.layout == MER_LAYOUT_CELL8) rifk = P.rif.buf_bytes ? RIFK_CELL8_BUF : RIFK_CELL8;
-        else rifk = P.rif.buf_bytes ? RIFK_DENSE_BUF : MER_RIF_TRILINEAR;
-    }
-#define MER_CONNECT_CASE(R) if (rifk == R) hipLaunchKernelGGL((connect_kernel<R>), dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), n, r.as<float>());
-    MER_CONNECT_CASE(MER_RIF_TRILINEAR) MER_CONNECT_CASE(MER_RIF_BSPLINE3) MER_CONNECT_CASE(RIFK_DENSE_BUF) MER_CONNECT_CASE(RIFK_CELL8) MER_CONNECT_CASE(RIFK_CELL8_BUF)
+    const int rifk = rif_fetch_kind(ctx, scene);
+    if (rifk == RIFK_BRICK27 || rifk == RIFK_BRICK27_BUF) return fail(ctx, "this leaf entry point takes the RIF in the dense or cell8 layout");
+    bool launched = false;
+#define MER_CONNECT_CASE(R, B) if (!launched && rifk == R && (scene->boundary == MER_BOUNDARY_SDF) == (B == 1)) { launched = true;   \
+        hipLaunchKernelGGL((connect_kernel<R, B>), dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), n, r.as<float>()); }
+    MER_CONNECT_CASE(MER_RIF_TRILINEAR, 0) MER_CONNECT_CASE(MER_RIF_BSPLINE3, 0) MER_CONNECT_CASE(RIFK_DENSE_BUF, 0) MER_CONNECT_CASE(RIFK_CELL8, 0) MER_CONNECT_CASE(RIFK_CELL8_BUF, 0)
+    // signed-distance boundary: the fetch kinds mer_render instantiates for it
+    MER_CONNECT_CASE(MER_RIF_TRILINEAR, 1) MER_CONNECT_CASE(RIFK_CELL8_BUF, 1) MER_CONNECT_CASE(MER_RIF_BSPLINE3, 1)
 #undef MER_CONNECT_CASE
+    if (!launched) {
+        // a dense RIF below 4 GiB selects buffer loads; the signed-distance kernels read it with global loads
+        if (scene->boundary == MER_BOUNDARY_SDF && rifk == RIFK_DENSE_BUF) {
+            hipLaunchKernelGGL((connect_kernel<MER_RIF_TRILINEAR, 1>), dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), n, r.as<float>());
+        } else return fail(ctx, "mer_connect: unsupported RIF layout for this boundary");
+    }
     HIP_CHECK(ctx, hipGetLastError());
     return r.download(out, n * 48);
 }

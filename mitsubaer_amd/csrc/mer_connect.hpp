@@ -94,7 +94,7 @@ __device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, CellCache &c
         bspline_weights(py - fly, wy, dy); bspline_weights2(py - fly, ey);
         bspline_weights(pz - flz, wz, dz); bspline_weights2(pz - flz, ez);
         int ix = min(max((int) flx - 1, 0), g.res[0] - 4), iy = min(max((int) fly - 1, 0), g.res[1] - 4), iz = min(max((int) flz - 1, 0), g.res[2] - 4);
-        const float *C = g.coeff + ((size_t) iz * g.res[1] + iy) * g.res[0] + ix;
+        const float *C = g.coeff + MER_CHK(g.chk, CHK_GRID_COEFF, ((size_t) iz * g.res[1] + iy) * g.res[0] + ix, g.n_dense - 3u * (uint32_t) (g.res[0] * g.res[1] + g.res[0] + 1));
         const int sy = g.res[0], sz = g.res[0] * g.res[1];
         float f = 0, gx = 0, gy = 0, gz = 0, hxx = 0, hyy = 0, hzz = 0, hxy = 0, hyz = 0, hzx = 0;
         for (int k = 0; k < 4; k++)
@@ -123,6 +123,8 @@ __device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, CellCache &c
         H.m[0][1] = H.m[1][0] = hxy; H.m[1][2] = H.m[2][1] = hyz; H.m[0][2] = H.m[2][0] = hzx;
     }
 }
+
+__device__ __forceinline__ bool finite3(f3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
 
 template <int RIF, int BND = 0> struct Connector {
     const Params &P;
@@ -155,6 +157,8 @@ template <int RIF, int BND = 0> struct Connector {
     __device__ bool computefdf(f3 v_i, f3 p1, f3 p2, f3 &error, m33 &J) const {
         m33 dp(0.0f), dv(1.0f);
         error = p1 - p2; J = m33(0.0f);
+        // a shooting direction that is not a finite non-zero vector has no ray (the solver's step can overflow: guard, not reference)
+        if (!finite3(v_i) || !(dot(v_i, v_i) > 0.0f) || !isfinite(dot(v_i, v_i))) return false;
         if (RIF == MER_RIF_BSPLINE3 && !inside_volume_limits(P.rif, p1)) return false;
         float h = P.sc.stepsize;
         int nBisect = (int) ceilf((float) precision / 0.30102999566f);
@@ -170,6 +174,7 @@ template <int RIF, int BND = 0> struct Connector {
         for (int i = 0; i < maxSteps; i++) {
             oldp = p; oldv = v; olddp = dp; olddv = dv;
             dstep(p, v, dp, dv, h);
+            if (!finite3(p) || !finite3(v)) return false;
             signNew = dot(p - p2, v) < 0.0f;
             if (signNew != signOld) {
                 while (nBisect > 0) {
@@ -198,6 +203,11 @@ template <int RIF, int BND = 0> struct Connector {
         f3 e; m33 J;
         bool ok = computefdf(x, p1, p2, e, J);
         float cost = 0.5f * dot(e, e), lambda = 1e-4f;
+        // computefdf rescales its argument to |v0| = n(p1): the residual does not depend on |x|, J^T J is singular along x and only the
+        // damping makes the step finite -- with little damping the step along x is rounding noise of any size.  The unknown lives on the
+        // sphere |x| = n(p1): every accepted iterate is put back on it, and a step whose determinant is below float resolution of the
+        // product of the pivots, or that is not finite, is retried with more damping.
+        const float radius = sqrtf(dot(x, x));
         for (int it = 0; it < maxIter && ok && cost >= tol * 1e-3f; ++it) {
             float A[3][3], b[3]; const float E[3] = {e.x, e.y, e.z};
             for (int i = 0; i < 3; i++) { b[i] = 0; for (int k = 0; k < 3; k++) b[i] -= J.m[k][i] * E[k];
@@ -208,12 +218,15 @@ template <int RIF, int BND = 0> struct Connector {
                 for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = A[i][j] + (i == j ? lambda * (A[i][i] + 1e-12f) : 0.0f);
                 const float det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
                                   M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
-                if (det == 0.0f || !isfinite(det)) { lambda *= 10; continue; }
+                if (!(fabsf(det) > 1e-6f * fabsf(M[0][0] * M[1][1] * M[2][2])) || !isfinite(det)) { lambda *= 10; continue; }
                 float d[3];
                 d[0] = (b[0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (b[1] * M[2][2] - M[1][2] * b[2]) + M[0][2] * (b[1] * M[2][1] - M[1][1] * b[2])) / det;
                 d[1] = (M[0][0] * (b[1] * M[2][2] - M[1][2] * b[2]) - b[0] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * b[2] - b[1] * M[2][0])) / det;
                 d[2] = (M[0][0] * (M[1][1] * b[2] - b[1] * M[2][1]) - M[0][1] * (M[1][0] * b[2] - b[1] * M[2][0]) + b[0] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
                 f3 xn(x.x + d[0], x.y + d[1], x.z + d[2]), en; m33 Jn;
+                const float ln = sqrtf(dot(xn, xn));
+                if (!(ln > 0.0f) || !isfinite(ln)) { lambda *= 10; continue; }
+                xn = xn * (radius / ln);
                 const bool okn = computefdf(xn, p1, p2, en, Jn);
                 const float cn = 0.5f * dot(en, en);
                 if (okn && cn < cost) { x = xn; e = en; J = Jn; cost = cn; lambda = fmaxf(lambda * 0.1f, 1e-9f); improved = true; }
@@ -242,6 +255,7 @@ template <int RIF, int BND = 0> struct Connector {
         for (int i = 0; i < maxSteps; i++) {
             oldp = p; oldv = v;
             verlet(p, v, h);
+            if (!finite3(p) || !finite3(v)) return false;
             signNew = dot(p - p2, v) < 0.0f;
             if (!inside_shape_b<BND>(P, p)) return false;
             if (signNew != signOld) {
@@ -379,12 +393,12 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
 }
 
 // leaf kernel: out stride 12: ok, weight, dirToP2[3], revDirToP1[3], dist, opticalDist, 0, 0; RNG stream (seed, i, 0)
-template <int RIF>
+template <int RIF, int BND = 0>
 __global__ void __launch_bounds__(64) connect_kernel(const Params P, const float *p1, const float *p2, int64_t n, float *out) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Rng rng; rng.seed(P.seed, (uint32_t) i, 0);
-    Connector<RIF> K(P);
+    Connector<RIF, BND> K(P);
     const f3 a(p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]), b(p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]);
     float w = 1.0f, od = 0, di = 0; f3 dir(0, 0, 0), rev(0, 0, 0);
     const bool ok = K.connect(a, b, normalize(b - a), rng, w, dir, rev, od, di);

@@ -34,6 +34,25 @@ __device__ __forceinline__ float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z))
 __device__ __forceinline__ bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
 
 // ------------------------------------------------------------------------------------------------
+// -DMER_BOUNDS_CHECK (libmer_check.so): every index a kernel forms into a device buffer -- path-state slots, work-list segments and
+// items, hit ring, film, per-path output, grid payloads and their re-laid-out records, spline coefficients -- is compared with the
+// buffer's extent before the access.  The first violation is recorded (kind, index, limit) in a device word array and the access is
+// redirected to element 0, so that an out-of-range index is REPORTED (mer_debug_bounds) instead of faulting or, worse, silently
+// reading mapped memory.  The product build compiles the checks away.
+enum { CHK_SLOT = 1, CHK_QUEUE_SEG, CHK_QUEUE_ITEM, CHK_HITQ, CHK_FILM, CHK_PATHOUT, CHK_GRID_DENSE, CHK_GRID_RECORD, CHK_GRID_COEFF,
+       CHK_GRID_RGB, CHK_LIVE_ROW };
+#ifdef MER_BOUNDS_CHECK
+__device__ __forceinline__ uint64_t mer_chk(unsigned long long *chk, int kind, uint64_t idx, uint64_t limit) {
+    if (idx < limit) return idx;
+    if (chk && atomicAdd(chk, 1ULL) == 0ULL) { chk[1] = (unsigned long long) kind; chk[2] = idx; chk[3] = limit; }
+    return 0;
+}
+#define MER_CHK(chkptr, kind, idx, limit) mer_chk((chkptr), (kind), (uint64_t) (idx), (uint64_t) (limit))
+#else
+#define MER_CHK(chkptr, kind, idx, limit) (idx)
+#endif
+
+// ------------------------------------------------------------------------------------------------
 // Sampler: counter-based PCG32 stream per (pixel, sample); float conversion as Random::nextFloat
 // (src/libcore/random.cpp:630-639: 23 mantissa bits in [1,2) minus 1).
 struct Rng {
@@ -77,6 +96,8 @@ struct DGrid {
     float   lim_min[3], lim_max[3];   // spline interpolatable limits (splinevolume.cpp:280-281)
     uint32_t buf_bytes;               // byte size of data / cell8 when it fits a buffer descriptor (< 4 GiB), else 0
     float   ac_n_o, ac_n_max, ac_k_r; int32_t ac_mode;   // RIFK_ACOUSTIC: the analytic field of acousticrifvolume (no data)
+    unsigned long long *chk;          // MER_BOUNDS_CHECK: violation record (NULL in the product build)
+    uint64_t n_dense, n_record;       // element counts of data (all channels) and of cell8 (floats): the extents the checks use
 };
 
 // include/mitsuba/core/aabb.h:308-339 (dRcp = 1/d as Ray::setDirection)
@@ -100,6 +121,7 @@ __device__ __forceinline__ bool aabb_intersect(const float mn[3], const float mx
 }
 
 __device__ __forceinline__ float grid_fetch(const DGrid &g, long long idx) {
+    idx = (long long) MER_CHK(g.chk, CHK_GRID_DENSE, idx, g.n_dense);
     if (g.dtype == MER_VOL_F32) return ((const float *) g.data)[idx];
     return (float) ((const uint8_t *) g.data)[idx] / 255.0f;      // m_densityMap, gridvolume.cpp:204-214
 }
@@ -120,7 +142,7 @@ __device__ __forceinline__ float lookup_float(const DGrid &g, f3 p, int *idx4 = 
     float d000, d001, d010, d011, d100, d101, d110, d111;
     if (g.layout == MER_LAYOUT_CELL8) {
         const int cell = (z1 * (g.res[1] - 1) + y1) * (g.res[0] - 1) + x1;
-        const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
+        const float4 *c = (const float4 *) (g.cell8 + (size_t) MER_CHK(g.chk, CHK_GRID_RECORD, (size_t) cell * 8, g.n_record - 7));
         const float4 a = c[0], b = c[1];
         d000 = a.x; d001 = a.y; d010 = a.z; d011 = a.w; d100 = b.x; d101 = b.y; d110 = b.z; d111 = b.w;
     } else {
@@ -203,7 +225,7 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
         cc.cz = __builtin_amdgcn_fmed3f(floorf(pz), 0.0f, (float) (g.res[2] - 2));
         const int x1 = (int) cc.cx, y1 = (int) cc.cy, z1 = (int) cc.cz;
         fx = px - cc.cx; fy = py - cc.cy; fz = pz - cc.cz;
-        const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);
+        const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);      // make_params: res[1] * res[2] <= 2^24
         if (RIFK == RIFK_BRICK27 || RIFK == RIFK_BRICK27_BUF) {
             if (base != cc.cell) {
                 // the cell's 8 corners as four x-pairs out of its brick's record (2^3 cells: 27 corners, one 128-byte line; 4^3 cells: 125
@@ -211,7 +233,8 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
                 cc.cell = base;
                 const int bs = g.bshift, bm = (1 << bs) - 1, bw = g.bw;
                 const int brick = (int) (__umul24(__umul24(z1 >> bs, g.nby) + (y1 >> bs), g.nbx) + (x1 >> bs));
-                const int o = brick * g.recw + ((z1 & bm) * bw + (y1 & bm)) * bw + (x1 & bm);   // word index of the cell's corner (0,0,0)
+                const int o = (int) MER_CHK(g.chk, CHK_GRID_RECORD, (uint32_t) (brick * g.recw + ((z1 & bm) * bw + (y1 & bm)) * bw + (x1 & bm)),
+                                            g.n_record - (uint32_t) (bw * bw + bw) - 1u);   // word index of the cell's corner (0,0,0)
                 u32x2 r00, r01, r10, r11;
                 if (RIFK == RIFK_BRICK27_BUF) {
                     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
@@ -220,7 +243,7 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
                     r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * bw * 4, 0);
                     r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, (bw * bw + bw) * 4, 0);
                 } else {
-                    const float *q = g.cell8 + (size_t) brick * g.recw + (((z1 & bm) * bw + (y1 & bm)) * bw + (x1 & bm));
+                    const float *q = g.cell8 + (size_t) o;
                     r00 = u32x2{__float_as_uint(q[0]), __float_as_uint(q[1])}; r01 = u32x2{__float_as_uint(q[bw]), __float_as_uint(q[bw + 1])};
                     r10 = u32x2{__float_as_uint(q[bw * bw]), __float_as_uint(q[bw * bw + 1])}; r11 = u32x2{__float_as_uint(q[bw * bw + bw]), __float_as_uint(q[bw * bw + bw + 1])};
                 }
@@ -230,8 +253,9 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
         } else
         if (MER_CELL_TEST(base != cc.cell)) {
             cc.cell = base;
+            const int dbase = (int) MER_CHK(g.chk, CHK_GRID_DENSE, (uint32_t) base, g.n_dense - (uint32_t) (g.res[0] * g.res[1] + g.res[0]) - 1u); (void) dbase;
             if (RIFK == RIFK_CELL8 || RIFK == RIFK_CELL8_BUF) {
-                const int cell = (int) (__umul24(__umul24(z1, g.res[1] - 1) + y1, g.res[0] - 1) + x1);
+                const int cell = (int) MER_CHK(g.chk, CHK_GRID_RECORD, (uint32_t) (__umul24(__umul24(z1, g.res[1] - 1) + y1, g.res[0] - 1) + x1), g.n_record >> 3);
                 float4 a, b;
                 if (RIFK == RIFK_CELL8_BUF) {
                     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
@@ -247,17 +271,17 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
             } else if (RIFK == RIFK_DENSE_BUF) {
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.data, 0, (int) g.buf_bytes, 0x00020000);
                 const int sy4 = g.res[0] * 4, sz4 = g.res[0] * g.res[1] * 4;
-                const u32x2 r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, 0, 0);
-                const u32x2 r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sy4, 0);
-                const u32x2 r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sz4, 0);
-                const u32x2 r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, base * 4, sz4 + sy4, 0);
+                const u32x2 r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, 0, 0);
+                const u32x2 r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sy4, 0);
+                const u32x2 r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sz4, 0);
+                const u32x2 r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sz4 + sy4, 0);
                 cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
                 cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
             } else {
                 const float *D = (const float *) g.data;
                 const int sy = g.res[0], sz = g.res[0] * g.res[1];
-                cc.d000 = D[base]; cc.d001 = D[base + 1]; cc.d010 = D[base + sy]; cc.d011 = D[base + sy + 1];
-                cc.d100 = D[base + sz]; cc.d101 = D[base + sz + 1]; cc.d110 = D[base + sz + sy]; cc.d111 = D[base + sz + sy + 1];
+                cc.d000 = D[dbase]; cc.d001 = D[dbase + 1]; cc.d010 = D[dbase + sy]; cc.d011 = D[dbase + sy + 1];
+                cc.d100 = D[dbase + sz]; cc.d101 = D[dbase + sz + 1]; cc.d110 = D[dbase + sz + sy]; cc.d111 = D[dbase + sz + sy + 1];
             }
         }
     }
@@ -302,7 +326,7 @@ __device__ __forceinline__ void bspline_value_grad(const DGrid &g, f3 p, float &
     bspline_weights(pz - flz, wz, dwz);
     int ix = (int) flx - 1, iy = (int) fly - 1, iz = (int) flz - 1;
     ix = min(max(ix, 0), g.res[0] - 4); iy = min(max(iy, 0), g.res[1] - 4); iz = min(max(iz, 0), g.res[2] - 4);  // memory safety only
-    const float *C = g.coeff + ((size_t) iz * g.res[1] + iy) * g.res[0] + ix;
+    const float *C = g.coeff + MER_CHK(g.chk, CHK_GRID_COEFF, ((size_t) iz * g.res[1] + iy) * g.res[0] + ix, g.n_dense - 3u * (uint32_t) (g.res[0] * g.res[1] + g.res[0] + 1));
     const int sy = g.res[0], sz = g.res[0] * g.res[1];
     float f = 0.0f, gx = 0.0f, gy = 0.0f, gz = 0.0f;
 #pragma unroll
@@ -449,6 +473,7 @@ struct SegQueue {
     uint32_t *items;          // [MER_NSEG][segcap]
     uint32_t *counts;         // [MER_LIVE_SLOTS][MER_NSEG], row = pass & (MER_LIVE_SLOTS-1)
     uint32_t segcap;
+    unsigned long long *chk;  // MER_BOUNDS_CHECK: violation record (NULL in the product build)
 };
 
 // Everything a render / leaf kernel needs, passed by value as the kernel argument.
@@ -483,9 +508,12 @@ struct Params {
     unsigned long long *hitq_ctr;       // [0] produced (tail), [1] consumed (head)
     int32_t gen_iters, gen_all;
     uint32_t cq_row;                    // row of the connection-request list that K_event appends to and the next K_connect drains
-    int32_t mq_sort;                    // 1: march lists sorted by estimated steps to the boundary (MER_MQ_SORT=0 turns it off for A/B runs)
+    int32_t mq_sort;                    // 1: march lists sorted by estimated steps to the boundary (option mq_sort = 0 turns it off for A/B runs)
+    unsigned long long *chk;            // MER_BOUNDS_CHECK: violation record (NULL in the product build)
+    uint64_t n_film, n_path_out;        // float counts of film / path_out: the extents the checks use
 };
 #define MER_LIVE_SLOTS 4096
+#define MER_COUNTER_REPLICAS 64        // counters are flushed into one of this many copies (summed on the host)
 
 __device__ __forceinline__ bool inside_shape(const mer_scene_desc &s, f3 p) {   // heterogeneousrefractive.cpp:707-726 as data (D5)
     if (s.boundary == MER_BOUNDARY_SPHERE) {
@@ -654,7 +682,7 @@ __device__ __forceinline__ void film_splat(const Params &P, float px, float py, 
         for (int x = minx; x <= maxx; ++x) {
             const float wx = P.fvalues[min((int) fabsf(((float) x - posx) * P.fscale), 31)];
             const float weight = wx * wy;
-            float *dest = P.film + ((size_t) y * W + x) * P.film_ch;
+            float *dest = P.film + MER_CHK(P.chk, CHK_FILM, ((size_t) y * W + x) * P.film_ch, P.n_film - (uint32_t) P.film_ch + 1u);
             if (what & 1) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) atomicAdd(dest + bin * 3 + k, weight * temp[k]);
@@ -677,7 +705,7 @@ __device__ __forceinline__ float mseq(const Params &P, float t, float phase) {
     else if (pathLength > (1 - 1.0 / mP) * lambda) return 1 - (lambda - pathLength) * (mP - 1) / lambda;
     else return (float) (1.0 / mP);
 }
-__device__ __noinline__ float correlation_function(const Params &P, float t) {
+static __device__ __noinline__ float correlation_function(const Params &P, float t) {
     const float lambda = P.sc.mod_lambda, modPhase = P.mod_phase;
     float pathLength = t;
     switch (P.sc.modulation) {
@@ -712,6 +740,31 @@ __device__ __forceinline__ void film_contribute(const Params &P, float px, float
     const float b = floorf((pathLength - P.sc.min_bound) / P.sc.bin_width);
     if (!(b >= 0.0f) || !(b < (float) P.frames)) return;
     film_splat(P, px, py, value, 0.0f, (int) b, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Work decode: w -> (pixel, sample).  Sample-major; inside a pass pixels go by 32x32 image tiles (the
+// reference's block size, src/mitsuba/mitsuba.cpp:80-81) and by 8x8 sub-tiles so that the 64 lanes of a
+// fresh wavefront start on one 8x8 pixel patch (coherent camera rays, distinct film pixels per lane).
+#define MER_BLOCK 256
+#define MER_TILE 32
+__device__ __forceinline__ bool decode_work(const Params &P, uint64_t w, int &x, int &y, uint32_t &sample) {
+    const uint32_t npix = (uint32_t) P.ntiles_mine * (MER_TILE * MER_TILE);
+    const uint32_t s_local = (uint32_t) (w / npix);
+    const uint32_t r = (uint32_t) (w - (uint64_t) s_local * npix);
+    const uint32_t tile_local = r >> 10, q = r & 1023u, sub = q >> 6, lane = q & 63u;
+    const uint32_t tile = (uint32_t) P.tile_rank + tile_local * (uint32_t) P.tile_count;
+    const uint32_t tx = tile % (uint32_t) P.tiles_x, ty = tile / (uint32_t) P.tiles_x;
+    x = (int) (tx * MER_TILE + (sub & 3u) * 8u + (lane & 7u));
+    y = (int) (ty * MER_TILE + (sub >> 2) * 8u + (lane >> 3));
+    sample = (uint32_t) P.spp_begin + s_local * (uint32_t) P.spp_stride;
+    return x < P.sc.width && y < P.sc.height;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
 
 }  // namespace mer

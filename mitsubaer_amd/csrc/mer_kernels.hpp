@@ -1,267 +1,10 @@
-// mer_kernels.hpp -- gfx950 kernels: the render megakernel (K_trace + K_film), leaf kernels for the
-// parity entry points, grid re-layout, B-spline prefilter, synthetic fields.
+// mer_kernels.hpp -- gfx950 kernels behind the leaf entry points (parity tests), grid re-layout, B-spline prefilter
+// (K_prefilter), synthetic fields.  The render kernels are in mer_wavefront.hpp.
 #pragma once
 #include "mer_walk.hpp"
+#include "mer_connect.hpp"
 
 namespace mer {
-
-#define MER_BLOCK 256
-#define MER_TILE 32
-
-// ---------------------------------------------------------------------------------------------------
-// Work decode: w -> (pixel, sample).  Sample-major; inside a pass pixels go by 32x32 image tiles (the
-// reference's block size, src/mitsuba/mitsuba.cpp:80-81) and by 8x8 sub-tiles so that the 64 lanes of a
-// fresh wavefront start on one 8x8 pixel patch (coherent camera rays, distinct film pixels per lane).
-__device__ __forceinline__ bool decode_work(const Params &P, uint64_t w, int &x, int &y, uint32_t &sample) {
-    const uint32_t npix = (uint32_t) P.ntiles_mine * (MER_TILE * MER_TILE);
-    const uint32_t s_local = (uint32_t) (w / npix);
-    const uint32_t r = (uint32_t) (w - (uint64_t) s_local * npix);
-    const uint32_t tile_local = r >> 10, q = r & 1023u, sub = q >> 6, lane = q & 63u;
-    const uint32_t tile = (uint32_t) P.tile_rank + tile_local * (uint32_t) P.tile_count;
-    const uint32_t tx = tile % (uint32_t) P.tiles_x, ty = tile / (uint32_t) P.tiles_x;
-    x = (int) (tx * MER_TILE + (sub & 3u) * 8u + (lane & 7u));
-    y = (int) (ty * MER_TILE + (sub >> 2) * 8u + (lane >> 3));
-    sample = (uint32_t) P.spp_begin + s_local * (uint32_t) P.spp_stride;
-    return x < P.sc.width && y < P.sc.height;
-}
-
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-}  // namespace mer
-#include "mer_wavefront.hpp"
-namespace mer {
-
-// ---------------------------------------------------------------------------------------------------
-// Megakernel form of the same state machine (kept for A/B timing: MER_MODE=mega).
-// K_trace: VolumetricPathTracer::Li (src/integrators/path/volpath.cpp:84-343) restricted to one convex
-// index-matched shape + interior medium + constant environment emitter, with the refractive hooks of
-// src/libbidir/edge.cpp:45-60,91-93 and src/libbidir/vertex.cpp:251-255, as a lane-persistent state machine.
-template <bool CURVED, int RIF, int STEPPER, int SIGMA>
-__global__ void __launch_bounds__(MER_BLOCK) render_kernel(const Params P) {
-    typedef Walk<CURVED, RIF, STEPPER, SIGMA> WalkT;
-    const mer_scene_desc &S = P.sc;
-    const f3 env(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
-    const bool hasEnv = !is_zero(env);
-    const bool hasEmission = S.emission[0] != 0 || S.emission[1] != 0 || S.emission[2] != 0;
-    const int maxDepth = S.max_depth;
-    const int nwalks = (SIGMA == MER_SIGMA_GRID && S.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
-
-    Rng rng; rng.state = 0; rng.inc = 1;
-    LaneCounters C; C.clear();
-    WalkT W;
-    W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = 0; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1;
-    W.dist = 0; W.opt = 0; W.sdens = 0; W.Tr = 1; W.trsum = 0; W.walk = 0; W.p = f3(0, 0, 0); W.v = f3(0, 0, 1);
-    W.backstep = 0; W.hprev = 0; W.cc.reset();
-    int st = ST_NEW;
-    int px_i = 0, py_i = 0; float px = 0, py = 0;
-    f3 L(0, 0, 0), T(1, 1, 1);
-    // path flags live in one VGPR word (lane-mask booleans spilled through SGPRs proved fragile here)
-    enum { F_SCATTERED = 1, F_EMITTED = 2, F_ITSVALID = 4 };
-    int depth = 1, flags = F_EMITTED;
-#define scattered ((flags & F_SCATTERED) != 0)
-#define emitted ((flags & F_EMITTED) != 0)
-#define itsValid ((flags & F_ITSVALID) != 0)
-#define SET_FLAG(f, v) flags = (v) ? (flags | (f)) : (flags & ~(f))
-    f3 ps(0, 0, 0), dsave(0, 0, 1), dd(0, 0, 1), wi(0, 0, 1);
-    f3 trv(1, 1, 1);                   // transmittance of the walk that just finished
-    float phasePdf = 0, itsT = 0;
-    uint32_t wave_iters = 0;
-
-    for (;;) {
-        int ev = EV_NONE;
-        float sigma = 0.0f;
-        // ------------------------------------------------------------------ regeneration (integrator.cpp:162-187)
-        if (st == ST_NEW) {
-            const uint64_t w = atomicAdd(P.work_counter, 1ULL);
-            if (w >= P.total_work) st = ST_DONE;
-            else {
-                uint32_t sample;
-                if (!decode_work(P, w, px_i, py_i, sample)) { /* pixel of a partial edge tile */ }
-                else {
-                    rng.seed(P.seed, (uint32_t) (py_i * S.width + px_i), sample);
-                    const float sx = rng.next1D(), sy = rng.next1D();
-                    px = (float) px_i + sx; py = (float) py_i + sy;
-                    f3 o, d; float mint, maxt;
-                    sample_ray(P, px, py, o, d, mint, maxt);
-                    L = f3(0, 0, 0); T = f3(1, 1, 1); depth = 1; flags = F_EMITTED;
-                    C.paths++;
-                    itsT = intersect_shape(S, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
-                    if (itsT < 0) {
-                        if (!S.hide_emitters) L = L + T * env;                         // volpath.cpp:194-201
-                        ev = EV_PATH_DONE;
-                    } else if (depth >= maxDepth && maxDepth != -1) ev = EV_PATH_DONE;
-                    else {
-                        (void) rng.next1D(); (void) rng.next1D();                      // null bsdf->sample(..., nextSample2D())
-                        const f3 ro = o + d * itsT;
-                        bool medium = true;
-                        if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
-                        else { itsT = intersect_shape(S, ro, d, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); if (!itsValid) medium = false; }
-                        depth++;
-                        if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
-                        else if (!medium) { if (!S.hide_emitters) L = L + T * env; ev = EV_PATH_DONE; }
-                        else { C.segments++; ps = ro; dsave = d; ev = W.begin(P, rng, C, K_FREE, ro, d, itsT); st = ST_MARCH; }
-                    }
-                }
-            }
-        } else if (st == ST_MARCH) {
-            ev = W.advance(P, rng, C);
-        }
-        wave_iters++;
-        if (st == ST_DONE) break;
-
-        // ------------------------------------------------------------------ events
-        while (ev != EV_NONE) {
-#ifdef MER_DEBUG
-            if (P.dbg_pixel == py_i * S.width + px_i && ev != EV_ARRIVED)
-                printf("gpu ev=%d kind=%d depth=%d T=%g L=%g Tr=%g trsum=%g walk=%d trv=%g t=%g tmax=%g rng=%llu\n", ev, W.kind, depth, T.x, L.x, W.Tr, W.trsum, W.walk, trv.x, W.t, W.tmax, (unsigned long long) rng.state);
-#endif
-            if (ev == EV_ARRIVED) {
-                ev = W.on_arrived(P, rng, C, sigma);
-            } else if (ev == EV_EXITED) {
-                ev = (W.kind == K_FREE) ? EV_FAIL : EV_WALK_END;
-            } else if (ev == EV_GATE_FAIL) {
-                if (W.kind == K_FREE) ev = EV_PATH_DONE;          // transmittance 0 => nothing further contributes
-                else { trv = f3(0, 0, 0); ev = EV_TR_DONE; }
-            } else if (ev == EV_WALK_END) {
-                W.trsum += W.Tr; W.walk++;
-                if (W.walk < nwalks) ev = W.begin(P, rng, C, W.kind, ps, W.kind == K_NEE ? dd : dsave, itsT, false);
-                else {
-                    if (SIGMA == MER_SIGMA_GRID) { const float tv = W.trsum / (float) nwalks; trv = f3(tv, tv, tv); }
-                    else trv = homogeneous_transmittance(P, -W.dist);                    // heterogeneousrefractive.cpp:393-400
-                    ev = EV_TR_DONE;
-                }
-            } else if (ev == EV_REAL) {
-                // ---- medium interaction: volpath.cpp:104-118
-                MRec m;
-                finish_free_flight(P, C, W, true, sigma, m);
-                bool success = true;
-                if (SIGMA == MER_SIGMA_HOMOGENEOUS) {
-                    const f3 o0 = ps;
-                    if (m.p.x == o0.x && m.p.y == o0.y && m.p.z == o0.z) success = false;   // no forward progress
-                }
-                if (!success) { ev = EV_FAIL; continue; }
-                C.real++;
-                if (depth >= maxDepth && maxDepth != -1) { ev = EV_PATH_DONE; continue; }
-                if (hasEmission && SIGMA == MER_SIGMA_GRID)
-                    L = L + T * f3(S.emission[0], S.emission[1], S.emission[2]) * m.refRatioSq;
-                T = T * (m.sigmaS * m.transmittance / m.pdfSuccess);
-                if (CURVED) T = T * m.refRatioSq;                                         // edge.cpp:91-93
-                wi = CURVED ? normalize(-m.d) : -W.v;                                     // vertex.cpp:251-255
-                ps = m.p;
-                if (hasEnv) {
-                    // ---- luminaire sampling: scene.cpp:854-874, constant.cpp:179-214
-                    C.nee++;
-                    const int interactions = maxDepth - depth - 1;
-                    const float s2x = rng.next1D(), s2y = rng.next1D();
-                    dd = square_to_uniform_sphere(s2x, s2y);
-                    W.kind = K_NEE;
-                    if (interactions != 0) {                                              // scene.cpp:619-678: one null crossing
-                        float tExit = 0.0f;
-                        if (!CURVED) tExit = intersect_shape(S, ps, dd, 0.0f, MER_INF);
-                        if (tExit >= 0) {
-                            itsT = tExit;
-                            ev = W.begin(P, rng, C, K_NEE, ps, dd, tExit);
-                            if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - tExit);
-                        } else { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
-                    } else { trv = f3(0, 0, 0); ev = EV_TR_DONE; }
-                } else ev = EV_PHASE;
-            } else if (ev == EV_TR_DONE) {
-                const f3 tr = trv;
-                if (W.kind == K_NEE) {
-                    const float dpdf = MER_INV_FOURPI;
-                    f3 value = env / dpdf;
-                    value = value * tr;
-                    if (!is_zero(value)) {
-                        const float phaseVal = phase_eval(S.phase, S.g, wi, dd);
-                        if (phaseVal != 0) {
-                            const float weight = mi_weight(dpdf, phaseVal);              // env emitter is "on surface": constant.cpp:47
-                            L = L + T * value * phaseVal * weight;
-                        }
-                    }
-                    ev = EV_PHASE;
-                } else {
-                    // emitter look-up along the phase-sampled direction: volpath.cpp:162-173,370-428
-                    const int maxInteractions = maxDepth - depth - 1;
-                    const bool blocked = (maxInteractions == 0) && (CURVED || itsValid);
-                    if (!blocked && !is_zero(tr)) {
-                        const f3 value = tr * env;
-                        L = L + T * value * mi_weight(phasePdf, MER_INV_FOURPI);
-                    }
-                    ev = EV_AFTER_LOOKUP;
-                }
-            } else if (ev == EV_PHASE) {
-                // ---- phase function sampling: volpath.cpp:149-160
-                const float p2x = rng.next1D(), p2y = rng.next1D();
-                f3 wo;
-                phase_sample(S.phase, S.g, wi, p2x, p2y, wo, phasePdf);
-                dsave = wo;
-                if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
-                else { itsT = intersect_shape(S, ps, wo, 0.0f, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
-                if (hasEnv) {
-                    W.kind = K_LOOKUP;
-                    if (!CURVED && !itsValid) { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
-                    else {
-                        ev = W.begin(P, rng, C, K_LOOKUP, ps, wo, itsT);
-                        if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - itsT);
-                    }
-                } else ev = EV_AFTER_LOOKUP;
-            } else if (ev == EV_AFTER_LOOKUP) {
-                SET_FLAG(F_EMITTED, false);                                               // ERadianceNoEmission
-                ev = EV_NONE;
-                if (depth++ >= S.rr_depth) {                                              // volpath.cpp:326-336
-                    const float q = fminf(max3(T) * 1.0f * 1.0f, 0.95f);
-                    if (rng.next1D() >= q) ev = EV_PATH_DONE;
-                    else T = T / q;
-                }
-                if (ev == EV_NONE) {
-                    SET_FLAG(F_SCATTERED, true);
-                    if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
-                    else { C.segments++; ev = W.begin(P, rng, C, K_FREE, ps, dsave, itsT); }
-                }
-            } else if (ev == EV_FAIL) {
-                // ---- no medium interaction: volpath.cpp:183-201,289-301
-                MRec m;
-                finish_free_flight(P, C, W, false, 0.0f, m);
-                T = T * (m.transmittance / m.pdfFailure);
-                if (CURVED) { T = T * m.refRatioSq; SET_FLAG(F_ITSVALID, true); }         // edge.cpp:45-60
-                ev = EV_PATH_DONE;
-                if (!itsValid) {
-                    if (emitted && (!S.hide_emitters || scattered)) L = L + T * env;
-                } else if (!(depth >= maxDepth && maxDepth != -1)) {
-                    (void) rng.next1D(); (void) rng.next1D();                             // null BSDF sample
-                    SET_FLAG(F_EMITTED, !scattered);
-                    depth++;
-                    if (depth <= maxDepth || maxDepth < 0)
-                        if (emitted && (!S.hide_emitters || scattered)) L = L + T * env;
-                }
-            } else {  // EV_PATH_DONE: ImageBlock::put (imageblock.h:124-205)
-                if (P.path_out) {
-                    float *q = P.path_out + ((size_t) py_i * S.width + px_i) * 3;
-                    q[0] = L.x; q[1] = L.y; q[2] = L.z;
-                } else film_put(P, px, py, L, 1.0f);
-                st = ST_NEW;
-                ev = EV_NONE;
-            }
-        }
-    }
-#undef scattered
-#undef emitted
-#undef itsValid
-#undef SET_FLAG
-    // ---- counters (StatsCounter analogue; inputs of the roofline formula)
-    const uint32_t sums[8] = {wave_sum(C.paths), wave_sum(C.steps), wave_sum(C.rif_evals), wave_sum(C.tentative),
-                              wave_sum(C.real), wave_sum(C.segments), wave_sum(C.nee), wave_sum(C.marched)};
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int i = 0; i < 7; i++) if (sums[i]) atomicAdd(P.counters + i, (unsigned long long) sums[i]);
-        atomicAdd(P.counters + MER_C_LOOP_ITERS, (unsigned long long) wave_iters * 64ULL);
-        atomicAdd(P.counters + MER_C_ACTIVE_LANES, (unsigned long long) sums[7]);
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // Leaf kernels (parity entry points).  One thread per item; divergence is irrelevant here.

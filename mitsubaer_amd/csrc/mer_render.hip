@@ -1,0 +1,224 @@
+// mer_render.hip -- host loop of the wavefront render: K_gen, K_event, [K_connect,] K_march passes over the path-state slots until no
+// lane is alive.  The kernels themselves are instantiated in mer_render_<group>.hip (compiled in parallel); this file picks the
+// group's function pointers and launches them.
+//
+// The passes of ONE pipeline are a chain of dependent launches, and K_event -- fat, 2 waves per SIMD -- leaves most of the chip idle
+// while it runs.  So a render is cut into `pipes` independent pipelines: pipeline q takes the sample indices q, q + pipes, ... of the
+// shard (the sharding contract of SURVEY section 8e, applied inside one GPU), has its own slots, lists, hit ring and work counter, and
+// runs on its own stream; the film is shared (atomics).  One pipeline's K_event then overlaps the others' K_march.  Per-path results do
+// not depend on the number of pipelines.
+#include "mer_internal.hpp"
+#include "mer_wavefront.hpp"
+
+namespace mer {
+
+static bool pick_kernels(mer_context *ctx, const mer_scene_desc *sc, bool extra, KernelSet &k) {
+    const bool curved = sc->rif_mode != MER_RIF_CONST;
+    const int sigma = sc->sigma_mode == MER_SIGMA_GRID ? MER_SIGMA_GRID : MER_SIGMA_HOMOGENEOUS;
+    const int bnd = sc->boundary == MER_BOUNDARY_SDF ? 1 : 0;
+    if (!curved) return kernels_straight(sigma, bnd, extra, k);
+    const int rifk = rif_fetch_kind(ctx, sc);
+    if (bnd) return kernels_sdf_curved(rifk, sc->stepper, sigma, k);
+    switch (rifk) {
+    case RIFK_ACOUSTIC: return kernels_acoustic(sc->stepper, sigma, extra, k);
+    case MER_RIF_TRILINEAR: case RIFK_DENSE_BUF: return kernels_dense(rifk, sc->stepper, sigma, extra, k);
+    case RIFK_CELL8: case RIFK_CELL8_BUF: return kernels_cell8(rifk, sc->stepper, sigma, extra, k);
+    case RIFK_BRICK27: case RIFK_BRICK27_BUF: return kernels_brick(rifk, sc->stepper, sigma, extra, k);
+    case MER_RIF_BSPLINE3: return kernels_bspline(sc->stepper, sigma, extra, k);
+    }
+    return false;
+}
+
+int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed, float *film_dev, float *path_out_dev,
+                  uint64_t n_film, uint64_t n_path_out) {
+    Params P;
+    if (make_params(ctx, scene, P, true)) return 1;
+    if (!shard || shard->spp_count < 0 || shard->spp_stride <= 0 || shard->tile_count <= 0 || shard->tile_rank < 0 ||
+        shard->tile_rank >= shard->tile_count || shard->spp_begin < 0)
+        return fail(ctx, "invalid shard");
+    const Options &opt = ctx->opt;
+    P.seed = seed;
+    P.spp_begin = shard->spp_begin; P.spp_count = shard->spp_count; P.spp_stride = shard->spp_stride;
+    P.tile_rank = shard->tile_rank; P.tile_count = shard->tile_count;
+    P.tiles_x = (scene->width + MER_TILE - 1) / MER_TILE; P.tiles_y = (scene->height + MER_TILE - 1) / MER_TILE;
+    const int ntiles = P.tiles_x * P.tiles_y;
+    P.ntiles_mine = (ntiles - shard->tile_rank + shard->tile_count - 1) / shard->tile_count;
+    P.total_work = (uint64_t) P.ntiles_mine * MER_TILE * MER_TILE * (uint64_t) shard->spp_count;
+    P.film = film_dev; P.path_out = path_out_dev; P.n_film = n_film; P.n_path_out = n_path_out;
+    HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (P.total_work == 0) return 0;
+
+    const bool has_point = scene->point_intensity[0] != 0 || scene->point_intensity[1] != 0 || scene->point_intensity[2] != 0;
+    const bool curved = scene->rif_mode != MER_RIF_CONST;
+    // EXTRA kernels carry the point emitter, the modulated film and the dielectric boundary; the signed-distance boundary exists in
+    // the EXTRA kernels only
+    const bool extra = scene->boundary == MER_BOUNDARY_SDF || has_point || scene->modulation != MER_MODULATION_NONE || scene->boundary_bsdf != MER_BSDF_NULL;
+    KernelSet ks{};
+    if (!pick_kernels(ctx, scene, extra, ks)) {
+        if (scene->boundary == MER_BOUNDARY_SDF && curved) return fail(ctx, "signed-distance boundary: the RIF must be dense, cell8 below 4 GiB, or a B-spline volume");
+        return fail(ctx, "unsupported rif_mode / stepper combination");
+    }
+    const bool connect_stage = has_point && curved;
+
+    int npipes = (int) opt.pipes;
+    if (shard->spp_count < npipes) npipes = std::max(1, shard->spp_count);
+    uint32_t want = opt.nslots > 0 ? (uint32_t) opt.nslots : (uint32_t) ctx->prop.multiProcessorCount * 2048u * 4u;   // 4 x the resident lanes of the chip, over all pipelines
+    want = (want / (uint32_t) npipes + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;       // per pipeline
+    const int ksteps0 = (int) opt.ksteps;
+    // sorting the march lists by exit time scatters the lanes of a wave over the volume: a gain while the RIF sits near the caches
+    // (256^3: +8 %, 512^3: +3 %), a loss once every fetch goes to HBM (1024^3: -4 %)
+    P.mq_sort = opt.mq_sort >= 0 ? (opt.mq_sort != 0) : ((int64_t) P.rif.res[0] * P.rif.res[1] * P.rif.res[2] <= ((int64_t) 1 << 28) ? 1 : 0);
+    P.gen_iters = 8; P.gen_all = opt.gen_all ? 1 : 0;
+    // Connection requests gather in one row of cq over connect_every passes (the parked slots wait, the others keep marching) and
+    // K_connect drains the row at the end of the group: fuller launches, 5-8 % on configs[4]; in the tail it runs every pass.
+    const int connect_every0 = (int) opt.connect_every;
+    // K_gen: one launch = gen_blocks x 4 waves x 64 x gen_iters work ids
+    const unsigned gen_blocks_max = std::max(1u, std::min(want / MER_BLOCK, 1024u));
+    const unsigned long long ids_per_launch = (unsigned long long) gen_blocks_max * (MER_BLOCK / 64) * 64ull * (unsigned long long) P.gen_iters;
+
+    Run runs[MER_MAX_PIPES];
+    HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int q = 0; q < npipes; q++) {
+        Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
+        if (q == 0) pp.stream = ctx->stream;
+        else if (!pp.own_stream) { HIP_CHECK(ctx, hipStreamCreateWithFlags(&pp.own_stream, hipStreamNonBlocking)); }
+        if (q > 0) { pp.stream = pp.own_stream; HIP_CHECK(ctx, hipStreamWaitEvent(pp.stream, ctx->ev0, 0)); }   // after what the caller queued (film zeroing ...)
+        // The hit ring holds what K_gen's throttle lets wait (cap / 2: a wave produces while at most that many ids are waiting) plus,
+        // in the worst case, every id of ONE launch (all its waves read the tail before any of them pushes, and every camera sample
+        // may hit the medium): capacity >= 2 x max(slots, ids per launch), or unread ids would be overwritten.
+        unsigned long long ring = 1; while (ring < 2ull * std::max<unsigned long long>(want, ids_per_launch)) ring <<= 1;
+        if (pp.nslots < want || pp.hitq_cap < ring) {                 // capacity: grows, never shrinks
+            const uint32_t cap = std::max(want, pp.nslots);
+            if (pp.slots) (void) hipFree(pp.slots);
+            if (pp.hitq) (void) hipFree(pp.hitq);
+            pp.slots = nullptr; pp.hitq = nullptr; pp.nslots = 0;
+            HIP_CHECK(ctx, hipMalloc((void **) &pp.slots, (size_t) cap * MER_SLOT_WORDS * sizeof(uint32_t)));
+            for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq}) {
+                if (sq->items) (void) hipFree(sq->items);
+                sq->items = nullptr;
+                sq->segcap = 2u * (cap / MER_NSEG) + 256u;          // two producer kernels may feed one segment
+                if (sq == &pp.eq) sq->segcap = 2u * (cap / (MER_NSEG / MER_EV_CLASSES)) + 256u;   // every lane may be of one event class
+                if (sq == &pp.mq[0] || sq == &pp.mq[1]) sq->segcap = 2u * (cap / (MER_NSEG / MER_MQ_CLASSES)) + 256u;   // ... or of one march class
+                if (sq == &pp.cq) sq->segcap = cap + 256u;   // requests gather over several passes: a segment may see every slot once
+                HIP_CHECK(ctx, hipMalloc((void **) &sq->items, (size_t) sq->segcap * MER_NSEG * sizeof(uint32_t)));
+                if (!sq->counts) HIP_CHECK(ctx, hipMalloc((void **) &sq->counts, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t)));
+                sq->chk = ctx->chk;
+            }
+            pp.hitq_cap = std::max(ring, pp.hitq_cap);
+            HIP_CHECK(ctx, hipMalloc((void **) &pp.hitq, (size_t) pp.hitq_cap * sizeof(unsigned long long)));
+            pp.nslots = cap;
+        }
+        if (!pp.live) {
+            HIP_CHECK(ctx, hipMalloc((void **) &pp.live, MER_LIVE_SLOTS * sizeof(uint32_t)));
+            HIP_CHECK(ctx, hipHostMalloc((void **) &pp.host_live, 8 * sizeof(uint32_t)));
+            HIP_CHECK(ctx, hipMalloc((void **) &pp.hitq_ctr, 64 * sizeof(unsigned long long)));       // [0] tail, [32] head, [48] this pipeline's work counter
+            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.readback[0], hipEventDisableTiming));
+            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.readback[1], hipEventDisableTiming));
+            HIP_CHECK(ctx, hipEventCreateWithFlags(&pp.finished, hipEventDisableTiming));
+        }
+        // pipeline q's part of the shard: sample indices spp_begin + (q + k npipes) spp_stride
+        R.P = P;
+        R.P.spp_begin = shard->spp_begin + q * shard->spp_stride; R.P.spp_stride = shard->spp_stride * npipes;
+        R.P.spp_count = (shard->spp_count - q + npipes - 1) / npipes;
+        R.P.total_work = (uint64_t) P.ntiles_mine * MER_TILE * MER_TILE * (uint64_t) R.P.spp_count;
+        R.nslots = want;
+        const uint64_t need_slots = (R.P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
+        if (need_slots < R.nslots) R.nslots = (uint32_t) need_slots;
+        R.P.slots = pp.slots; R.P.nslots = R.nslots; R.P.live = pp.live; R.P.eq = pp.eq; R.P.mq[0] = pp.mq[0]; R.P.mq[1] = pp.mq[1];
+        R.P.sq[0] = pp.sq[0]; R.P.sq[1] = pp.sq[1]; R.P.cq = pp.cq;
+        R.P.hitq = pp.hitq; R.P.hitq_cap = pp.hitq_cap; R.P.hitq_ctr = pp.hitq_ctr; R.P.work_counter = pp.hitq_ctr + 48;
+        R.P.ksteps = ksteps0; R.P.cq_row = 0;
+        R.connect_every = connect_every0;
+        R.done = R.P.total_work == 0;
+        if (R.done) continue;
+        R.blocks = R.nslots / MER_BLOCK;
+        R.gen_blocks = std::max(1u, std::min(R.nslots / MER_BLOCK, gen_blocks_max));
+        HIP_CHECK(ctx, hipMemsetAsync(pp.slots, 0, (size_t) R.nslots * MER_SLOT_WORDS * sizeof(uint32_t), pp.stream));
+        HIP_CHECK(ctx, hipMemsetAsync(pp.live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), pp.stream));
+        for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq})
+            HIP_CHECK(ctx, hipMemsetAsync(sq->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), pp.stream));
+        HIP_CHECK(ctx, hipMemsetAsync(pp.hitq_ctr, 0, 64 * sizeof(unsigned long long), pp.stream));
+    }
+
+    const uint32_t check_every = 8;
+    const bool adaptive = opt.adaptive_k != 0;
+    const bool pass_events = opt.pass_events != 0;          // per-kernel timing of every pass (mer_last_render_stats)
+    // one batch = check_every passes of a pipeline followed by the read-back of its finished-slot count into slot `rb`.  Two batches
+    // are kept in flight per pipeline, so that a pipeline never runs dry while the host waits for another one's read-back (a
+    // finished render thus carries one batch of empty passes: ~0.5 ms)
+    auto enqueue_batch = [&](int q, int rb) -> int {
+        Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
+        for (uint32_t b = 0; b < check_every; b++) {
+            const uint32_t pass = R.pass;
+            while (pp.pass_events.size() < (size_t) (pass + 1) * 3) {
+                hipEvent_t e; HIP_CHECK(ctx, hipEventCreate(&e)); pp.pass_events.push_back(e);
+            }
+            if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 0], pp.stream));
+            for (int g = 0; R.work_left && g < (pass == 0 ? 6 : 1); g++) hipLaunchKernelGGL(ks.gen, dim3(R.gen_blocks), dim3(MER_BLOCK), 0, pp.stream, R.P);
+            hipLaunchKernelGGL(ks.event, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+            if (connect_stage && ++R.since_connect >= (uint32_t) R.connect_every) {
+                hipLaunchKernelGGL(ks.connect, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+                R.since_connect = 0; R.P.cq_row++;
+            }
+            if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 1], pp.stream));
+            hipLaunchKernelGGL(ks.march, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+            if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 2], pp.stream));
+            R.pass++;
+        }
+        HIP_CHECK(ctx, hipGetLastError());
+        HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 4 * rb, pp.live, sizeof(uint32_t), hipMemcpyDeviceToHost, pp.stream));
+        HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 4 * rb + 2, R.P.work_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, pp.stream));
+        HIP_CHECK(ctx, hipEventRecord(pp.readback[rb], pp.stream));
+        return 0;
+    };
+    for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q, 0)) return 1;
+    for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q, 1)) return 1;
+    for (;;) {
+        bool any = false;
+        for (int q = 0; q < npipes; q++) {
+            Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
+            if (R.done) continue;
+            any = true;
+            const int rb = R.cur; R.cur ^= 1;
+            HIP_CHECK(ctx, hipEventSynchronize(pp.readback[rb]));
+            const uint32_t finished_slots = pp.host_live[4 * rb];
+            if (finished_slots >= R.nslots) { R.done = true; continue; }
+            R.work_left = *(unsigned long long *) (pp.host_live + 4 * rb + 2) < R.P.total_work;
+            if (adaptive) {          // tail: few lanes left => longer passes, fewer launches
+                const uint32_t alive = R.nslots - finished_slots;
+                R.P.ksteps = alive < R.nslots / 64 ? ksteps0 * 32 : (alive < R.nslots / 16 ? ksteps0 * 8 : (alive < R.nslots / 4 ? ksteps0 * 2 : ksteps0));
+                R.connect_every = alive < R.nslots / 4 ? 1 : connect_every0;
+            }
+            if (R.pass > (1u << 24)) return fail(ctx, "mer_render: pass limit exceeded");
+            if (enqueue_batch(q, rb)) return 1;
+        }
+        if (!any) break;
+    }
+    // join: the caller's stream continues after every pipeline
+    for (int q = 1; q < npipes; q++) {
+        if (runs[q].pass == 0) continue;
+        HIP_CHECK(ctx, hipEventRecord(ctx->pipes[q].finished, ctx->pipes[q].stream));
+        HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, ctx->pipes[q].finished, 0));
+    }
+    HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    {   // per-kernel device time of this render, from HIP events on the launch streams (summed over the pipelines: with several of
+        // them running side by side the sum exceeds the wall time)
+        HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+        double em = 0, mm = 0; uint32_t passes = 0;
+        for (int q = 0; q < npipes; q++) {
+            for (uint32_t k = 0; pass_events && k < runs[q].pass; k++) {
+                float a = 0, b = 0;
+                (void) hipEventElapsedTime(&a, ctx->pipes[q].pass_events[k * 3 + 0], ctx->pipes[q].pass_events[k * 3 + 1]);
+                (void) hipEventElapsedTime(&b, ctx->pipes[q].pass_events[k * 3 + 1], ctx->pipes[q].pass_events[k * 3 + 2]);
+                em += a; mm += b;
+            }
+            passes += runs[q].pass;
+        }
+        ctx->last_event_ms = (float) em; ctx->last_march_ms = (float) mm; ctx->last_passes = (int) passes; ctx->last_pipes = npipes;
+    }
+    if (opt.verbose) { float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1); fprintf(stderr, "[mer] wavefront: %d pipelines, %u + %u passes, K=%d, nslots=%u each, %.3f ms\n", npipes, runs[0].pass, npipes > 1 ? runs[1].pass : 0u, ksteps0, runs[0].nslots, ms); }
+    return 0;
+}
+
+}  // namespace mer

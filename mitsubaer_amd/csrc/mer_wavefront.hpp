@@ -36,12 +36,12 @@ __device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg
 #ifndef MER_WORK_BATCH
 #define MER_WORK_BATCH 8
 #endif
-#define SLOT(k) P.slots[(size_t) i * MER_SLOT_WORDS + (k)]
+#define SLOT(k) P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots) * MER_SLOT_WORDS + (k)]
 #define SLOTF(k) __uint_as_float(SLOT(k))
 
 template <class WalkT>
 __device__ __forceinline__ void load_hot(const Params &P, uint32_t i, uint32_t &fl, WalkT &W, Rng &rng, uint32_t &pixel, uint32_t &sample, float &sigma) {
-    const uint4 *r = (const uint4 *) (P.slots + (size_t) i * MER_SLOT_WORDS);
+    const uint4 *r = (const uint4 *) (P.slots + (size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots) * MER_SLOT_WORDS);
     const uint4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4];
     W.p = f3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
     W.v = f3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
@@ -57,7 +57,7 @@ __device__ __forceinline__ void load_hot(const Params &P, uint32_t i, uint32_t &
 template <class WalkT>
 __device__ __forceinline__ void store_hot(const Params &P, uint32_t i, int st, int ev, const WalkT &W, const Rng &rng,
                                           uint32_t pixel, uint32_t sample, float sigma) {
-    uint4 *r = (uint4 *) (P.slots + (size_t) i * MER_SLOT_WORDS);
+    uint4 *r = (uint4 *) (P.slots + (size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots) * MER_SLOT_WORDS);
     r[0] = make_uint4(__float_as_uint(W.p.x), __float_as_uint(W.p.y), __float_as_uint(W.p.z), __float_as_uint(W.v.x));
     r[1] = make_uint4(__float_as_uint(W.v.y), __float_as_uint(W.v.z), __float_as_uint(W.opt), __float_as_uint(W.dist));
     r[2] = make_uint4(__float_as_uint(W.rem), __float_as_uint(W.hprev), __float_as_uint(W.Tr), __float_as_uint(W.t));
@@ -70,7 +70,6 @@ __device__ __forceinline__ void store_hot(const Params &P, uint32_t i, int st, i
 // Counter flush: one set of atomics per wave, spread over MER_COUNTER_REPLICAS copies (summed on the host) so that a
 // pass of thousands of waves does not serialise on nine addresses (one word sustains ~88 atomics/us).  No barrier:
 // a wave that is done must not wait for its block mates while holding registers.
-#define MER_COUNTER_REPLICAS 64
 __device__ __forceinline__ void flush_counters(const Params &P, const LaneCounters &C, uint32_t lane_slots) {
     const uint32_t sums[9] = {wave_sum(C.paths), wave_sum(C.steps), wave_sum(C.rif_evals), wave_sum(C.tentative),
                               wave_sum(C.real), wave_sum(C.segments), wave_sum(C.nee), wave_sum(C.marched), wave_sum(lane_slots)};
@@ -136,7 +135,7 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
                 }
                 if (!hit) {
                     C.paths++;
-                    if (P.path_out) { const f3 Lm = mod_weight<EXTRA>(P, L, plen); float *q = P.path_out + ((size_t) y * S.width + x) * 3; q[0] = Lm.x; q[1] = Lm.y; q[2] = Lm.z; }
+                    if (P.path_out) { const f3 Lm = mod_weight<EXTRA>(P, L, plen); float *q = P.path_out + MER_CHK(P.chk, CHK_PATHOUT, ((size_t) y * S.width + x) * 3, P.n_path_out - 2); q[0] = Lm.x; q[1] = Lm.y; q[2] = Lm.z; }
                     else { film_contribute(P, px, py, L, plen); film_put(P, px, py, mod_weight<EXTRA>(P, L, plen), 1.0f); }
                 }
             }
@@ -148,6 +147,8 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
             unsigned long long base = 0;
             if (lane == leader) base = atomicAdd(P.hitq_ctr, (unsigned long long) __popcll(mask));
             base = ((unsigned long long) (uint32_t) __shfl((int) (base >> 32), leader, 64) << 32) | (uint32_t) __shfl((int) (uint32_t) base, leader, 64);
+            // ring occupancy: launch_render sizes the ring for cap/2 (the throttle) + every id one launch can produce
+            (void) MER_CHK(P.chk, CHK_HITQ, base + (unsigned long long) __popcll(mask) - min(base, P.hitq_ctr[MER_HITQ_HEAD]), P.hitq_cap + 1);
             if (hit) P.hitq[(base + (unsigned long long) __popcll(mask & ((1ULL << lane) - 1ULL))) & (P.hitq_cap - 1)] = w;
         }
         if (wave_base + (unsigned long long) (it + 1) * 64ULL >= P.total_work) break;
@@ -168,7 +169,7 @@ __device__ __forceinline__ void queue_push(const SegQueue &q, uint32_t row, bool
         uint32_t base = 0;
         if (lane == leader) base = atomicAdd(q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG + seg, (uint32_t) __popcll(mask));
         base = (uint32_t) __shfl((int) base, leader, 64);
-        if (pred) q.items[(size_t) seg * q.segcap + base + (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL))] = i;
+        if (pred) q.items[(size_t) seg * q.segcap + MER_CHK(q.chk, CHK_QUEUE_SEG, base + (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL)), q.segcap)] = i;
     }
 }
 // Class-sorted lists: the same segments, grouped by a class of the item (MER_NSEG / NCLS segments per class), so that the
@@ -199,7 +200,7 @@ __device__ __forceinline__ void queue_push_class(const SegQueue &q, uint32_t row
         if (lane < NCLS && lane_mask)
             base = atomicAdd(q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG + (uint32_t) lane * SPC + (wave & (SPC - 1)), (uint32_t) __popcll(lane_mask));
         base = (uint32_t) __shfl((int) base, c, 64);
-        if (pred) q.items[(size_t) ((uint32_t) c * SPC + (wave & (SPC - 1))) * q.segcap + base + (uint32_t) __popcll(mine & ((1ULL << lane) - 1ULL))] = i;
+        if (pred) q.items[(size_t) ((uint32_t) c * SPC + (wave & (SPC - 1))) * q.segcap + MER_CHK(q.chk, CHK_QUEUE_SEG, base + (uint32_t) __popcll(mine & ((1ULL << lane) - 1ULL)), q.segcap)] = i;
     }
 }
 // Class of a marching lane: 0 = at least one whole pass (ksteps trips) left before the ray can leave the shape, 1 .. 7 = sevenths
@@ -243,7 +244,7 @@ __device__ __forceinline__ uint32_t queue_item(const SegQueue &q, uint32_t row, 
     uint32_t seg = 0, off = j;
 #pragma unroll
     for (int s = 0; s < MER_NSEG - 1; s++) { const uint32_t n = c[s]; if (seg == (uint32_t) s && off >= n) { off -= n; seg = s + 1; } }
-    return q.items[(size_t) seg * q.segcap + off];
+    return q.items[(size_t) seg * q.segcap + MER_CHK(q.chk, CHK_QUEUE_ITEM, off, q.segcap)];
 }
 __device__ __forceinline__ void queue_clear_row(const SegQueue &q, uint32_t row, uint32_t j) {
     if (j < MER_NSEG) q.counts[(size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG + j] = 0;
@@ -612,7 +613,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             }
         } else {  // EV_PATH_DONE: ImageBlock::put (imageblock.h:124-205)
             if (P.path_out) {
-                float *q = P.path_out + ((size_t) py_i * S.width + px_i) * 3;
+                float *q = P.path_out + MER_CHK(P.chk, CHK_PATHOUT, ((size_t) py_i * S.width + px_i) * 3, P.n_path_out - 2);
                 q[0] = L.x; q[1] = L.y; q[2] = L.z;
             } else film_put(P, px, py, L, 1.0f);
             st = ST_NEW;

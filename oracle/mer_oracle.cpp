@@ -966,6 +966,8 @@ template <typename FLOAT> struct M33 {
     }
 };
 
+template <typename FLOAT> inline bool finite3(const V3<FLOAT> &a) { return std::isfinite(a.x) && std::isfinite(a.y) && std::isfinite(a.z); }
+
 template <typename FLOAT> struct Connector {
     const Scene &S; const Rif<FLOAT> &R; Counters &C; Pcg32 &rng;
     FLOAT tol, rrweight; int precision, maxIter;
@@ -997,6 +999,8 @@ template <typename FLOAT> struct Connector {
     bool computefdf(const V3<FLOAT> &v_i, const V3<FLOAT> &p1, const V3<FLOAT> &p2, V3<FLOAT> &error, M33<FLOAT> &J) const {
         M33<FLOAT> dpdv0((FLOAT) 0), dvdv0((FLOAT) 1);
         error = p1 - p2; J = M33<FLOAT>((FLOAT) 0);
+        /* a shooting direction that is not a finite non-zero vector has no ray (the stand-in solver's step can overflow: guard, not reference) */
+        if (!finite3(v_i) || !(dot(v_i, v_i) > 0) || !std::isfinite(dot(v_i, v_i))) return false;
         if (!R.insideVolumeLimits(p1)) return false;
         FLOAT h = (FLOAT) S.s.stepsize;
         long nBisect = (long) std::ceil(precision / std::log10(2.0));
@@ -1012,6 +1016,7 @@ template <typename FLOAT> struct Connector {
         for (int i = 0; i < ms; i++) {
             oldp = p; oldv = v; olddp = dpdv0; olddv = dvdv0;
             er_derivativestep(p, v, dpdv0, dvdv0, h);
+            if (!finite3(p) || !finite3(v)) return false;
             signNew = std::signbit(dot(p - p2, v));
             if (signNew != signOld) {
                 while (nBisect > 0) {
@@ -1040,6 +1045,11 @@ template <typename FLOAT> struct Connector {
         V3<FLOAT> e; M33<FLOAT> J;
         bool ok = computefdf(x, p1, p2, e, J);
         FLOAT cost = (FLOAT) 0.5 * dot(e, e), lambda = (FLOAT) 1e-4;
+        /* computefdf rescales its argument to |v0| = n(p1): the residual does not depend on |x|, J^T J is singular along x and only the
+           damping makes the step finite.  The unknown lives on the sphere |x| = n(p1): every trial iterate is put back on it, and a
+           step whose determinant is below float resolution of the product of the pivots, or that is not finite, is retried with
+           more damping (same rule on the GPU: mer_connect.hpp). */
+        const FLOAT radius = std::sqrt(dot(x, x));
         for (int it = 0; it < maxIter && ok && cost >= tol * (FLOAT) 1e-3; ++it) {
             /* (J^T J + lambda I) d = -J^T e */
             FLOAT A[3][3], b[3];
@@ -1051,12 +1061,15 @@ template <typename FLOAT> struct Connector {
                 FLOAT M[3][3]; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = A[i][j] + (i == j ? lambda * (A[i][i] + (FLOAT) 1e-12) : 0);
                 const FLOAT det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
                                   M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
-                if (det == 0 || !std::isfinite(det)) { lambda *= 10; continue; }
+                if (!(std::fabs(det) > (FLOAT) 1e-6f * std::fabs(M[0][0] * M[1][1] * M[2][2])) || !std::isfinite(det)) { lambda *= 10; continue; }
                 FLOAT d[3];
                 d[0] = (b[0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (b[1] * M[2][2] - M[1][2] * b[2]) + M[0][2] * (b[1] * M[2][1] - M[1][1] * b[2])) / det;
                 d[1] = (M[0][0] * (b[1] * M[2][2] - M[1][2] * b[2]) - b[0] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * b[2] - b[1] * M[2][0])) / det;
                 d[2] = (M[0][0] * (M[1][1] * b[2] - b[1] * M[2][1]) - M[0][1] * (M[1][0] * b[2] - b[1] * M[2][0]) + b[0] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
                 V3<FLOAT> xn(x.x + d[0], x.y + d[1], x.z + d[2]), en; M33<FLOAT> Jn;
+                const FLOAT ln = std::sqrt(dot(xn, xn));
+                if (!(ln > 0) || !std::isfinite(ln)) { lambda *= 10; continue; }
+                xn = xn * (radius / ln);
                 const bool okn = computefdf(xn, p1, p2, en, Jn);
                 const FLOAT cn = (FLOAT) 0.5 * dot(en, en);
                 if (okn && cn < cost) { x = xn; e = en; J = Jn; cost = cn; lambda = std::max(lambda * (FLOAT) 0.1, (FLOAT) 1e-9); improved = true; }
@@ -1080,6 +1093,7 @@ template <typename FLOAT> struct Connector {
         for (int i = 0; i < ms; i++) {
             oldp = p; oldv = v;
             T.er_step_verlet(p, v, h, dummy);
+            if (!finite3(p) || !finite3(v)) return false;
             signNew = std::signbit(dot(p - p2, v));
             if (!S.insideShape(p)) return false;
             if (signNew != signOld) {

@@ -14,7 +14,7 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """The built libraries are git-ignored: on a fresh checkout compile them first (hipcc cross-compiles gfx950 without a GPU;
     the same thing __graft_entry__.build() does).  A failed build is reported by the tests that need the library."""
-    need = [os.path.join(ROOT, "mitsubaer_amd", "libmer.so"), os.path.join(ROOT, "mitsubaer_amd", "libmer_host.so"),
+    need = [os.path.join(ROOT, "mitsubaer_amd", "libmer.so"), os.path.join(ROOT, "mitsubaer_amd", "libmer_check.so"), os.path.join(ROOT, "mitsubaer_amd", "libmer_host.so"),
             os.path.join(ROOT, "oracle", "libmer_oracle.so")]
     if not all(os.path.exists(f) for f in need):
         try:

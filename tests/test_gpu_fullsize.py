@@ -93,11 +93,10 @@ def test_cfg3_linearity_sorting_and_pass_length_change_no_path(ctx, fields, monk
     sc.env_radiance[:] = [1.0, 1.0, 1.0]
     assert np.array_equal(ctx.render_paths(sc, 3, seed=7), a)                       # determinism
     assert not np.array_equal(ctx.render_paths(sc, 4, seed=7), a)                   # another sample index: other paths
-    monkeypatch.setenv("MER_MQ_SORT", "0")
-    assert np.array_equal(ctx.render_paths(sc, 3, seed=7), a)
-    monkeypatch.setenv("MER_KSTEPS", "37")
-    assert np.array_equal(ctx.render_paths(sc, 3, seed=7), a)
-    monkeypatch.delenv("MER_MQ_SORT"); monkeypatch.delenv("MER_KSTEPS")
+    with ctx.options(mq_sort=0):
+        assert np.array_equal(ctx.render_paths(sc, 3, seed=7), a)
+        with ctx.options(ksteps=37):
+            assert np.array_equal(ctx.render_paths(sc, 3, seed=7), a)
     sd, vd = ctx.upload_scene(p, layout=capi.LAYOUT_DENSE)
     assert np.array_equal(ctx.render_paths(sd, 3, seed=7), a)
     for v in vols + vd:

@@ -67,8 +67,8 @@ def test_bspline_parallel_prefilter_matches_sequential_and_oracle(ctx, orc, shap
     rng = np.random.RandomState(7)
     data = (1.3 + 0.3 * rng.rand(*shape)).astype(np.float32)
     par = ctx.upload_volume(data, [-1] * 3, [1] * 3).build_spline().download_spline()
-    monkeypatch.setenv("MER_PREFILTER_SEQ", "1")
-    seq = ctx.upload_volume(data, [-1] * 3, [1] * 3).build_spline().download_spline()
+    with ctx.options(prefilter=1):
+        seq = ctx.upload_volume(data, [-1] * 3, [1] * 3).build_spline().download_spline()
     assert np.abs(par - seq).max() < 2e-6               # same recursion per sample; only the truncated warm-up differs
     assert np.abs(par - orc.bspline_build(data)).max() < 5e-6
 
@@ -198,16 +198,21 @@ def test_eval_transmittance(ctx, orc, est, curved):
     assert abs(a.mean() - b.mean()) < 5e-3
 
 
-@pytest.mark.parametrize("kind", ["bspline", "trilinear"])
+@pytest.mark.parametrize("kind", ["bspline", "trilinear", "trilinear_sdf"])
 def test_curved_ray_connection(ctx, orc, kind):
     """A12: the shooting solver finds the optical momentum at p1 whose eikonal ray passes through p2.  Parity with the
     reference's Ceres iterates is unpinned; pinned here: the converged ray (direction, length, optical
     length) against the oracle's solver, and the physical property itself -- tracing the found ray lands on p2."""
     p = scenes.bspline_scene(N=24) if kind == "bspline" else scenes.curved_scene(N=24, rif="radial", stepper=P.STEP_VERLET)
+    if kind == "trilinear_sdf":         # the medium shape as a signed-distance grid (K_connect's BND = 1 code, global loads)
+        from mitsubaer_amd import synth
+        box = ([-1.2] * 3, [1.2] * 3)
+        p = p.copy(boundary=P.BOUNDARY_SDF, sdf=-synth.sphere_sdf(64, radius=0.9, aabb_min=box[0], aabb_max=box[1]), sdf_aabb=box)
     sc, vols = ctx.upload_scene(p)
     rng = np.random.RandomState(0)
     n = 512
-    p1 = rng.uniform(-0.6, 0.6, (n, 3)).astype(np.float32); p2 = rng.uniform(-0.6, 0.6, (n, 3)).astype(np.float32)
+    lim = 0.45 if kind == "trilinear_sdf" else 0.6
+    p1 = rng.uniform(-lim, lim, (n, 3)).astype(np.float32); p2 = rng.uniform(-lim, lim, (n, 3)).astype(np.float32)
     a = ctx.connect(sc, p1, p2, 1)
     b = orc.connect(p, p1, p2, 1)
     ok = (a[:, 0] == 1) & (b[:, 0] == 1)
@@ -225,5 +230,5 @@ def test_curved_ray_connection(ctx, orc, kind):
     # curved, not straight: the arc is longer than the chord and the launch direction differs from it
     chord = np.linalg.norm(p2[ok] - p1[ok], axis=1)
     assert (a[ok, 8] >= chord - 5e-3).all()                      # h = 0.043 here; closest approach within sqrt(2 tol2) of p2
-    n1, _ = ctx.rif_value_grad(vols[-1], P.RIF_BSPLINE3 if kind == "bspline" else P.RIF_TRILINEAR, p1[ok])
+    n1, _ = ctx.rif_value_grad([v for v in vols if v is not None][1 if kind == "trilinear_sdf" else -1], P.RIF_BSPLINE3 if kind == "bspline" else P.RIF_TRILINEAR, p1[ok])
     assert np.abs(np.linalg.norm(a[ok, 2:5], axis=1) - n1).max() < 1e-4       # |v0| = n(p1)

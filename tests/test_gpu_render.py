@@ -67,6 +67,51 @@ def test_per_path_radiance_matches_oracle(ctx, orc, name):
         v.destroy()
 
 
+@pytest.mark.parametrize("layout", ["dense", "cell8", "brick27"])
+@pytest.mark.parametrize("name", ["cfg4_radial_rk4", "cfg3_curved_verlet_trilinear", "point_curved_trilinear"])
+def test_global_load_kernels_match_oracle(ctx, orc, name, layout):
+    """configs[3]'s code paths: a field of 4 GiB or more cannot be read through a buffer descriptor and the march lists are left
+    unsorted above 2^28 nodes.  Option buffer_loads = 0 selects those kernels (global loads: RIFK_DENSE / CELL8 / BRICK27 without
+    _BUF) for a small field, mq_sort = 0 the unsorted lists: same per-path contract against the oracle."""
+    p = CASES[name]()
+    lay = {"dense": capi.LAYOUT_DENSE, "cell8": capi.LAYOUT_CELL8, "brick27": capi.LAYOUT_BRICK27}[layout]
+    with ctx.options(buffer_loads=0, mq_sort=0):
+        sc, vols = ctx.upload_scene(p, layout=lay)
+        ref, vr = None, []
+        for s in (0, 1):
+            a = ctx.render_paths(sc, s, seed=3)
+            b = orc.render_paths(p, s, 3)
+            close = np.abs(a - b).max(2) <= 1e-4 * np.maximum(1.0, np.abs(b).max(2))
+            assert close.mean() > (0.92 if name.startswith("point_curved") else 0.99), close.mean()
+        a = ctx.render_paths(sc, 0, seed=3)
+    sb, vb = ctx.upload_scene(p, layout=lay)                  # the same field through buffer loads and sorted lists: no bit differs
+    assert np.array_equal(ctx.render_paths(sb, 0, seed=3), a)
+    for v in vols + vb:
+        v.destroy()
+
+
+def test_full_frame_camera_does_not_overrun_the_hit_ring(ctx):
+    """Every camera sample reaches the medium (hit fraction 1, against ~0.2 in the bench scene): K_gen's launches push as many work ids
+    as they reserve.  The ring must hold the throttle's backlog plus a whole launch, or unread ids are overwritten: samples rendered
+    twice and samples lost, with C_PATHS still adding up.  Checked on the film's weight channel (box filter: exactly spp per pixel)
+    and on 1 vs 4 pipelines."""
+    N = 16
+    p = scenes.straight_scene(N=N, w=512, h=512, fov_x_deg=20.0, rfilter=P.FILTER_BOX, rfilter_param=0.5, density_scale=1.0, max_depth=3)
+    sc, vols = ctx.upload_scene(p)
+    spp = 32                                                  # 8.4 M samples: 4 pipelines x 2.1 M
+    ctx.counters_reset()
+    f4 = ctx.render_to_host(sc, 0, spp, seed=1)
+    c4 = ctx.counters()
+    assert c4[capi.C_PATHS] == 512 * 512 * spp
+    assert np.array_equal(f4[..., 4], np.full((512, 512), float(spp), np.float32))
+    with ctx.options(pipes=1, nslots=262144):                 # a small slot pool: the ring is sized by the launch, not by the slots
+        f1 = ctx.render_to_host(sc, 0, spp, seed=1)
+    assert np.array_equal(f1[..., 4], f4[..., 4])
+    assert np.allclose(f1, f4, rtol=1e-4, atol=1e-4)
+    for v in vols:
+        v.destroy()
+
+
 @pytest.mark.parametrize("name", ["cfg2_straight_ratio", "cfg3_curved_rk4_trilinear", "parity_verlet_bspline", "cfg1_homogeneous_isotropic",
                                   "dielectric_straight_grid", "dielectric_curved_trilinear"])
 def test_film_matches_oracle_at_equal_spp(ctx, orc, name):
@@ -156,11 +201,10 @@ def test_auto_layout_and_list_sorting_change_nothing_per_path(ctx, monkeypatch):
     p = scenes.curved_scene(N=24, w=48, h=40)
     sc, vols = ctx.upload_scene(p, layout=capi.LAYOUT_DENSE)
     sc2, vols2 = ctx.upload_scene(p, layout=capi.LAYOUT_AUTO)
-    monkeypatch.setenv("MER_MQ_SORT", "0")
-    a = [ctx.render_paths(sc, s, seed=2) for s in (0, 1)]
-    monkeypatch.setenv("MER_MQ_SORT", "1")
-    b = [ctx.render_paths(sc2, s, seed=2) for s in (0, 1)]
-    monkeypatch.delenv("MER_MQ_SORT")
+    with ctx.options(mq_sort=0):
+        a = [ctx.render_paths(sc, s, seed=2) for s in (0, 1)]
+    with ctx.options(mq_sort=1):
+        b = [ctx.render_paths(sc2, s, seed=2) for s in (0, 1)]
     c = [ctx.render_paths(sc2, s, seed=2) for s in (0, 1)]
     for x, y, z in zip(a, b, c):
         assert np.array_equal(x, y) and np.array_equal(x, z)
@@ -170,25 +214,24 @@ def test_auto_layout_and_list_sorting_change_nothing_per_path(ctx, monkeypatch):
 
 @pytest.mark.parametrize("name", ["curved", "straight", "point_curved"])
 def test_concurrent_pipelines_render_the_same_film(ctx, monkeypatch, name):
-    """mer_render cuts a shard into MER_PIPES independent pipelines (own slots, lists, stream; shared film): same samples, same paths --
+    """mer_render cuts a shard into `pipes` (option) independent pipelines (own slots, lists, stream; shared film): same samples, same paths --
     the film differs by float summation order only, the counters not at all; a pipeline without samples is skipped"""
     p = {"curved": lambda: scenes.curved_scene(N=24, w=70, h=45), "straight": lambda: scenes.straight_scene(N=24, w=70, h=45),
          "point_curved": lambda: scenes.curved_scene(N=16, w=24, h=20, rif="radial", env_radiance=[0, 0, 0], point_position=[0.2, 0.3, -0.1],
                                                      point_intensity=[1.0, 0.8, 0.5])}[name]()
     sc, vols = ctx.upload_scene(p)
     films, counts = [], []
-    for n in ("1", "2", "3", "4"):
-        monkeypatch.setenv("MER_PIPES", n)
-        ctx.counters_reset()
-        films.append(ctx.render_to_host(sc, 1, 7, seed=3, spp_stride=2))
-        counts.append(np.array(ctx.counters()[:7]))
-    monkeypatch.delenv("MER_PIPES")
+    for n in (1, 2, 3, 4):
+        with ctx.options(pipes=n):
+            ctx.counters_reset()
+            films.append(ctx.render_to_host(sc, 1, 7, seed=3, spp_stride=2))
+            counts.append(np.array(ctx.counters()[:7]))
     for f, c in zip(films[1:], counts[1:]):
         assert np.allclose(f, films[0], rtol=1e-4, atol=1e-5)
         assert np.array_equal(c, counts[0])
     one = ctx.render_to_host(sc, 5, 1, seed=3)                      # a single sample per pixel: one pipeline has all the work
-    monkeypatch.setenv("MER_PIPES", "1")
-    assert np.allclose(one, ctx.render_to_host(sc, 5, 1, seed=3), rtol=1e-4, atol=1e-5)
+    with ctx.options(pipes=1):
+        assert np.allclose(one, ctx.render_to_host(sc, 5, 1, seed=3), rtol=1e-4, atol=1e-5)
     for v in vols:
         v.destroy()
 
