@@ -130,6 +130,9 @@ template <int RIF, int BND = 0> struct Connector {
     const Params &P;
     float tol, rrweight; int precision, maxIter, maxSteps;
     mutable CellCache cc;                       // the 8 corners of the cell the ray is in (trilinear RIF): reused across evaluations
+#ifdef MER_CONNECT_DEBUG
+    mutable float dbg0 = -1, dbg1 = -1, dbg2 = 0, dbg3 = 0, dbg4 = 0;
+#endif
     __device__ Connector(const Params &p) : P(p) {
         cc.reset();
         tol = 1e-6f; rrweight = 1e-2f; precision = 3; maxIter = 20;                 // :209-213, :217
@@ -157,13 +160,16 @@ template <int RIF, int BND = 0> struct Connector {
     __device__ bool computefdf(f3 v_i, f3 p1, f3 p2, f3 &error, m33 &J) const {
         m33 dp(0.0f), dv(1.0f);
         error = p1 - p2; J = m33(0.0f);
-        // a shooting direction that is not a finite non-zero vector has no ray (the solver's step can overflow: guard, not reference)
+        // a shooting direction that is not a finite non-zero vector has no ray (the solver's step can overflow: guard, not reference).
+        // Past this point a non-finite p or v cannot reach memory: every fetch index is clamped or bounds-tested in a NaN-safe form
+        // (mer_device.hpp), a NaN position fails inside_shape (all its comparisons are false) and a NaN residual never beats the
+        // current cost -- the march ends at the next test, as for a ray that leaves the shape.
         if (!finite3(v_i) || !(dot(v_i, v_i) > 0.0f) || !isfinite(dot(v_i, v_i))) return false;
         if (RIF == MER_RIF_BSPLINE3 && !inside_volume_limits(P.rif, p1)) return false;
         float h = P.sc.stepsize;
         int nBisect = (int) ceilf((float) precision / 0.30102999566f);
-        f3 p = p1, oldp, v = v_i, oldv; m33 olddp, olddv;
-        const bool signOld = dot(p - p2, v) < 0.0f; bool signNew;
+        f3 p = p1, oldp = p1, v = v_i, oldv = v_i; m33 olddp(0.0f), olddv(1.0f);
+        const bool signOld = dot(p - p2, v) < 0.0f; bool signNew = signOld;
         const float r = rif_value(p);
         const float n1 = sqrtf(dot(v_i, v_i)), n2 = n1 * n1, n3 = n2 * n1;
         { m33 a(n2); const m33 o = outer(v, v);
@@ -174,7 +180,6 @@ template <int RIF, int BND = 0> struct Connector {
         for (int i = 0; i < maxSteps; i++) {
             oldp = p; oldv = v; olddp = dp; olddv = dv;
             dstep(p, v, dp, dv, h);
-            if (!finite3(p) || !finite3(v)) return false;
             signNew = dot(p - p2, v) < 0.0f;
             if (signNew != signOld) {
                 while (nBisect > 0) {
@@ -250,13 +255,16 @@ template <int RIF, int BND = 0> struct Connector {
         dist = 0; optDist = 0;
         float h = P.sc.stepsize;
         int nBisect = (int) ceilf((float) precision / 0.30102999566f);
-        f3 p = p1, oldp, v = dirToP2, oldv;
-        const bool signOld = dot(p - p2, v) < 0.0f; bool signNew;
+        f3 p = p1, oldp = p1, v = dirToP2, oldv = dirToP2;
+        const bool signOld = dot(p - p2, v) < 0.0f; bool signNew = signOld;
         for (int i = 0; i < maxSteps; i++) {
             oldp = p; oldv = v;
             verlet(p, v, h);
-            if (!finite3(p) || !finite3(v)) return false;
             signNew = dot(p - p2, v) < 0.0f;
+#ifdef MER_CONNECT_DEBUG
+            dbg0 = (float) i;
+            if (!inside_shape_b<BND>(P, p)) { dbg1 = -2.0f - sdf_value(P, p); dbg2 = p.x; dbg3 = p.y; dbg4 = p.z; return false; }
+#endif
             if (!inside_shape_b<BND>(P, p)) return false;
             if (signNew != signOld) {
                 while (nBisect > 0) {
@@ -269,6 +277,9 @@ template <int RIF, int BND = 0> struct Connector {
                 break;
             } else { dist += h; optDist += h * rif_value(0.5f * (p + oldp)); }
         }
+#ifdef MER_CONNECT_DEBUG
+        dbg1 = dot(p - p2, p - p2);
+#endif
         if (dot(p - p2, p - p2) > tol) return false;
         revDir = -normalize(v);
         return true;
@@ -405,6 +416,9 @@ __global__ void __launch_bounds__(64) connect_kernel(const Params P, const float
     float *o = out + 12 * i;
     o[0] = ok ? 1.0f : 0.0f; o[1] = w; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z;
     o[5] = ok ? rev.x : 0.0f; o[6] = ok ? rev.y : 0.0f; o[7] = ok ? rev.z : 0.0f; o[8] = ok ? di : 0.0f; o[9] = ok ? od : 0.0f; o[10] = o[11] = 0.0f;
+#ifdef MER_CONNECT_DEBUG
+    o[10] = K.dbg0; o[11] = K.dbg1; o[5] = K.dbg2; o[6] = K.dbg3; o[7] = K.dbg4;
+#endif
 }
 
 }  // namespace mer

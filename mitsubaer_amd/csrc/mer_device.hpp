@@ -127,21 +127,23 @@ __device__ __forceinline__ float grid_fetch(const DGrid &g, long long idx) {
 }
 
 // GridDataSource::lookupFloat (gridvolume.cpp:337-388).  The integer part (x1,y1,z1, bounds test, linear
-// index) is the bit-exact contract; the blend keeps the reference's operation order.
+// index) is the bit-exact contract; the blend keeps the reference's operation order.  Branch-free: the reference's early
+// `return 0` for a point off the grid is a select at the end -- the cell index is clamped into the grid and the eight corners are
+// always fetched (a point off the grid is rare on this path, and a divergent early return inside the marching loops is what this
+// toolchain miscompiled in K_connect: see sdf_value).  The bounds test is written so that it cannot wrap: v_cvt_i32_f32 saturates,
+// a coordinate of +inf (or >= 2^31) gives x1 = INT_MAX, and INT_MAX + 1 >= res would pass.
 __device__ __forceinline__ float lookup_float(const DGrid &g, f3 p, int *idx4 = nullptr) {
     const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
     const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
-    if (idx4) { idx4[0] = x1; idx4[1] = y1; idx4[2] = z1; idx4[3] = -1; }
-    // x2 = x1 + 1 >= res, written so that it cannot wrap: v_cvt_i32_f32 saturates, a coordinate of +inf (or >= 2^31) gives
-    // x1 = INT_MAX, and INT_MAX + 1 would pass the test and fetch from a wild address
-    if (x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1) return 0.0f;
+    const bool inside = !(x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1);
+    const int xc = min(max(x1, 0), g.res[0] - 2), yc = min(max(y1, 0), g.res[1] - 2), zc = min(max(z1, 0), g.res[2] - 2);
     const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
                 _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
-    const int base = (z1 * g.res[1] + y1) * g.res[0] + x1;
-    if (idx4) idx4[3] = base;
+    const int base = (zc * g.res[1] + yc) * g.res[0] + xc;
+    if (idx4) { idx4[0] = x1; idx4[1] = y1; idx4[2] = z1; idx4[3] = inside ? base : -1; }
     float d000, d001, d010, d011, d100, d101, d110, d111;
     if (g.layout == MER_LAYOUT_CELL8) {
-        const int cell = (z1 * (g.res[1] - 1) + y1) * (g.res[0] - 1) + x1;
+        const int cell = (zc * (g.res[1] - 1) + yc) * (g.res[0] - 1) + xc;
         const float4 *c = (const float4 *) (g.cell8 + (size_t) MER_CHK(g.chk, CHK_GRID_RECORD, (size_t) cell * 8, g.n_record - 7));
         const float4 a = c[0], b = c[1];
         d000 = a.x; d001 = a.y; d010 = a.z; d011 = a.w; d100 = b.x; d101 = b.y; d110 = b.z; d111 = b.w;
@@ -152,18 +154,20 @@ __device__ __forceinline__ float lookup_float(const DGrid &g, f3 p, int *idx4 = 
         d100 = grid_fetch(g, base + sz);     d101 = grid_fetch(g, base + sz + 1);
         d110 = grid_fetch(g, base + sz + sy); d111 = grid_fetch(g, base + sz + sy + 1);
     }
-    return ((d000 * _fx + d001 * fx) * _fy + (d010 * _fx + d011 * fx) * fy) * _fz +
-           ((d100 * _fx + d101 * fx) * _fy + (d110 * _fx + d111 * fx) * fy) * fz;
+    const float v = ((d000 * _fx + d001 * fx) * _fy + (d010 * _fx + d011 * fx) * fy) * _fz +
+                    ((d100 * _fx + d101 * fx) * _fy + (d110 * _fx + d111 * fx) * fy) * fz;
+    return inside ? v : 0.0f;
 }
 
-// GridDataSource::lookupSpectrum (gridvolume.cpp:390-421), 3 channels
+// GridDataSource::lookupSpectrum (gridvolume.cpp:390-421), 3 channels; branch-free as lookup_float
 __device__ __forceinline__ f3 lookup_spectrum(const DGrid &g, f3 p) {
     const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
     const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
-    if (x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1) return f3(0, 0, 0);   // as lookup_float
+    const bool inside = !(x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1);
+    const int xc = min(max(x1, 0), g.res[0] - 2), yc = min(max(y1, 0), g.res[1] - 2), zc = min(max(z1, 0), g.res[2] - 2);
     const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
                 _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
-    const int base = (z1 * g.res[1] + y1) * g.res[0] + x1, sy = g.res[0], sz = g.res[0] * g.res[1];
+    const int base = (zc * g.res[1] + yc) * g.res[0] + xc, sy = g.res[0], sz = g.res[0] * g.res[1];
     float out[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -172,8 +176,9 @@ __device__ __forceinline__ f3 lookup_spectrum(const DGrid &g, f3 p) {
                     d010 = grid_fetch(g, b3 + y3), d011 = grid_fetch(g, b3 + y3 + 3),
                     d100 = grid_fetch(g, b3 + z3), d101 = grid_fetch(g, b3 + z3 + 3),
                     d110 = grid_fetch(g, b3 + z3 + y3), d111 = grid_fetch(g, b3 + z3 + y3 + 3);
-        out[c] = ((d000 * _fx + d001 * fx) * _fy + (d010 * _fx + d011 * fx) * fy) * _fz +
-                 ((d100 * _fx + d101 * fx) * _fy + (d110 * _fx + d111 * fx) * fy) * fz;
+        const float v = ((d000 * _fx + d001 * fx) * _fy + (d010 * _fx + d011 * fx) * fy) * _fz +
+                        ((d100 * _fx + d101 * fx) * _fy + (d110 * _fx + d111 * fx) * fy) * fz;
+        out[c] = inside ? v : 0.0f;
     }
     return f3(out[0], out[1], out[2]);
 }
@@ -585,10 +590,24 @@ __device__ __forceinline__ f3 shape_normal(const mer_scene_desc &s, f3 x) {
 }
 // ---- boundary kind as a template switch (BND = 1: the negative region of a signed-distance grid, the reference's `sdf` child,
 // src/medium/heterogeneousrefractive.cpp:366-375,481).  Kept out of the BND = 0 kernels: the hot loop must not carry a second gather.
-__device__ __forceinline__ float sdf_value(const Params &P, f3 p) {        // lookupFloat is 0 outside the grid: far outside here
-    int idx4[4];
-    const float v = lookup_float(P.sdf, p, idx4);
-    return idx4[3] >= 0 ? v : 1e30f;
+// lookupFloat (gridvolume.cpp:337-388) of the signed-distance grid, "far outside" (1e30) where lookupFloat returns 0 for a point off
+// the grid.  Written without a branch: the cell index is clamped into the grid, the eight corners are always fetched and the bounds
+// test selects the result (same integer contract and blend order as lookup_float).  The branching form -- an early return inside
+// the marching loops of K_connect -- was miscompiled by this toolchain at -O2 and above when the lanes of a wave diverge
+// (scratch/miscompile/: 1 of 64 connections found against 61 at -O1).
+__device__ __forceinline__ float sdf_value(const Params &P, f3 p) {
+    const DGrid &g = P.sdf;
+    const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
+    const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
+    const bool inside = !(x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1);
+    const int xc = min(max(x1, 0), g.res[0] - 2), yc = min(max(y1, 0), g.res[1] - 2), zc = min(max(z1, 0), g.res[2] - 2);
+    const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1, _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
+    const int base = (zc * g.res[1] + yc) * g.res[0] + xc, sy = g.res[0], sz = g.res[0] * g.res[1];
+    const float d000 = grid_fetch(g, base), d001 = grid_fetch(g, base + 1), d010 = grid_fetch(g, base + sy), d011 = grid_fetch(g, base + sy + 1),
+                d100 = grid_fetch(g, base + sz), d101 = grid_fetch(g, base + sz + 1), d110 = grid_fetch(g, base + sz + sy), d111 = grid_fetch(g, base + sz + sy + 1);
+    const float v = ((d000 * _fx + d001 * fx) * _fy + (d010 * _fx + d011 * fx) * fy) * _fz +
+                    ((d100 * _fx + d101 * fx) * _fy + (d110 * _fx + d111 * fx) * fy) * fz;
+    return inside ? v : 1e30f;
 }
 template <int BND> __device__ __forceinline__ bool inside_shape_b(const Params &P, f3 p) {
     if (BND == 0) return inside_shape(P.sc, p);

@@ -1016,7 +1016,6 @@ template <typename FLOAT> struct Connector {
         for (int i = 0; i < ms; i++) {
             oldp = p; oldv = v; olddp = dpdv0; olddv = dvdv0;
             er_derivativestep(p, v, dpdv0, dvdv0, h);
-            if (!finite3(p) || !finite3(v)) return false;
             signNew = std::signbit(dot(p - p2, v));
             if (signNew != signOld) {
                 while (nBisect > 0) {
@@ -1093,7 +1092,6 @@ template <typename FLOAT> struct Connector {
         for (int i = 0; i < ms; i++) {
             oldp = p; oldv = v;
             T.er_step_verlet(p, v, h, dummy);
-            if (!finite3(p) || !finite3(v)) return false;
             signNew = std::signbit(dot(p - p2, v));
             if (!S.insideShape(p)) return false;
             if (signNew != signOld) {

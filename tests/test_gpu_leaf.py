@@ -223,7 +223,7 @@ def test_curved_ray_connection(ctx, orc, kind):
     assert np.abs(a[ok, 8] - b[ok, 8]).max() < 5e-3 and np.abs(a[ok, 9] - b[ok, 9]).max() < 1e-2
     assert np.all(a[ok, 1] >= 1.0)                              # weight = (#agreeing solutions) / RR probability
     # the connection is a ray: re-trace it with the reference's Verlet trace() and land on p2
-    q = p.copy(stepper=P.STEP_VERLET)
+    q = p.copy(stepper=P.STEP_VERLET, boundary=P.BOUNDARY_AABB, sdf=None)        # mer_er_trace knows the cube / sphere boundaries
     scq, _ = ctx.upload_scene(q)
     op, ov, ds, oo, okk = ctx.er_trace(scq, p1[ok], da, a[ok, 8])
     assert np.abs(op - p2[ok]).max() < 3e-3                     # sqrt(2 tol2) = 1.4e-3 plus bisection granularity

@@ -103,10 +103,17 @@ def test_full_frame_camera_does_not_overrun_the_hit_ring(ctx):
     f4 = ctx.render_to_host(sc, 0, spp, seed=1)
     c4 = ctx.counters()
     assert c4[capi.C_PATHS] == 512 * 512 * spp
-    assert np.array_equal(f4[..., 4], np.full((512, 512), float(spp), np.float32))
+    def weights_ok(f):
+        # every sample adds the same weight w0 = (box-filter table value)^2 to its own pixel, and to a neighbour too when it falls
+        # within 1e-5 of the pixel's edge (box.cpp:39): a pixel BELOW spp * w0 has lost a sample, one well above has one twice
+        w = f[..., 4].astype(np.float64); w0 = np.median(w) / spp
+        assert abs(w0 - 1.0) < 1e-3
+        assert (w > (spp - 0.5) * w0).all(), "samples lost: min weight %g of %g" % (w.min(), spp * w0)
+        assert (w > (spp + 0.5) * w0).mean() < 5e-3 and abs(w.sum() / (512 * 512 * spp * w0) - 1.0) < 1e-4
+    weights_ok(f4)
     with ctx.options(pipes=1, nslots=262144):                 # a small slot pool: the ring is sized by the launch, not by the slots
         f1 = ctx.render_to_host(sc, 0, spp, seed=1)
-    assert np.array_equal(f1[..., 4], f4[..., 4])
+    weights_ok(f1)
     assert np.allclose(f1, f4, rtol=1e-4, atol=1e-4)
     for v in vols:
         v.destroy()
