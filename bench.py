@@ -3,15 +3,20 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-A step = one full render of the workload (default: config 3 = 256^3 sigma_t grid + 256^3 linear RIF,
-RK4 eikonal stepping on the trilinear field (BRICK27 records), HG g=0.8, 512^2 x 256 spp, half-voxel steps, ratio-tracking
-transmittance, box filter) with all inputs resident in HBM.  N > 1 (launched by torch.distributed.run) shards
-sample indices across ranks (weak scaling: every rank renders 512^2 x 256 spp of a 512^2 x (256 N) spp job)
-and sum-reduces the film with RCCL inside the timed region.  Rank 0 prints ONE JSON line.
+A step = one full render of the workload (default: configs[2] = 256^3 sigma_t grid + 256^3 linear RIF, RK4 eikonal stepping on the
+trilinear field, HG g=0.8, 512^2 x 256 spp, half-voxel steps, ratio-tracking transmittance, box filter) with all inputs resident in HBM.
+
+N > 1: one process per GPU.  Launched by torch.distributed.run (the driver's way) the ranks come from the environment; launched as
+plain `python bench.py --gpus N` this process starts that launcher itself -- N ranks, before it touches a GPU -- and relays rank 0's
+line.  A world size that differs from --gpus is an error.  --scaling weak (default): every rank renders --spp samples per pixel of a
+(spp x N)-sample job, sample-interleaved.  --scaling strong: the job is fixed (--spp samples per pixel of the whole film) and is cut
+into 32x32 image tiles dealt round-robin to the ranks (the reference's block partition, src/librender/renderproc.cpp:79,142-149).
+Either way the film is sum-reduced with one RCCL all-reduce inside the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -19,39 +24,67 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~6300 measured by a float4 copy
+# wave64 VALU instructions the chip can issue per second: 256 CUs x 4 SIMDs x 2.4 GHz / 2.3 cycles per independent v_fma_f32
+# (profiles/round1/ubench_valu_issue_rate.txt: 2.25-2.40 cycles measured; a DEPENDENT v_fma_f32 issues every 4.2-4.4 cycles)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.3
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round2", "hbm_traffic.json")
 
 
-def build_workload(name, res, size, spp):
+def workload_tag(name, res, size):
+    return "%s_%d_film%d" % (name, res, size)
+
+
+def scene_params(name, res, size, with_fields):
+    """SceneParams of a BASELINE config; with_fields: numpy grids (the CPU baseline needs them; the GPU side of large grids uses fields
+    generated in HBM by mer_synth_field_dev, see upload())."""
     import numpy as np
     from mitsubaer_amd import params as P, synth
     common = dict(width=size, height=size, rfilter=P.FILTER_BOX, rfilter_param=0.5, tr_estimator=P.TR_RATIO,
                   phase=P.PHASE_HG, g=0.8, density_scale=4.0, albedo=[0.9, 0.9, 0.9])
-    dens = synth.density_field(res)
+    dens = synth.density_field(res) if with_fields else None
+    step = 0.5 * 2.0 / (res - 1)
     if name == "cfg2":
         p = P.SceneParams(density=dens, rif_mode=P.RIF_CONST, **common)
-        desc = "%d^3 sigma_t grid, constant RIF (straight rays), HG g=0.8, %d^2 x %d spp" % (res, size, spp)
+        desc = "configs[1]: %d^3 sigma_t grid, constant RIF (straight rays), HG g=0.8" % res
     elif name == "cfg3":
-        rres = int(os.environ.get("BENCH_RIF_RES", res))
-        p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.linear_rif(rres), stepper=P.STEP_RK4,
-                          stepsize=0.5 * 2.0 / (res - 1), **common)
-        desc = "%d^3 sigma_t grid + %d^3 linear-gradient RIF, RK4 eikonal curved rays, HG g=0.8, %d^2 x %d spp" % (res, res, size, spp)
+        p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.linear_rif(res) if with_fields else None, stepper=P.STEP_RK4, stepsize=step, **common)
+        desc = "configs[2]: %d^3 sigma_t grid + %d^3 linear-gradient RIF, RK4 eikonal curved rays, HG g=0.8" % (res, res)
     elif name == "cfg4":
-        p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.radial_rif(res), stepper=P.STEP_RK4,
-                          stepsize=0.5 * 2.0 / (res - 1), **common)
-        desc = "%d^3 sigma_t grid + %d^3 radial RIF, RK4 eikonal curved rays, HG g=0.8, %d^2 x %d spp" % (res, res, size, spp)
+        p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.radial_rif(res) if with_fields else None, stepper=P.STEP_RK4, stepsize=step, **common)
+        desc = "configs[3]: %d^3 sigma_t grid + %d^3 radial RIF, RK4 eikonal curved rays, HG g=0.8" % (res, res)
     elif name == "cfg5":
         # emissive heterogeneous medium + RGB albedo grid + curved-ray luminaire sampling of a point emitter (A12)
         g = np.linspace(0.0, 1.0, res, dtype=np.float32)
         alb = np.empty((res, res, res, 3), np.float32)
         alb[..., 0] = 0.55 + 0.4 * g[None, None, :]; alb[..., 1] = 0.55 + 0.4 * g[None, :, None]; alb[..., 2] = 0.55 + 0.4 * g[:, None, None]
         common.pop("albedo")
-        p = P.SceneParams(density=dens, rif_mode=P.RIF_TRILINEAR, rif=synth.linear_rif(res), stepper=P.STEP_RK4,
-                          stepsize=0.5 * 2.0 / (res - 1), albedo_mode=P.ALBEDO_GRID, albedo_grid=alb, env_radiance=[0, 0, 0],
-                          emission=[0.2, 0.12, 0.06], point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5], **common)
-        desc = "%d^3 sigma_t + RGB albedo grids, emissive medium, %d^3 linear RIF, RK4 curved rays + curved-ray point-emitter NEE, %d^2 x %d spp" % (res, res, size, spp)
+        p = P.SceneParams(density=synth.density_field(res), rif_mode=P.RIF_TRILINEAR, rif=synth.linear_rif(res), stepper=P.STEP_RK4, stepsize=step,
+                          albedo_mode=P.ALBEDO_GRID, albedo_grid=alb, env_radiance=[0, 0, 0], emission=[0.2, 0.12, 0.06],
+                          point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5], **common)
+        desc = "configs[4]: %d^3 sigma_t + RGB albedo grids, emissive medium, %d^3 linear RIF, RK4 curved rays + curved-ray point-emitter NEE" % (res, res)
     else:
         raise SystemExit("unknown workload %s" % name)
     return p, desc
+
+
+def build_workload(name, res, size, spp):
+    """(SceneParams with numpy fields, description) -- used by the full-size tests"""
+    p, desc = scene_params(name, res, size, with_fields=True)
+    return p, desc + ", %d^2 x %d spp" % (size, spp)
+
+
+def upload(ctx, name, res, p, layout):
+    """-> (scene desc, volumes).  Grids of 512^3 and more are generated on the device (mer_synth_field_dev: the same formulas as
+    mitsubaer_amd/synth.py) instead of 0.5 - 4 GiB numpy arrays per field."""
+    from mitsubaer_amd import capi
+    if p.density is not None or name in ("cfg5",):
+        return ctx.upload_scene(p, layout=layout)
+    dl = capi.LAYOUT_CELL8 if layout in (capi.LAYOUT_BRICK27, capi.LAYOUT_BRICK125, capi.LAYOUT_AUTO) else layout
+    dens = ctx.synth_volume(0, res, layout=dl)
+    rif = None
+    if name in ("cfg3", "cfg4"):
+        rif = ctx.synth_volume(1 if name == "cfg3" else 2, res, layout=layout)
+    return ctx.scene_desc(p, dens, None, rif), [v for v in (dens, rif) if v is not None]
 
 
 def algorithmic_bytes(c, p):
@@ -94,6 +127,74 @@ def cpu_baseline(p, target_seconds=20.0):
             "sample": "%dx%d x %d spp of the same scene (%.1f s), oracle/libmer_oracle.so fp32, std::thread over rows" % (p.width, p.height, spp, dt)}
 
 
+def measured_traffic(tag):
+    """HBM bytes per eikonal step of K_march for this workload, from the committed rocprofv3 --pmc passes (they cannot be counted
+    inside this process): profiles/round2/hbm_traffic.json, written by scratch/pmc_traffic.py."""
+    try:
+        return json.load(open(TRAFFIC_FILE)).get(tag)
+    except Exception:
+        return None
+
+
+def roofline_block(ctx, capi, p, tag, solo, timed, layout_name):
+    """roofline of the dominant kernel (K_march).  `solo` = (passes, march_ms, event_ms, counters, wall_s) of one step rendered as ONE
+    pipeline -- its launches have the chip to themselves, so bytes / duration is a chip-level rate; `timed` = the same for the timed
+    region's average step (concurrent pipelines: only the aggregate over the step means anything there)."""
+    n1, m1, e1, c1, wall1 = solo
+    steps = float(c1[capi.C_STEPS]); tent = float(c1[capi.C_TENTATIVE]); paths = float(c1[capi.C_PATHS])
+    b_alg = algorithmic_bytes(c1, p) - 40.0 * paths                       # K_march performs every field fetch; the film write is K_event's
+    launches = max(n1, 1)
+    launch_ms = m1 / launches
+    tr = measured_traffic(tag)
+    out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "kernel": "mer::march_kernel<curved, %s trilinear, rk4, grid>" % layout_name,
+           "kernel_avg_launch_ms": launch_ms, "launches_per_step": n1, "kernel_ms_per_step": m1, "event_kernel_ms_per_step": e1,
+           "step_wall_ms": wall1 * 1e3, "pipelines": 1,
+           "what": "one untimed step rendered as ONE pipeline (option pipes = 1): K_march's launches have the chip to themselves, HIP events on the launch stream",
+           "algorithmic_bytes_per_launch": b_alg / launches,
+           "algorithmic_GBps": b_alg / max(m1, 1e-9) / 1e6,
+           "counters_per_step": {"paths": paths, "eikonal_steps": steps, "tentative_collisions": tent, "real_collisions": float(c1[capi.C_REAL])},
+           "active_lane_fraction": float(c1[capi.C_ACTIVE_LANES] / max(c1[capi.C_LOOP_ITERS], 1.0))}
+    if tr:
+        # measured HBM-side bytes per eikonal step (rocprofv3 --pmc, TCC_EA0_RDREQ by request size + WRREQ), scaled by this run's steps
+        hbm = tr["hbm_bytes_per_eikonal_step"] * steps
+        out.update({"achieved": hbm / max(m1, 1e-9) / 1e6, "traffic": hbm / launches,
+                    "reuse_factor": b_alg / max(hbm, 1.0),
+                    "traffic_source": "%s [%s]: %s" % (os.path.relpath(TRAFFIC_FILE, ROOT), tag, tr.get("method", ""))})
+        out["frac"] = out["achieved"] / HBM_PEAK_GBS
+    else:
+        # no counter pass committed for this workload: the algorithmic rate is an UPPER bound of the HBM rate only when nothing is
+        # reused, which is not the case here (register cell cache, L2, Infinity Cache) -- report no fraction rather than a wrong one
+        out.update({"achieved": None, "frac": None, "traffic": None, "traffic_source": "no rocprofv3 --pmc pass committed for %s" % tag})
+    if tr and tr.get("valu_inst_per_wave_step"):
+        wave_steps = float(c1[capi.C_LOOP_ITERS]) / 64.0
+        ginst = tr["valu_inst_per_wave_step"] * wave_steps / max(m1, 1e-9) / 1e6
+        out["valu"] = {"inst_per_wave_step": tr["valu_inst_per_wave_step"], "achieved_Ginst_s": ginst, "peak_Ginst_s": VALU_PEAK_GINST,
+                       "frac": ginst / VALU_PEAK_GINST,
+                       "note": "peak = independent v_fma_f32 issue (2.3 cycles per wave64 instruction, measured); a dependent one issues every ~4.3 cycles"}
+    out["limiter"] = (tr or {}).get("limiter", "see DESIGN.md section 4")
+    if timed is not None:
+        k_ms, m_ms, e_ms, n_pass, counters, pipes = timed
+        b_step = algorithmic_bytes(counters, p)
+        ws = {"pipelines": pipes, "ms": k_ms, "kernel_ms_summed_over_pipelines": m_ms, "event_kernel_ms_summed_over_pipelines": e_ms,
+              "launches": n_pass, "algorithmic_bytes": b_step, "algorithmic_GBps": b_step / max(k_ms, 1e-9) / 1e6,
+              "note": "timed region: concurrent pipelines stretch one another's launches, so only the aggregate over the step is a chip-level figure"}
+        if tr:
+            hb = tr["hbm_bytes_per_eikonal_step"] * float(counters[capi.C_STEPS])
+            ws.update({"hbm_bytes": hb, "achieved": hb / max(k_ms, 1e-9) / 1e6, "frac": hb / max(k_ms, 1e-9) / 1e6 / HBM_PEAK_GBS})
+        out["whole_step"] = ws
+    return out
+
+
+def spawn_ranks(args):
+    """plain `python bench.py --gpus N`: start N ranks with torch.distributed.run before this process touches a GPU, relay rank 0."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,38 +206,49 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--layout", default="auto", choices=["auto", "dense", "cell8", "brick27", "brick125"],
                     help="HBM layout of the trilinear RIF (auto: brick27 up to 2^28 nodes, cell8 above)")
-    ap.add_argument("--shard", default="samples", choices=["samples", "tiles"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--shard", default=None, choices=["samples", "tiles"], help="default: samples for weak scaling, tiles for strong")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--device", type=int, default=None, help="force this GPU index for every rank (rehearsal on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-target-512", action="store_true", help="skip the 512^3 block of the default run")
+    ap.add_argument("--no-solo-step", action="store_true", help="skip the extra single-pipeline step (profiled runs)")
+    ap.add_argument("--options", default="", help="mer_context_set_option pairs, e.g. pipes=1,ksteps=96")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
 
     import numpy as np
     import torch
     from mitsubaer_amd import capi, dist as mdist
     rank, world, local = mdist.init_process_group(args.backend)
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if args.device is not None:
         local = args.device
-    if world != args.gpus:
-        if rank == 0:
-            print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    shard_mode = args.shard or ("tiles" if args.scaling == "strong" else "samples")
 
-    p, desc = build_workload(args.workload, args.res, args.size, args.spp)
+    small = args.res < 512 or args.workload == "cfg5"
+    p, desc = scene_params(args.workload, args.res, args.size, with_fields=small)
+    desc += ", %d^2 x %d spp" % (args.size, args.spp)
     ctx = capi.Context(local)
+    for kv in filter(None, args.options.split(",")):
+        k, v = kv.split("="); ctx.set_option(k, int(v))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     if args.layout == "auto":
         args.layout = "brick27" if args.res ** 3 <= 1 << 28 else "cell8"
     layout = {"cell8": capi.LAYOUT_CELL8, "brick27": capi.LAYOUT_BRICK27, "brick125": capi.LAYOUT_BRICK125, "dense": capi.LAYOUT_DENSE}[args.layout]
-    sc, vols = ctx.upload_scene(p, layout=layout)
+    sc, vols = upload(ctx, args.workload, args.res, p, layout)
     film = torch.zeros((p.height, p.width, 5), dtype=torch.float32, device=dev)
-    # weak scaling: every rank renders args.spp samples per pixel of a (spp * world)-sample job
-    sh = mdist.shard_args(args.shard, rank, world, args.spp * world) if args.shard == "samples" else \
-        mdist.shard_args(args.shard, rank, world, args.spp * world)
+    spp_job = args.spp * world if args.scaling == "weak" else args.spp
+    sh = mdist.shard_args(shard_mode, rank, world, spp_job)
 
     def step(seed):
         film.zero_()
@@ -158,91 +270,91 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-        # HIP events recorded by libmer around the render kernel on the launch stream; reading them waits for
-        # this step's kernel only (steps are dependent through the film anyway)
+        # HIP events recorded by libmer around the render on the launch stream; reading them waits for this step's kernels only
         kernel_ms.append(ctx.last_kernel_ms())
         n_, m_, e_ = ctx.last_render_stats()
         passes.append(n_); march_ms.append(m_); event_ms.append(e_)
     barrier()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tl = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank_ms = [elapsed / max(args.steps, 1) * 1e3]
+    rccl_ranks = 1
     if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        gathered = [torch.zeros_like(tl) for _ in range(world)]
+        torch.distributed.all_gather(gathered, tl)
+        per_rank_ms = [float(g.item()) / max(args.steps, 1) * 1e3 for g in gathered]
+        elapsed = max(float(g.item()) for g in gathered)                  # MAX over ranks
+        rccl_ranks = torch.distributed.get_world_size()
     counters = ctx.counters().astype(np.float64)
-    paths_rank = float(counters[capi.C_PATHS])
-    # one more step OUTSIDE the timed region with a single pipeline: the dominant kernel's launch duration when its launches do not
-    # share the chip with those of other pipelines (reported as roofline.single_pipeline, next to the figures of the timed region)
+    # one more step OUTSIDE the timed region as a single pipeline: per-launch figures of the dominant kernel
     solo = None
-    if ctx.get_option("pipes") > 1 and not os.environ.get("BENCH_NO_SOLO_STEP"):
+    if not args.no_solo_step and world == 1:
         with ctx.options(pipes=1):
             ctx.counters_reset()
-            t1 = time.perf_counter(); step(args.steps); torch.cuda.synchronize(); solo_wall = time.perf_counter() - t1
+            mer_sh = mdist.shard_args("samples", 0, 1, args.spp)
+            film2 = torch.zeros_like(film)
+            t1 = time.perf_counter()
+            ctx.render(sc, film2.data_ptr(), mer_sh["spp_begin"], mer_sh["spp_count"], seed=args.steps, spp_stride=1)
+            torch.cuda.synchronize(); solo_wall = time.perf_counter() - t1
             n1, m1, e1 = ctx.last_render_stats()
-            c1 = ctx.counters().astype(np.float64)
-            solo = (n1, m1, e1, c1, solo_wall)
+            solo = (n1, m1, e1, ctx.counters().astype(np.float64), solo_wall)
+            del film2
     ct = torch.tensor(counters, dtype=torch.float64, device=dev)
     mdist.reduce_counters(ct)
     total_paths = float(ct[capi.C_PATHS].item())
 
     if rank == 0:
-        k_ms = float(np.mean(kernel_ms))                                  # whole render (all wavefront passes)
-        m_ms = float(np.mean(march_ms)); e_ms = float(np.mean(event_ms)); n_pass = float(np.mean(passes))
-        b_alg = algorithmic_bytes(counters, p) / max(args.steps, 1)      # per step (one full render), this rank
-        # the dominant kernel is K_march: it performs every field fetch; the film write (40 B/path) is K_event's
-        b_march = (b_alg - 40.0 * paths_rank / max(args.steps, 1))
-        per_launch_bytes = b_march / max(n_pass, 1.0)
-        per_launch_ms = m_ms / max(n_pass, 1.0)
-        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0     # 0: MER_NO_PASS_EVENTS A/B runs
-        achieved_step = b_alg / (k_ms * 1e-3) / 1e9
-        lane_eff = float(counters[capi.C_ACTIVE_LANES] / max(counters[capi.C_LOOP_ITERS], 1.0))
         name, cus, hbm = ctx.device_info()
+        pipes = ctx.get_option("pipes")
+        tag = workload_tag(args.workload, args.res, args.size)
         out = {
-            "metric": "Mpaths/sec (curved-ray heterogeneous volume); roofline = achieved algorithmic HBM GB/s vs peak",
+            "metric": "Mpaths/sec (curved-ray heterogeneous volume); roofline = measured HBM GB/s of the dominant kernel vs peak",
             "value": total_paths / elapsed / 1e6, "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"cfg2": "configs[1]: ", "cfg3": "configs[2]: ", "cfg4": "configs[3]: ", "cfg5": "configs[4]: "}[args.workload] + desc, "grid": args.res, "film": [p.width, p.height], "spp_per_gpu": args.spp, "pipelines_per_gpu": ctx.get_option("pipes"),
-                       "stepper": "rk4", "rif_interp": "trilinear", "layout": args.layout, "shard": args.shard,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "grid": args.res, "film": [p.width, p.height],
+                       "spp_job": spp_job, "spp_per_gpu": args.spp if args.scaling == "weak" else None,
+                       "pipelines_per_gpu": pipes, "stepper": "rk4", "rif_interp": "trilinear", "layout": args.layout, "shard": shard_mode,
                        "stepsize": p.stepsize, "estimator": "volpath + delta tracking on eikonal rays, ratio-tracking NEE",
-                       "device": name, "cus": cus},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "mer::march_kernel<curved, %s trilinear, rk4, grid>" % args.layout,
-                         "kernel_avg_launch_ms": per_launch_ms, "launches_per_step": n_pass, "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "kernel_ms_per_step": m_ms, "event_kernel_ms_per_step": e_ms,
-                         "whole_step": {"ms": k_ms, "algorithmic_bytes": b_alg, "achieved": achieved_step, "frac": achieved_step / HBM_PEAK_GBS},
-                         "counters_per_launch": {"paths": paths_rank / args.steps, "steps": counters[capi.C_STEPS] / args.steps,
-                                                 "tentative": counters[capi.C_TENTATIVE] / args.steps, "real": counters[capi.C_REAL] / args.steps},
-                         "active_lane_fraction": lane_eff,
-                         # the render runs as several independent pipelines on their own streams (launch_render): launches of different
-                         # pipelines execute side by side, so one launch's duration is stretched by its neighbours and `achieved` (bytes of
-                         # ONE launch / its duration, the rocprofv3 figure) understates the chip's rate by up to that factor;
-                         # whole_step is the aggregate: all algorithmic bytes of the step / its wall time
-                         "concurrent_pipelines": ctx.get_option("pipes")},
+                       "device": name, "cus": cus, "backend": (args.backend or "nccl") if world > 1 else None},
+            "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": per_rank_ms,
         }
-        if solo is not None:
-            n1, m1, e1, c1, solo_wall = solo
-            b1 = algorithmic_bytes(c1, p) - 40.0 * float(c1[capi.C_PATHS])
-            out["roofline"]["single_pipeline"] = {
-                "what": "one extra untimed step with MER_PIPES=1: K_march launches that have the chip to themselves",
-                "kernel_avg_launch_ms": m1 / max(n1, 1), "launches_per_step": n1, "algorithmic_bytes_per_launch": b1 / max(n1, 1),
-                "achieved": b1 / max(n1, 1) / (m1 / max(n1, 1) * 1e-3) / 1e9 if m1 > 0 else 0.0,
-                "frac": (b1 / max(n1, 1) / (m1 / max(n1, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS) if m1 > 0 else 0.0,
-                "kernel_ms_per_step": m1, "event_kernel_ms_per_step": e1, "step_wall_ms": solo_wall * 1e3,
-                "active_lane_fraction": float(c1[capi.C_ACTIVE_LANES] / max(c1[capi.C_LOOP_ITERS], 1.0))}
-        # HBM traffic cannot be counted inside this process: it comes from separate `rocprofv3 --pmc` passes of this very
-        # command (FETCH_SIZE / WRITE_SIZE, gfx950 read correction applied), committed under profiles/
-        tf = os.path.join(ROOT, "profiles", "round1", "pmc_traffic_cfg3_n1.json")
-        if args.workload == "cfg3" and args.res == 256 and args.size == 512 and args.spp == 256 and args.layout == "brick27" and os.path.exists(tf):
-            try:
-                t = json.load(open(tf))["march_kernel"]
-                out["roofline"]["traffic"] = t["traffic_bytes_per_launch_with_gfx950_x2_read_correction"]
-                out["roofline"]["traffic_source"] = "profiles/round1/pmc_traffic_cfg3_n1.json (separate rocprofv3 --pmc passes; bytes per K_march launch)"
-            except Exception:
-                pass
+        if solo is not None and p.rif_mode != 0:
+            timed = (float(np.mean(kernel_ms)), float(np.mean(march_ms)), float(np.mean(event_ms)), float(np.mean(passes)),
+                     counters / max(args.steps, 1), pipes)
+            out["roofline"] = roofline_block(ctx, capi, p, tag, solo, timed, args.layout)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(p, args.cpu_seconds)
+            if p.density is None:
+                pc, _ = scene_params(args.workload, args.res, args.size, with_fields=True)
+            else:
+                pc = p
+            out["cpu_baseline"] = cpu_baseline(pc, args.cpu_seconds)
+        # the north star's target volume (512^3) in the same run: two steps + its CPU baseline on a bounded sample
+        if (args.workload == "cfg3" and args.res == 256 and world == 1 and not args.no_target_512 and not args.no_cpu_baseline):
+            for v in vols:
+                v.destroy()
+            vols = []
+            p5, d5 = scene_params("cfg3", 512, args.size, with_fields=False)
+            sc5, v5 = upload(ctx, "cfg3", 512, p5, capi.LAYOUT_BRICK27)
+            film.zero_(); ctx.render(sc5, film.data_ptr(), 0, args.spp, seed=50); torch.cuda.synchronize()       # warm-up
+            ts = time.perf_counter()
+            for i in range(2):
+                film.zero_(); ctx.render(sc5, film.data_ptr(), 0, args.spp, seed=60 + i)
+            torch.cuda.synchronize(); dt5 = (time.perf_counter() - ts) / 2
+            with ctx.options(pipes=1):
+                ctx.counters_reset(); film.zero_(); t1 = time.perf_counter()
+                ctx.render(sc5, film.data_ptr(), 0, args.spp, seed=70); torch.cuda.synchronize(); w5 = time.perf_counter() - t1
+                n5, m5, e5 = ctx.last_render_stats(); c5 = ctx.counters().astype(np.float64)
+            t512 = {"workload": d5 + ", %d^2 x %d spp" % (args.size, args.spp), "value": p5.width * p5.height * args.spp / dt5 / 1e6, "unit": "Mpaths/s",
+                    "ms_per_step": dt5 * 1e3, "steps": 2,
+                    "roofline": roofline_block(ctx, capi, p5, workload_tag("cfg3", 512, args.size), (n5, m5, e5, c5, w5), None, "brick27")}
+            pc5, _ = scene_params("cfg3", 512, args.size, with_fields=True)
+            t512["cpu_baseline"] = cpu_baseline(pc5, 12.0)
+            t512["gpu_over_cpu"] = t512["value"] / t512["cpu_baseline"]["value"]
+            out["target_512"] = t512
+            for v in v5:
+                v.destroy()
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -595,6 +595,40 @@ __device__ __forceinline__ f3 shape_normal(const mer_scene_desc &s, f3 x) {
 // test selects the result (same integer contract and blend order as lookup_float).  The branching form -- an early return inside
 // the marching loops of K_connect -- was miscompiled by this toolchain at -O2 and above when the lanes of a wave diverge
 // (scratch/miscompile/: 1 of 64 connections found against 61 at -O1).
+#ifdef MER_SDF_BRANCHING          // scratch/miscompile/pl.hip only: round 1's form, kept to reproduce the miscompile
+__device__ __forceinline__ float lookup_float_branching(const DGrid &g, f3 p, int *idx4 = nullptr) {
+    const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
+    const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
+    if (idx4) { idx4[0] = x1; idx4[1] = y1; idx4[2] = z1; idx4[3] = -1; }
+    // x2 = x1 + 1 >= res, written so that it cannot wrap: v_cvt_i32_f32 saturates, a coordinate of +inf (or >= 2^31) gives
+    // x1 = INT_MAX, and INT_MAX + 1 would pass the test and fetch from a wild address
+    if (x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1) return 0.0f;
+    const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
+                _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
+    const int base = (z1 * g.res[1] + y1) * g.res[0] + x1;
+    if (idx4) idx4[3] = base;
+    float d000, d001, d010, d011, d100, d101, d110, d111;
+    if (g.layout == MER_LAYOUT_CELL8) {
+        const int cell = (z1 * (g.res[1] - 1) + y1) * (g.res[0] - 1) + x1;
+        const float4 *c = (const float4 *) (g.cell8 + (size_t) MER_CHK(g.chk, CHK_GRID_RECORD, (size_t) cell * 8, g.n_record - 7));
+        const float4 a = c[0], b = c[1];
+        d000 = a.x; d001 = a.y; d010 = a.z; d011 = a.w; d100 = b.x; d101 = b.y; d110 = b.z; d111 = b.w;
+    } else {
+        const int sy = g.res[0], sz = g.res[0] * g.res[1];
+        d000 = grid_fetch(g, base);          d001 = grid_fetch(g, base + 1);
+        d010 = grid_fetch(g, base + sy);     d011 = grid_fetch(g, base + sy + 1);
+        d100 = grid_fetch(g, base + sz);     d101 = grid_fetch(g, base + sz + 1);
+        d110 = grid_fetch(g, base + sz + sy); d111 = grid_fetch(g, base + sz + sy + 1);
+    }
+    return ((d000 * _fx + d001 * fx) * _fy + (d010 * _fx + d011 * fx) * fy) * _fz +
+           ((d100 * _fx + d101 * fx) * _fy + (d110 * _fx + d111 * fx) * fy) * fz;
+}
+__device__ __forceinline__ float sdf_value(const Params &P, f3 p) {
+    int idx4[4];
+    const float v = lookup_float_branching(P.sdf, p, idx4);
+    return idx4[3] >= 0 ? v : 1e30f;
+}
+#else
 __device__ __forceinline__ float sdf_value(const Params &P, f3 p) {
     const DGrid &g = P.sdf;
     const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
@@ -609,6 +643,7 @@ __device__ __forceinline__ float sdf_value(const Params &P, f3 p) {
                     ((d100 * _fx + d101 * fx) * _fy + (d110 * _fx + d111 * fx) * fy) * fz;
     return inside ? v : 1e30f;
 }
+#endif
 template <int BND> __device__ __forceinline__ bool inside_shape_b(const Params &P, f3 p) {
     if (BND == 0) return inside_shape(P.sc, p);
     return sdf_value(P, p) < 0.0f;

@@ -1,4 +1,10 @@
-// Reproducer: Connector<RIF,BND>::path_lengths on one known pair, standalone (no libmer).  Build at -O3 and -O1 and compare.
+// Reproducer of the K_connect miscompile: Connector<RIF,BND>::connect on 64 different pairs, standalone (no libmer).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-math-errno -fno-slp-vectorize -DMER_SDF_BRANCHING -o pl_O3_branching pl.hip
+//   ... -O1 -DMER_SDF_BRANCHING -o pl_O1_branching      ... -O3 -o pl_O3
+// MER_SDF_BRANCHING selects round 1's sdf_value (lookupFloat with its early `return 0` for a point off the grid).  Measured on MI355X,
+// ROCm 7.2.0: "connect BND=1" finds 1 of 64 connections at -O3 (and -O2) with the branching form, 61 of 64 at -O1, and 61 of 64 at -O3
+// with the branch-free form that ships; BND=0 (no grid look-up in the inside test) finds 61 of 64 in every build.  With 64 identical
+// pairs (no lane divergence) the -O3 branching build is correct too.
 #include "../../mitsubaer_amd/csrc/mer_connect.hpp"
 #include <cstdio>
 #include <vector>

@@ -1,12 +1,19 @@
 #!/bin/bash
-# usage: scratch/pmc_pass.sh <tag> <bench args quoted> <counters...>   (run from the repo root on the GPU box)
-tag=$1; shift; bargs=$1; shift
-out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
+# One rocprofv3 counter pass (run from the repo root ON THE GPU BOX): scratch/pmc_pass.sh <outdir under gpurun_out> <counters (space separated, quoted)> -- <program and args>
+# Counters are collected in their own run with --kernel-trace only (the pool refuses --pmc together with the hip/hsa/memory trace domains).
+out=$GRAFT_REPO_ROOT/gpurun_out/$1; ctr=$2; shift; shift; [ "$1" == "--" ] && shift
 rm -rf $out; mkdir -p $out
+prog=$1; shift
+case "$prog" in /*) ;; *) prog=$GRAFT_REPO_ROOT/$prog;; esac
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/bench.py $bargs --steps 1 --warmup 0 --no-cpu-baseline > $out/bench.json 2> $out/bench.err
-echo "pass $tag rc=$?"
+if [[ "$prog" == *.py ]]; then
+  timeout -k 10 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -- python3 $prog "$@" > $out/stdout.txt 2> $out/stderr.txt
+else
+  timeout -k 10 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -- $prog "$@" > $out/stdout.txt 2> $out/stderr.txt
+fi
+rc=$?
 cd $GRAFT_REPO_ROOT
-python3 scratch/pmc_sum.py $out > gpurun_out/pmc_$tag.txt 2>&1
+python3 scratch/pmc_sum.py $out > $out/summary.txt 2>&1
 find $out -name "*.csv" -size +1M -delete
+echo "pmc pass $out [$ctr] rc=$rc"
 exit 0

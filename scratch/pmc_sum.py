@@ -1,12 +1,23 @@
-import csv, glob, sys, collections
+"""Sums the counters of one rocprofv3 --pmc pass per kernel family: usage pmc_sum.py <pass dir> [--json]"""
+import csv, glob, json, sys, collections, re
 d = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(int)
+
+
+def family(k):
+    m = re.match(r"(?:void )?(?:mer::)?([A-Za-z_0-9]+)", k)
+    return m.group(1) if m else k[:40]
+
+
 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:60]
+        k = family(r["Kernel_Name"])
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         n[(k, r["Counter_Name"])] += 1
-for k in acc:
-    print(k)
-    for c, v in sorted(acc[k].items()):
-        print("   %-44s %.6g   (dispatches %d)" % (c, v, n[(k, c)]))
+if "--json" in sys.argv:
+    print(json.dumps({k: {c: {"sum": v, "dispatches": n[(k, c)]} for c, v in cs.items()} for k, cs in acc.items()}))
+else:
+    for k in sorted(acc):
+        print(k)
+        for c, v in sorted(acc[k].items()):
+            print("   %-44s %.6g   (dispatches %d)" % (c, v, n[(k, c)]))
