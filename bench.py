@@ -319,6 +319,10 @@ def main():
                        "stepsize": p.stepsize, "estimator": "volpath + delta tracking on eikonal rays, ratio-tracking NEE",
                        "device": name, "cus": cus, "backend": (args.backend or "nccl") if world > 1 else None},
             "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": per_rank_ms,
+            # device counters of rank 0, per step of the timed region (inputs of SURVEY section 8d's byte formula)
+            "counters_per_step": {"paths": counters[capi.C_PATHS] / max(args.steps, 1), "eikonal_steps": counters[capi.C_STEPS] / max(args.steps, 1),
+                                  "tentative_collisions": counters[capi.C_TENTATIVE] / max(args.steps, 1), "real_collisions": counters[capi.C_REAL] / max(args.steps, 1),
+                                  "lane_slots": counters[capi.C_LOOP_ITERS] / max(args.steps, 1), "active_lane_steps": counters[capi.C_ACTIVE_LANES] / max(args.steps, 1)},
         }
         if solo is not None and p.rif_mode != 0:
             timed = (float(np.mean(kernel_ms)), float(np.mean(march_ms)), float(np.mean(event_ms)), float(np.mean(passes)),

@@ -1,34 +1,53 @@
 #!/usr/bin/env python3
-"""Aggregates the FETCH_SIZE / WRITE_SIZE passes (rocprofv3 --pmc, one bench step each) into profiles/round1/pmc_traffic_cfg3_n1.json.
-usage: pmc_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> <bench json of one of the passes> <out json>"""
-import csv, glob, json, sys, collections
+"""Merges the rocprofv3 --pmc passes of one workload (scratch/pmc_all.sh <tag> ...) into profiles/round2/hbm_traffic.json[<bench tag>].
 
-def collect(d, counter):
-    tot = collections.defaultdict(float); n = collections.defaultdict(int)
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
-                continue
-            k = r["Kernel_Name"]
-            fam = "march_kernel" if "march_kernel" in k else "event_kernel" if "event_kernel" in k else "gen_kernel" if "gen_kernel" in k else None
-            if fam:
-                tot[fam] += float(r["Counter_Value"]); n[fam] += 1
-    return tot, n
+  python scratch/pmc_traffic.py <pass tag> <bench tag> [limiter text]
 
-fd, wd, bj, out = sys.argv[1:5]
-ft, fn = collect(fd, "FETCH_SIZE"); wt, wn = collect(wd, "WRITE_SIZE")
-bench = json.loads(open(bj).read().strip().splitlines()[-1])
-res = {}
-for fam in ("gen_kernel", "event_kernel", "march_kernel"):
-    res[fam] = {"FETCH_SIZE_KiB_sum": ft.get(fam, 0.0), "launches": fn.get(fam, 0), "WRITE_SIZE_KiB_sum": wt.get(fam, 0.0)}
-m = res["march_kernel"]
-if m["launches"]:
-    rf = m["FETCH_SIZE_KiB_sum"] * 1024 / m["launches"]; rw = m["WRITE_SIZE_KiB_sum"] * 1024 / max(wn.get("march_kernel", 1), 1)
-    alg = bench["roofline"]["algorithmic_bytes_per_launch"]
-    m.update({"raw_fetch_bytes_per_launch": rf, "raw_write_bytes_per_launch": rw,
-              "traffic_bytes_per_launch_with_gfx950_x2_read_correction": 2 * rf + rw, "algorithmic_bytes_per_launch": alg,
-              "traffic_over_algorithmic": (2 * rf + rw) / alg})
-res["note"] = ("one bench step (512^2 x 256 spp, cfg3, K = %d passes) per PMC pass, separate --pmc passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled per "
-               "MI355X_MICROARCH.md (16-B-per-lane reads report half); uncalibrated for gathers" % int(bench["roofline"]["launches_per_step"]))
-json.dump(res, open(out, "w"), indent=1)
-print(json.dumps(res["march_kernel"]))
+Memory-side read bytes of a kernel = 128 x TCC_EA0_RDREQ_128B_sum + 64 x TCC_EA0_RDREQ_64B_sum + 32 x TCC_EA0_RDREQ_32B_sum: the
+requests L2 sends to the fabric, by size (on gfx950 FETCH_SIZE tallies the 128-byte requests at 64 bytes, so 2 x FETCH_SIZE is the
+same number: MI355X_MICROARCH.md, HBM; checked on patterns of known byte count by scratch/ubench/hbm_calib.hip,
+profiles/round2/hbm_counter_calibration.txt).  Write bytes = WRITE_SIZE.  Infinity-Cache hits are included: this is the traffic
+beyond L2, an upper bound of the HBM traffic."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, btag = sys.argv[1], sys.argv[2]
+limiter = sys.argv[3] if len(sys.argv) > 3 else None
+
+
+def sums(kind):
+    d = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, kind))
+    out = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "scratch", "pmc_sum.py"), d, "--json"]))
+    return out.get("march_kernel", {}), d
+
+
+rd, d_rd = sums("rd"); fe, _ = sums("fetch"); wr, _ = sums("write"); l2, _ = sums("l2"); sq, _ = sums("sq"); sq2, _ = sums("sq2")
+bench = json.loads(open(os.path.join(d_rd, "stdout.txt")).read().strip().splitlines()[-1])
+c = bench["counters_per_step"]
+steps = c["eikonal_steps"]; wave_steps = c["lane_slots"] / 64.0
+v = lambda d, k: d.get(k, {}).get("sum", 0.0)
+read_b = 128 * v(rd, "TCC_EA0_RDREQ_128B_sum") + 64 * v(rd, "TCC_EA0_RDREQ_64B_sum") + 32 * v(rd, "TCC_EA0_RDREQ_32B_sum")
+write_b = 1024 * v(wr, "WRITE_SIZE")
+entry = {
+    "method": "rocprofv3 --pmc, separate passes of one single-pipeline bench step each (scratch/pmc_all.sh %s): read = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B, write = WRITE_SIZE; includes Infinity-Cache hits" % tag,
+    "workload": bench["config"]["workload"], "march_launches": rd.get("TCC_EA0_RDREQ_sum", {}).get("dispatches"),
+    "eikonal_steps": steps, "wave_steps": wave_steps,
+    "read_bytes": read_b, "write_bytes": write_b, "two_x_FETCH_SIZE_bytes": 2 * 1024 * v(fe, "FETCH_SIZE"),
+    "hbm_bytes_per_eikonal_step": (read_b + write_b) / steps,
+    "rdreq": {k: v(rd, k) for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_128B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_32B_sum")},
+    "l2": {"TCC_REQ": v(l2, "TCC_REQ_sum"), "TCC_HIT": v(l2, "TCC_HIT_sum"), "TCC_MISS": v(l2, "TCC_MISS_sum"),
+           "hit_rate": v(l2, "TCC_HIT_sum") / max(v(l2, "TCC_HIT_sum") + v(l2, "TCC_MISS_sum"), 1.0),
+           "l2_requests_per_eikonal_step": v(l2, "TCC_REQ_sum") / steps},
+    "sq": {k: v(sq, k) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY")},
+    "sq2": {k: v(sq2, k) for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "GRBM_GUI_ACTIVE")},
+    "valu_inst_per_wave_step": v(sq, "SQ_INSTS_VALU") / max(wave_steps, 1.0),
+    "wave_time_split": {"waiting_on_memory_or_barrier (SQ_WAIT_ANY)": v(sq2, "SQ_WAIT_ANY") / max(v(sq, "SQ_WAVE_CYCLES"), 1.0),
+                        "issue_stall (SQ_WAIT_INST_ANY)": v(sq, "SQ_WAIT_INST_ANY") / max(v(sq, "SQ_WAVE_CYCLES"), 1.0),
+                        "issuing (SQ_ACTIVE_INST_ANY)": v(sq2, "SQ_ACTIVE_INST_ANY") / max(v(sq, "SQ_WAVE_CYCLES"), 1.0)},
+}
+if limiter:
+    entry["limiter"] = limiter
+path = os.path.join(ROOT, "profiles", "round2", "hbm_traffic.json")
+allv = json.load(open(path)) if os.path.exists(path) else {}
+allv[btag] = entry
+json.dump(allv, open(path, "w"), indent=1)
+print(btag, "hbm bytes / eikonal step %.1f, L2 hit rate %.3f, VALU / wave-step %.0f" % (entry["hbm_bytes_per_eikonal_step"], entry["l2"]["hit_rate"], entry["valu_inst_per_wave_step"]))

@@ -135,3 +135,42 @@ def test_cfg3_at_512_cubed(ctx):
     assert np.array_equal(ctx.render_paths(sd, 1, seed=9), a)
     for v in vd:
         v.destroy()
+
+
+def test_configs3_at_1024_cubed(ctx):
+    """BASELINE configs[3] at its full sizes: 1024^3 sigma_t + 1024^3 radial RIF (createRadialRIFWithBox.m), 1024^2 film.  The CELL8
+    records are 32 GiB per field: no buffer descriptor reaches them (the global-load kernels run) and the march lists stay unsorted
+    (> 2^28 nodes), which is what the 8-GPU job runs on every rank.  The oracle would need hours here; checked instead:
+    the 8 image-tile shards of the job add up to the unsharded film, emitter linearity bit for bit, determinism, and Bouguer's
+    invariant |r x n d| of a spherically symmetric index along eikonal rays traced through the same records."""
+    import bench
+    NN, W = 1024, 1024
+    p, _ = bench.scene_params("cfg4", NN, W, with_fields=False)
+    sc, vols = bench.upload(ctx, "cfg4", NN, p, capi.LAYOUT_CELL8)
+    assert ctx.get_option("buffer_loads") == 1 and ctx.get_option("mq_sort") == -1          # nothing forced: the sizes select the kernels
+    full = ctx.render_to_host(sc, 0, 1, seed=5)
+    assert np.isfinite(full).all() and full[..., 4].min() > 0.99 and full[..., :3].max() > 0
+    tiles = sum(ctx.render_to_host(sc, 0, 1, seed=5, tile_rank=r, tile_count=8) for r in range(8))
+    assert np.allclose(full, tiles, rtol=1e-4, atol=1e-4)
+    a = ctx.render_paths(sc, 0, seed=5)
+    assert np.array_equal(a, ctx.render_paths(sc, 0, seed=5))                               # determinism
+    sc.env_radiance[:] = [0.5, 0.5, 0.5]
+    assert np.array_equal(ctx.render_paths(sc, 0, seed=5), 0.5 * a)                         # emitter linearity, bit for bit
+    sc.env_radiance[:] = [1.0, 1.0, 1.0]
+    # the film is the box-filtered image of the paths: same samples, same radiance
+    assert abs(full[..., :3].sum() / full[..., 4].sum() - a.mean()) < 1e-3 * a.mean()
+    # Bouguer: n(r) r sin(angle between r and the ray) is constant along a ray of a radial field; v = n d, so |p x v| is
+    rng = np.random.RandomState(3)
+    n = 4096
+    p0 = rng.uniform(-0.5, 0.5, (n, 3)).astype(np.float32)
+    d0 = rng.normal(size=(n, 3)); d0 = (d0 / np.linalg.norm(d0, axis=1, keepdims=True)).astype(np.float32)
+    n0, _ = ctx.rif_value_grad(vols[1], P.RIF_TRILINEAR, p0)
+    op, ov, ds, oo, ok = ctx.er_trace(sc, p0, d0, np.full(n, 0.4, np.float32))
+    assert ok.all() and np.abs(ds - 0.4).max() < 1e-4
+    inv0 = np.linalg.norm(np.cross(p0.astype(np.float64), d0.astype(np.float64) * n0[:, None]), axis=1)
+    inv1 = np.linalg.norm(np.cross(op.astype(np.float64), ov.astype(np.float64)), axis=1)
+    assert np.abs(inv1 - inv0).max() < 2e-4, np.abs(inv1 - inv0).max()
+    n1, _ = ctx.rif_value_grad(vols[1], P.RIF_TRILINEAR, op)
+    assert np.abs(np.linalg.norm(ov, axis=1) - n1).max() < 2e-4                             # |v| = n along the ray
+    for v in vols:
+        v.destroy()
