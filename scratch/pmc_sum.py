@@ -9,7 +9,9 @@ def family(k):
     return m.group(1) if m else k[:40]
 
 
-for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+import os
+files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+for f in files[-1:]:          # one pass = one process; a directory merged from several gpurun calls keeps older files: newest only
     for r in csv.DictReader(open(f)):
         k = family(r["Kernel_Name"])
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
