@@ -322,7 +322,10 @@ def main():
             # device counters of rank 0, per step of the timed region (inputs of SURVEY section 8d's byte formula)
             "counters_per_step": {"paths": counters[capi.C_PATHS] / max(args.steps, 1), "eikonal_steps": counters[capi.C_STEPS] / max(args.steps, 1),
                                   "tentative_collisions": counters[capi.C_TENTATIVE] / max(args.steps, 1), "real_collisions": counters[capi.C_REAL] / max(args.steps, 1),
-                                  "lane_slots": counters[capi.C_LOOP_ITERS] / max(args.steps, 1), "active_lane_steps": counters[capi.C_ACTIVE_LANES] / max(args.steps, 1)},
+                                  "lane_slots": counters[capi.C_LOOP_ITERS] / max(args.steps, 1), "active_lane_steps": counters[capi.C_ACTIVE_LANES] / max(args.steps, 1),
+                                  "connections": counters[capi.C_NEE] / max(args.steps, 1) if any(p.point_intensity) else 0.0,
+                                  "connect_units": counters[capi.C_CONNECT_UNITS] / max(args.steps, 1), "connect_steps": counters[capi.C_CONNECT_STEPS] / max(args.steps, 1),
+                                  "connect_lane_slots": counters[capi.C_CONNECT_LANE_SLOTS] / max(args.steps, 1)},
         }
         if solo is not None and p.rif_mode != 0:
             timed = (float(np.mean(kernel_ms)), float(np.mean(march_ms)), float(np.mean(event_ms)), float(np.mean(passes)),

@@ -130,7 +130,11 @@ typedef struct {
 
 enum {
     MER_C_PATHS = 0, MER_C_STEPS, MER_C_RIF_EVALS, MER_C_TENTATIVE, MER_C_REAL,
-    MER_C_SEGMENTS, MER_C_NEE, MER_C_LOOP_ITERS, MER_C_ACTIVE_LANES, MER_C_COUNT = 16
+    MER_C_SEGMENTS, MER_C_NEE, MER_C_LOOP_ITERS, MER_C_ACTIVE_LANES,
+    MER_C_CONNECT_UNITS,        /* solver units (traced rays) K_connect ran: a connection costs 3 ... 100+ */
+    MER_C_CONNECT_STEPS,        /* sensitivity / Verlet steps inside them */
+    MER_C_CONNECT_LANE_SLOTS,   /* 64 x the steps of the longest unit of every K_connect wave: CONNECT_STEPS / this = its active-lane fraction */
+    MER_C_COUNT = 16
 };
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -152,7 +156,7 @@ int  mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu
      ksteps         eikonal steps / tentative collisions per lane per K_march launch (default 128)
      mq_sort        march lists sorted by steps-to-boundary class: -1 by field size (default), 0 off, 1 on
      cell_sort      march lists additionally ordered by coarse spatial cell: -1 by field size (default), 0 off, 1 on
-     connect_every  passes over which curved-ray connection requests gather before K_connect runs (default 4)
+     connect_launches  K_connect launches per pass: each runs one solver unit (one traced ray) per pending curved-ray connection (default 2)
      adaptive_k     longer passes in the tail of a render (default 1)
      pass_events    per-pass HIP events feeding mer_last_render_stats (default 1)
      buffer_loads   0 = read fields with global loads even below 4 GiB, i.e. run the kernels a >= 4 GiB field selects (default 1)

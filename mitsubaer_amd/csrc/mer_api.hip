@@ -327,7 +327,7 @@ int mer_context_create(int32_t device_id, mer_context **out) {
 static int64_t *option_slot(mer_context *ctx, const char *name) {
     Options &o = ctx->opt;
     const struct { const char *n; int64_t *p; } table[] = {
-        {"pipes", &o.pipes}, {"nslots", &o.nslots}, {"ksteps", &o.ksteps}, {"mq_sort", &o.mq_sort}, {"connect_every", &o.connect_every},
+        {"pipes", &o.pipes}, {"nslots", &o.nslots}, {"ksteps", &o.ksteps}, {"mq_sort", &o.mq_sort}, {"connect_launches", &o.connect_launches},
         {"adaptive_k", &o.adaptive_k}, {"pass_events", &o.pass_events}, {"buffer_loads", &o.buffer_loads}, {"gen_all", &o.gen_all},
         {"prefilter", &o.prefilter}, {"verbose", &o.verbose}, {"debug_pixel", &o.debug_pixel}, {"cell_sort", &o.cell_sort}};
     for (const auto &t : table) if (std::strcmp(t.n, name) == 0) return t.p;
@@ -339,7 +339,7 @@ int mer_context_set_option(mer_context *ctx, const char *name, int64_t value) {
     if (!p) return fail(ctx, std::string("unknown option '") + name + "'");
     const std::string n(name);
     if ((n == "pipes" && (value < 1 || value > MER_MAX_PIPES)) || (n == "ksteps" && (value < 1 || value > (1 << 20))) ||
-        (n == "connect_every" && (value < 1 || value > 1024)) || (n == "nslots" && (value < 0 || value > ((int64_t) 1 << 28))) ||
+        (n == "connect_launches" && (value < 1 || value > 1024)) || (n == "nslots" && (value < 0 || value > ((int64_t) 1 << 28))) ||
         (n == "prefilter" && (value < 0 || value > 4)))
         return fail(ctx, std::string("option '") + name + "': value out of range");
     *p = value;
@@ -377,7 +377,8 @@ void mer_context_destroy(mer_context *ctx) {
     for (Pipe &pp : ctx->pipes) {
         if (pp.slots) (void) hipFree(pp.slots);
         if (pp.live) (void) hipFree(pp.live);
-        for (SegQueue *q : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq}) { if (q->items) (void) hipFree(q->items); if (q->counts) (void) hipFree(q->counts); }
+        for (SegQueue *q : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq[0], &pp.cq[1]}) { if (q->items) (void) hipFree(q->items); if (q->counts) (void) hipFree(q->counts); }
+        if (pp.cstate) (void) hipFree(pp.cstate);
         if (pp.hitq) (void) hipFree(pp.hitq);
         if (pp.hitq_ctr) (void) hipFree(pp.hitq_ctr);
         if (pp.host_live) (void) hipHostFree(pp.host_live);

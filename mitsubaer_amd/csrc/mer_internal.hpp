@@ -28,7 +28,8 @@ struct Volume {
 struct Pipe {
     hipStream_t stream = nullptr, own_stream = nullptr;      // pipeline 0 runs on the context stream
     uint32_t *slots = nullptr; uint32_t nslots = 0; uint32_t *live = nullptr; uint32_t *host_live = nullptr;
-    SegQueue eq{}, mq[2]{}, sq[2]{}, cq{};
+    SegQueue eq{}, mq[2]{}, sq[2]{}, cq[2]{};
+    uint32_t *cstate = nullptr; uint32_t cstate_slots = 0;        // parked solver states of K_connect (allocated on first use)
     unsigned long long *hitq = nullptr, *hitq_ctr = nullptr; unsigned long long hitq_cap = 0;
     hipEvent_t readback[2] = {nullptr, nullptr}, finished = nullptr;     // two batches in flight per pipeline
     std::vector<hipEvent_t> pass_events;          // 3 per pass: before K_event, between, after K_march
@@ -40,7 +41,7 @@ struct Options {
     int64_t nslots = 0;           // path-state slots over all pipelines; 0 = 4 x the resident lanes of the chip
     int64_t ksteps = 128;         // eikonal steps / tentative collisions per lane per K_march launch
     int64_t mq_sort = -1;         // march lists sorted by steps-to-boundary class: -1 = by field size, 0 / 1 = off / on
-    int64_t connect_every = 4;    // passes over which connection requests gather before K_connect runs
+    int64_t connect_launches = 2;    // K_connect launches per pass (one solver unit per pending connection per launch; 1-3 measured equal, 6+ slower)
     int64_t adaptive_k = 1;       // lengthen passes in the tail of a render
     int64_t pass_events = 1;      // per-pass HIP events (mer_last_render_stats)
     int64_t buffer_loads = 1;     // 0: global loads even for fields below 4 GiB (the kernels a >= 4 GiB field selects)
@@ -93,12 +94,8 @@ int rif_fetch_kind(mer_context *ctx, const mer_scene_desc *sc);
 
 // mer_render.hip: one render = a few independent pipelines of K_gen / K_event / [K_connect] / K_march passes
 struct Run {
-    Params P; uint32_t nslots = 0, pass = 0, since_connect = 0; unsigned blocks = 0, gen_blocks = 0;
-    int connect_every = 1, cur = 0; bool work_left = true, done = false;
-};
-struct RenderJob {
-    mer_context *ctx; const mer_scene_desc *scene;
-    Run runs[MER_MAX_PIPES]; int npipes; int ksteps0, connect_every0;
+    Params P; uint32_t nslots = 0, pass = 0; unsigned blocks = 0, gen_blocks = 0;
+    int cur = 0; bool work_left = true, done = false;
 };
 // the kernels of one (CURVED, RIF, STEPPER, SIGMA, BND) combination, as launchable function pointers
 typedef void (*GenKernel)(const Params);

@@ -69,9 +69,8 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
     // (256^3: +8 %, 512^3: +3 %), a loss once every fetch goes to HBM (1024^3: -4 %)
     P.mq_sort = opt.mq_sort >= 0 ? (opt.mq_sort != 0) : ((int64_t) P.rif.res[0] * P.rif.res[1] * P.rif.res[2] <= ((int64_t) 1 << 28) ? 1 : 0);
     P.gen_iters = 8; P.gen_all = opt.gen_all ? 1 : 0;
-    // Connection requests gather in one row of cq over connect_every passes (the parked slots wait, the others keep marching) and
-    // K_connect drains the row at the end of the group: fuller launches, 5-8 % on configs[4]; in the tail it runs every pass.
-    const int connect_every0 = (int) opt.connect_every;
+    // K_connect runs one solver unit (one traced ray) per pending connection per launch: several launches per pass
+    const int connect_launches = (int) opt.connect_launches;
     // K_gen: one launch = gen_blocks x 4 waves x 64 x gen_iters work ids
     const unsigned gen_blocks_max = std::max(1u, std::min(want / MER_BLOCK, 1024u));
     const unsigned long long ids_per_launch = (unsigned long long) gen_blocks_max * (MER_BLOCK / 64) * 64ull * (unsigned long long) P.gen_iters;
@@ -93,13 +92,13 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
             if (pp.hitq) (void) hipFree(pp.hitq);
             pp.slots = nullptr; pp.hitq = nullptr; pp.nslots = 0;
             HIP_CHECK(ctx, hipMalloc((void **) &pp.slots, (size_t) cap * MER_SLOT_WORDS * sizeof(uint32_t)));
-            for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq}) {
+            for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq[0], &pp.cq[1]}) {
                 if (sq->items) (void) hipFree(sq->items);
                 sq->items = nullptr;
                 sq->segcap = 2u * (cap / MER_NSEG) + 256u;          // two producer kernels may feed one segment
                 if (sq == &pp.eq) sq->segcap = 2u * (cap / (MER_NSEG / MER_EV_CLASSES)) + 256u;   // every lane may be of one event class
                 if (sq == &pp.mq[0] || sq == &pp.mq[1]) sq->segcap = 2u * (cap / (MER_NSEG / MER_MQ_CLASSES)) + 256u;   // ... or of one march class
-                if (sq == &pp.cq) sq->segcap = cap + 256u;   // requests gather over several passes: a segment may see every slot once
+                if (sq == &pp.cq[0] || sq == &pp.cq[1]) sq->segcap = cap + 256u;   // every slot may be pending, in one class
                 HIP_CHECK(ctx, hipMalloc((void **) &sq->items, (size_t) sq->segcap * MER_NSEG * sizeof(uint32_t)));
                 if (!sq->counts) HIP_CHECK(ctx, hipMalloc((void **) &sq->counts, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t)));
                 sq->chk = ctx->chk;
@@ -125,17 +124,23 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         const uint64_t need_slots = (R.P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
         if (need_slots < R.nslots) R.nslots = (uint32_t) need_slots;
         R.P.slots = pp.slots; R.P.nslots = R.nslots; R.P.live = pp.live; R.P.eq = pp.eq; R.P.mq[0] = pp.mq[0]; R.P.mq[1] = pp.mq[1];
-        R.P.sq[0] = pp.sq[0]; R.P.sq[1] = pp.sq[1]; R.P.cq = pp.cq;
+        R.P.sq[0] = pp.sq[0]; R.P.sq[1] = pp.sq[1]; R.P.cq[0] = pp.cq[0]; R.P.cq[1] = pp.cq[1];
+        if (connect_stage && pp.cstate_slots < pp.nslots) {
+            if (pp.cstate) (void) hipFree(pp.cstate);
+            pp.cstate = nullptr; pp.cstate_slots = 0;
+            HIP_CHECK(ctx, hipMalloc((void **) &pp.cstate, (size_t) pp.nslots * MER_CSTATE_WORDS * sizeof(uint32_t)));
+            pp.cstate_slots = pp.nslots;
+        }
+        R.P.cstate = pp.cstate;
         R.P.hitq = pp.hitq; R.P.hitq_cap = pp.hitq_cap; R.P.hitq_ctr = pp.hitq_ctr; R.P.work_counter = pp.hitq_ctr + 48;
         R.P.ksteps = ksteps0; R.P.cq_row = 0;
-        R.connect_every = connect_every0;
         R.done = R.P.total_work == 0;
         if (R.done) continue;
         R.blocks = R.nslots / MER_BLOCK;
         R.gen_blocks = std::max(1u, std::min(R.nslots / MER_BLOCK, gen_blocks_max));
         HIP_CHECK(ctx, hipMemsetAsync(pp.slots, 0, (size_t) R.nslots * MER_SLOT_WORDS * sizeof(uint32_t), pp.stream));
         HIP_CHECK(ctx, hipMemsetAsync(pp.live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), pp.stream));
-        for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq})
+        for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq[0], &pp.cq[1]})
             HIP_CHECK(ctx, hipMemsetAsync(sq->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), pp.stream));
         HIP_CHECK(ctx, hipMemsetAsync(pp.hitq_ctr, 0, 64 * sizeof(unsigned long long), pp.stream));
     }
@@ -156,9 +161,9 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
             if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 0], pp.stream));
             for (int g = 0; R.work_left && g < (pass == 0 ? 6 : 1); g++) hipLaunchKernelGGL(ks.gen, dim3(R.gen_blocks), dim3(MER_BLOCK), 0, pp.stream, R.P);
             hipLaunchKernelGGL(ks.event, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
-            if (connect_stage && ++R.since_connect >= (uint32_t) R.connect_every) {
+            for (int l = 0; connect_stage && l < connect_launches; l++) {
                 hipLaunchKernelGGL(ks.connect, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
-                R.since_connect = 0; R.P.cq_row++;
+                R.P.cq_row++;
             }
             if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 1], pp.stream));
             hipLaunchKernelGGL(ks.march, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
@@ -187,7 +192,6 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
             if (adaptive) {          // tail: few lanes left => longer passes, fewer launches
                 const uint32_t alive = R.nslots - finished_slots;
                 R.P.ksteps = alive < R.nslots / 64 ? ksteps0 * 32 : (alive < R.nslots / 16 ? ksteps0 * 8 : (alive < R.nslots / 4 ? ksteps0 * 2 : ksteps0));
-                R.connect_every = alive < R.nslots / 4 ? 1 : connect_every0;
             }
             if (R.pass > (1u << 24)) return fail(ctx, "mer_render: pass limit exceeded");
             if (enqueue_batch(q, rb)) return 1;

@@ -180,6 +180,16 @@ __device__ __forceinline__ void queue_push(const SegQueue &q, uint32_t row, bool
 //    the lanes of a wave park at about the same trip of K_march's loop instead of idling until the slowest one has.
 #define MER_EV_CLASSES 4
 #define MER_MQ_CLASSES 8
+#define MER_CQ_CLASSES 8
+// class of a pending connection: the length of the rays its solver traces (the chord to the emitter over the size of the shape), longest first
+__device__ __forceinline__ int connect_class(const Params &P, f3 ps) {
+    const mer_scene_desc &S = P.sc;
+    const f3 d(S.point_position[0] - ps.x, S.point_position[1] - ps.y, S.point_position[2] - ps.z);
+    float diag2 = 4.0f * S.sph_radius * S.sph_radius;
+    if (S.boundary != MER_BOUNDARY_SPHERE) { diag2 = 0; for (int k = 0; k < 3; k++) diag2 += (S.bmax[k] - S.bmin[k]) * (S.bmax[k] - S.bmin[k]); }
+    const float f = sqrtf(dot(d, d) * __builtin_amdgcn_rcpf(diag2)) * (float) (2 * MER_CQ_CLASSES);      // chords beyond half the diagonal share class 0
+    return max(0, MER_CQ_CLASSES - 1 - (int) f);
+}
 template <int NCLS>
 __device__ __forceinline__ void queue_push_class(const SegQueue &q, uint32_t row, bool pred, uint32_t i, int cls) {
     constexpr uint32_t SPC = MER_NSEG / NCLS;
@@ -341,9 +351,8 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
     const uint32_t count = nq + ns;
     // ring hygiene: the rows K_march / K_event of pass+1 will add to
     queue_clear_row(P.eq, pass + 2, j); queue_clear_row(P.mq[pass & 1u], pass + 2, j); queue_clear_row(P.sq[pass & 1u], pass + 2, j);
-    if (EXTRA && CURVED) queue_clear_row(P.cq, P.cq_row + 2, j);
     LaneCounters C; C.clear();
-    bool marching = false, starved_out = false, connecting = false; uint32_t i = 0; int mq_class = 0;
+    bool marching = false, starved_out = false, connecting = false; uint32_t i = 0; int mq_class = 0, cq_class = 0;
     if (j < count) {
     i = pass == 0 ? j : (j < nq ? queue_item(P.eq, pass, j) : queue_item(P.sq[pass & 1u], pass, j - nq));
     const uint32_t fl = SLOT(H_FLAGS);
@@ -542,7 +551,11 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             // Curved rays: the connection is a shooting problem of hundreds of sensitivity steps -- it gets a kernel of its
             // own (K_connect) in which every lane solves one; the path resumes at EV_PHASE2 in the next pass.
             if (EXTRA && hasPoint && ev == EV_PHASE) {
-                if (CURVED) { connecting = true; break; }
+                if (CURVED) {                        // park the slot: K_connect takes the connection from here (state CP_NEW)
+                    connecting = true; cq_class = connect_class(P, ps);
+                    P.cstate[(size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots) * MER_CSTATE_WORDS + MER_CSTATE_WORDS - 1] = (uint32_t) CP_NEW << 15;
+                    break;
+                }
                 float optLen = 0.0f;
                 const f3 c = T * point_nee<false, RIF, STEPPER, SIGMA, BND>(P, rng, C, ps, wi, depth, optLen);
                 L = L + mod_weight<EXTRA>(P, c, plen + optLen);
@@ -647,9 +660,8 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
 
     }
     }   // j < count
-    // requests of several passes gather in one row (launch_render).  Sorting them by distance to the emitter (the length of the ray
-    // every iterate of the shooting solver traces) was measured and changes nothing: the solves differ in their iteration counts
-    if (EXTRA && CURVED) queue_push(P.cq, P.cq_row, connecting, i);
+    // a new connection joins the pending ones of the next K_connect launch, grouped by the length of the rays its solver will trace
+    if (EXTRA && CURVED) queue_push_class<MER_CQ_CLASSES>(P.cq[P.cq_row & 1u], P.cq_row, connecting, i, cq_class);
     queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class);
     queue_push(P.sq[(pass + 1) & 1u], pass + 1, starved_out, i);
     flush_counters(P, C, 0);
@@ -657,10 +669,15 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
 
 // ---------------------------------------------------------------------------------------------------
 // K_connect: curved-ray luminaire sampling of the point emitter for the slots K_event parked on a scattering event
-// (Medium::eval -> makeDirectConnections, src/medium/heterogeneousrefractive.cpp:571-640,1087-1163).  One lane per
-// connection; the sampler stream continues where K_event left it, so the draw order is the oracle's.
+// (Medium::eval -> makeDirectConnections, src/medium/heterogeneousrefractive.cpp:571-640,1087-1163).  One lane per pending
+// connection and ONE unit of its solver per launch (Connector::unit: one traced ray + the algebra up to the next one; then the
+// transmittance walk along the found ray): a connection needs 3 ... 100+ units and which needs how many cannot be known in advance,
+// so unfinished connections are re-queued -- grouped by the length of the rays they trace -- and the host launches the kernel
+// several times per pass.  Every launch is a dense sweep over the connections still pending; run to completion per lane instead, a
+// wave idled until its slowest solve had finished.  The sampler stream of the path continues through the units in order, so the
+// draws are the oracle's.
 #ifndef MER_CONNECT_WAVES
-#define MER_CONNECT_WAVES 3       // measured on configs[4]: unconstrained (243 VGPR, 2 waves/SIMD) 5.2, 3 waves 5.7, 4 waves 5.0 Mpaths/s
+#define MER_CONNECT_WAVES 3
 #endif
 #define MER_CONNECT_BOUNDS __launch_bounds__(MER_BLOCK, MER_CONNECT_WAVES)
 template <int RIF, int STEPPER, int SIGMA, int BND = 0>
@@ -668,27 +685,55 @@ __global__ void MER_CONNECT_BOUNDS connect_stage_kernel(const Params P, uint32_t
     constexpr bool EXTRA = true;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
-    const uint32_t count = queue_total(P.cq, P.cq_row);
+    const uint32_t row = P.cq_row;
+    const SegQueue &qin = P.cq[row & 1u], &qout = P.cq[(row + 1u) & 1u];
+    const uint32_t count = queue_total(qin, row);
+    queue_clear_row(qin, row + 2, j);                    // the row launch l+1 re-queues into for launch l+2 (same list as this one's input)
     LaneCounters C; C.clear();
-    uint32_t i = 0;
-    const bool mine = j < count;
-    if (mine) {
-        i = queue_item(P.cq, P.cq_row, j);
+    uint32_t i = 0, usteps = 0; bool again = false, finished = false; int cls = 0;
+    if (j < count) {
+        i = queue_item(qin, row, j);
         Rng rng;
         const uint32_t pixel = SLOT(H_PIXEL), sample = SLOT(H_SAMPLE);
         rng.state = (uint64_t) SLOT(H_RNG_LO) | ((uint64_t) SLOT(H_RNG_HI) << 32);
         rng.inc = (((((uint64_t) sample) << 32) | (uint64_t) pixel) << 1) | 1ULL;
-        const f3 T(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ)), ps(SLOTF(CO_PSX), SLOTF(CO_PSY), SLOTF(CO_PSZ)), wi(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
-        const int depth = (int) SLOT(CO_DEPTH);
-        float optLen = 0.0f;
-        const f3 c0 = T * point_nee<true, RIF, STEPPER, SIGMA, BND>(P, rng, C, ps, wi, depth, optLen);
-        film_contribute(P, SLOTF(CO_PXF), SLOTF(CO_PYF), c0, SLOTF(CO_PLEN) + optLen);
-        const f3 c = mod_weight<EXTRA>(P, c0, SLOTF(CO_PLEN) + optLen);
-        SLOT(CO_LX) = __float_as_uint(SLOTF(CO_LX) + c.x); SLOT(CO_LY) = __float_as_uint(SLOTF(CO_LY) + c.y); SLOT(CO_LZ) = __float_as_uint(SLOTF(CO_LZ) + c.z);
+        uint32_t *cs = P.cstate + (size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots) * MER_CSTATE_WORDS;
+        ConnState S; S.load(cs);
+        const f3 ps(SLOTF(CO_PSX), SLOTF(CO_PSY), SLOTF(CO_PSZ)), pp(P.sc.point_position[0], P.sc.point_position[1], P.sc.point_position[2]);
+        if (S.phase == CP_OK) {
+            // the connecting ray is known: transmittance along it, emitter value, phase function -- the luminaire sample of this vertex
+            const f3 T(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ)), wi(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
+            const f3 c0 = T * connection_value<RIF, STEPPER, SIGMA, BND>(P, rng, C, ps, wi, S.dir, S.dist, S.weight);
+            const float plen = SLOTF(CO_PLEN) + S.optDist;
+            film_contribute(P, SLOTF(CO_PXF), SLOTF(CO_PYF), c0, plen);
+            const f3 c = mod_weight<EXTRA>(P, c0, plen);
+            SLOT(CO_LX) = __float_as_uint(SLOTF(CO_LX) + c.x); SLOT(CO_LY) = __float_as_uint(SLOTF(CO_LY) + c.y); SLOT(CO_LZ) = __float_as_uint(SLOTF(CO_LZ) + c.z);
+            finished = true;
+        } else {
+            if (S.phase == CP_NEW) { S.weight = 1.0f; C.nee++; }
+            Connector<RIF, BND> K(P);
+            f3 rev;
+            K.unit(S, ps, pp, rng, rev);
+            usteps = K.nsteps;
+            if (S.phase == CP_FAIL) finished = true;            // no connection: the luminaire sample is zero
+            else { S.store(cs); again = true; cls = connect_class(P, ps); }
+        }
         SLOT(H_RNG_LO) = (uint32_t) rng.state; SLOT(H_RNG_HI) = (uint32_t) (rng.state >> 32);
     }
-    queue_push_class<MER_EV_CLASSES>(P.eq, pass + 1, mine, i, 1);   // resumes at EV_PHASE2 in K_event of the next pass (with the ends of NEE walks)
+    queue_push_class<MER_CQ_CLASSES>(qout, row + 1u, again, i, cls);
+    queue_push_class<MER_EV_CLASSES>(P.eq, pass + 1, finished, i, 1);   // resumes at EV_PHASE2 in K_event of the next pass (with the ends of NEE walks)
     flush_counters(P, C, 0);
+    {   // K_connect's own counters: units, steps, and the lane slots its waves held (every lane is held for the longest unit of its wave)
+        const uint32_t units = wave_sum(j < count ? 1u : 0u), steps = wave_sum(usteps);
+        uint32_t longest = usteps;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) longest = max(longest, (uint32_t) __shfl_xor((int) longest, off, 64));
+        if ((threadIdx.x & 63) == 0 && units) {
+            unsigned long long *dst = P.counters + (size_t) ((j >> 6) % MER_COUNTER_REPLICAS) * MER_C_COUNT;
+            atomicAdd(dst + MER_C_CONNECT_UNITS, (unsigned long long) units); atomicAdd(dst + MER_C_CONNECT_STEPS, (unsigned long long) steps);
+            atomicAdd(dst + MER_C_CONNECT_LANE_SLOTS, 64ull * longest);
+        }
+    }
 }
 
 #undef SLOT

@@ -126,42 +126,10 @@ __device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, CellCache &c
 
 __device__ __forceinline__ bool finite3(f3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
 
-// State of one curved-ray connection between two units of work (Connector::unit): 32 words when parked (K_connect's cstate record)
-enum { CP_NEW = 0, CP_EVAL0, CP_TRIAL, CP_PATHLEN, CP_OK, CP_FAIL };
-struct ConnState {
-    f3 x, e, xn, tempSol, dir;        // iterate, its residual, trial iterate, first converged direction, direction found (x n(p1) once accepted)
-    m33 J;                            // Jacobian of the residual at x
-    float cost, lambda, radius, weight, RIFp, optDist, dist;
-    int it, tries, iterations, phase, ok;
-    __device__ __forceinline__ void load(const uint32_t *r) {
-        const uint4 *q = (const uint4 *) r; const uint4 a = q[0], b = q[1], c = q[2], d = q[3], g = q[4], h = q[5], k = q[6], l = q[7];
-#define F(u) __uint_as_float(u)
-        x = f3(F(a.x), F(a.y), F(a.z)); e = f3(F(a.w), F(b.x), F(b.y)); xn = f3(F(b.z), F(b.w), F(c.x)); tempSol = f3(F(c.y), F(c.z), F(c.w));
-        dir = f3(F(d.x), F(d.y), F(d.z));
-        J.m[0][0] = F(d.w); J.m[0][1] = F(g.x); J.m[0][2] = F(g.y); J.m[1][0] = F(g.z); J.m[1][1] = F(g.w); J.m[1][2] = F(h.x);
-        J.m[2][0] = F(h.y); J.m[2][1] = F(h.z); J.m[2][2] = F(h.w);
-        cost = F(k.x); lambda = F(k.y); radius = F(k.z); weight = F(k.w); RIFp = F(l.x); optDist = F(l.y); dist = F(l.z);
-#undef F
-        it = (int) (l.w & 31u); tries = (int) ((l.w >> 5) & 7u); iterations = (int) ((l.w >> 8) & 127u); phase = (int) ((l.w >> 15) & 7u); ok = (int) ((l.w >> 18) & 1u);
-    }
-    __device__ __forceinline__ void store(uint32_t *r) const {
-        uint4 *q = (uint4 *) r;
-#define U(f) __float_as_uint(f)
-        q[0] = make_uint4(U(x.x), U(x.y), U(x.z), U(e.x)); q[1] = make_uint4(U(e.y), U(e.z), U(xn.x), U(xn.y));
-        q[2] = make_uint4(U(xn.z), U(tempSol.x), U(tempSol.y), U(tempSol.z)); q[3] = make_uint4(U(dir.x), U(dir.y), U(dir.z), U(J.m[0][0]));
-        q[4] = make_uint4(U(J.m[0][1]), U(J.m[0][2]), U(J.m[1][0]), U(J.m[1][1])); q[5] = make_uint4(U(J.m[1][2]), U(J.m[2][0]), U(J.m[2][1]), U(J.m[2][2]));
-        q[6] = make_uint4(U(cost), U(lambda), U(radius), U(weight));
-        q[7] = make_uint4(U(RIFp), U(optDist), U(dist), (uint32_t) it | ((uint32_t) tries << 5) | ((uint32_t) iterations << 8) | ((uint32_t) phase << 15) | ((uint32_t) (ok != 0) << 18));
-#undef U
-    }
-};
-#define MER_CSTATE_WORDS 32
-
 template <int RIF, int BND = 0> struct Connector {
     const Params &P;
     float tol, rrweight; int precision, maxIter, maxSteps;
     mutable CellCache cc;                       // the 8 corners of the cell the ray is in (trilinear RIF): reused across evaluations
-    mutable uint32_t nsteps = 0;                // sensitivity / Verlet steps taken (MER_C_CONNECT_STEPS)
 #ifdef MER_CONNECT_DEBUG
     mutable float dbg0 = -1, dbg1 = -1, dbg2 = 0, dbg3 = 0, dbg4 = 0;
 #endif
@@ -211,7 +179,7 @@ template <int RIF, int BND = 0> struct Connector {
         bool found = false;
         for (int i = 0; i < maxSteps; i++) {
             oldp = p; oldv = v; olddp = dp; olddv = dv;
-            dstep(p, v, dp, dv, h); nsteps++;
+            dstep(p, v, dp, dv, h);
             signNew = dot(p - p2, v) < 0.0f;
             if (signNew != signOld) {
                 while (nBisect > 0) {
@@ -235,86 +203,43 @@ template <int RIF, int BND = 0> struct Connector {
         error = p - p2;
         return true;
     }
-    // ---- the solver as a resumable state machine ---------------------------------------------------------------------------------
-    // makeDirectConnections (:1087-1163) around the stand-in for ceres::Solve (damped Gauss-Newton, <= 20 iterations of <= 6 damping
-    // trials).  One connection costs 1 ... 100+ traced rays (`computefdf`), and which lane needs how many is not predictable: run to
-    // completion per lane, a wave waits for its slowest solve (round 1: K_connect at a quarter of K_march's step rate).  So the loop
-    // nest is flattened: `unit()` performs ONE expensive operation -- one traced ray -- plus the algebra up to the next one, and the
-    // state in between (ConnState, 32 words) can be parked in HBM: K_connect runs one unit per pending connection per launch and
-    // re-compacts the unfinished ones (mer_wavefront.hpp); the leaf entry point just loops.  Per lane the sequence of arithmetic
-    // operations and sampler draws is the loop nest's (the oracle keeps the loops).
-    //
-    // computefdf rescales its argument to |v0| = n(p1): the residual does not depend on |x|, J^T J is singular along x and only the
-    // damping makes the step finite -- with little damping the step along x is rounding noise of any size.  The unknown lives on the
-    // sphere |x| = n(p1): every trial iterate is put back on it, and a step whose determinant is below float resolution of the
-    // product of the pivots, or that is not finite, is retried with more damping.
-    // The next damped Gauss-Newton candidate S.xn from (S.x, S.e, S.J); false: the solve has ended (converged, stuck or out of iterations)
-    __device__ bool next_candidate(ConnState &S) const {
-        if (S.tries == 0 && !(S.it < maxIter && S.ok && S.cost >= tol * 1e-3f)) return false;
-        float A[3][3], b[3]; const float E[3] = {S.e.x, S.e.y, S.e.z};
-        for (int i = 0; i < 3; i++) { b[i] = 0; for (int k = 0; k < 3; k++) b[i] -= S.J.m[k][i] * E[k];
-            for (int j = 0; j < 3; j++) { A[i][j] = 0; for (int k = 0; k < 3; k++) A[i][j] += S.J.m[k][i] * S.J.m[k][j]; } }
-        while (S.tries < 6) {
-            S.tries++;
-            float M[3][3];
-            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = A[i][j] + (i == j ? S.lambda * (A[i][i] + 1e-12f) : 0.0f);
-            const float det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
-                              M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
-            if (!(fabsf(det) > 1e-6f * fabsf(M[0][0] * M[1][1] * M[2][2])) || !isfinite(det)) { S.lambda *= 10; continue; }
-            float d[3];
-            d[0] = (b[0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (b[1] * M[2][2] - M[1][2] * b[2]) + M[0][2] * (b[1] * M[2][1] - M[1][1] * b[2])) / det;
-            d[1] = (M[0][0] * (b[1] * M[2][2] - M[1][2] * b[2]) - b[0] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * b[2] - b[1] * M[2][0])) / det;
-            d[2] = (M[0][0] * (M[1][1] * b[2] - b[1] * M[2][1]) - M[0][1] * (M[1][0] * b[2] - b[1] * M[2][0]) + b[0] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
-            const f3 xn(S.x.x + d[0], S.x.y + d[1], S.x.z + d[2]);
-            const float ln = sqrtf(dot(xn, xn));
-            if (!(ln > 0.0f) || !isfinite(ln)) { S.lambda *= 10; continue; }
-            S.xn = xn * (S.radius / ln);
-            return true;
-        }
-        return false;                                  // six trials without an improvement
-    }
-    // a solve has ended: accept / restart under Russian roulette (makeDirectConnections' loop body after ceres::Solve)
-    __device__ void end_solve(ConnState &S, f3 p1, f3 p2, Rng &rng) const {
-        const float cost = S.ok ? S.cost : MER_INF;
-        if (cost < tol) {
-            if (S.iterations == 1) { S.iterations++; S.tempSol = normalize(S.x); }
-            else S.iterations++;
-            S.dir = normalize(S.x);
-            if (dot(S.tempSol - S.dir, S.tempSol - S.dir) < 2 * tol) {
-                S.dir = S.dir * S.RIFp;
-                S.weight *= (float) (S.iterations - 1);
-                S.phase = CP_PATHLEN;
-                return;
+    // stand-in for ceres::Solve: damped Gauss-Newton, <= 20 iterations
+    __device__ float solve(f3 &x, f3 p1, f3 p2) const {
+        f3 e; m33 J;
+        bool ok = computefdf(x, p1, p2, e, J);
+        float cost = 0.5f * dot(e, e), lambda = 1e-4f;
+        // computefdf rescales its argument to |v0| = n(p1): the residual does not depend on |x|, J^T J is singular along x and only the
+        // damping makes the step finite -- with little damping the step along x is rounding noise of any size.  The unknown lives on the
+        // sphere |x| = n(p1): every accepted iterate is put back on it, and a step whose determinant is below float resolution of the
+        // product of the pivots, or that is not finite, is retried with more damping.
+        const float radius = sqrtf(dot(x, x));
+        for (int it = 0; it < maxIter && ok && cost >= tol * 1e-3f; ++it) {
+            float A[3][3], b[3]; const float E[3] = {e.x, e.y, e.z};
+            for (int i = 0; i < 3; i++) { b[i] = 0; for (int k = 0; k < 3; k++) b[i] -= J.m[k][i] * E[k];
+                for (int j = 0; j < 3; j++) { A[i][j] = 0; for (int k = 0; k < 3; k++) A[i][j] += J.m[k][i] * J.m[k][j]; } }
+            bool improved = false;
+            for (int tries = 0; tries < 6 && !improved; ++tries) {
+                float M[3][3];
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[i][j] = A[i][j] + (i == j ? lambda * (A[i][i] + 1e-12f) : 0.0f);
+                const float det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) +
+                                  M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+                if (!(fabsf(det) > 1e-6f * fabsf(M[0][0] * M[1][1] * M[2][2])) || !isfinite(det)) { lambda *= 10; continue; }
+                float d[3];
+                d[0] = (b[0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (b[1] * M[2][2] - M[1][2] * b[2]) + M[0][2] * (b[1] * M[2][1] - M[1][1] * b[2])) / det;
+                d[1] = (M[0][0] * (b[1] * M[2][2] - M[1][2] * b[2]) - b[0] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * b[2] - b[1] * M[2][0])) / det;
+                d[2] = (M[0][0] * (M[1][1] * b[2] - b[1] * M[2][1]) - M[0][1] * (M[1][0] * b[2] - b[1] * M[2][0]) + b[0] * (M[1][0] * M[2][1] - M[1][1] * M[2][0])) / det;
+                f3 xn(x.x + d[0], x.y + d[1], x.z + d[2]), en; m33 Jn;
+                const float ln = sqrtf(dot(xn, xn));
+                if (!(ln > 0.0f) || !isfinite(ln)) { lambda *= 10; continue; }
+                xn = xn * (radius / ln);
+                const bool okn = computefdf(xn, p1, p2, en, Jn);
+                const float cn = 0.5f * dot(en, en);
+                if (okn && cn < cost) { x = xn; e = en; J = Jn; cost = cn; lambda = fmaxf(lambda * 0.1f, 1e-9f); improved = true; }
+                else lambda *= 10;
             }
+            if (!improved) break;
         }
-        if (rng.next1D() < rrweight) S.weight = S.weight / rrweight;
-        else { S.dir = normalize(S.x); S.phase = CP_FAIL; return; }
-        if (S.iterations > 64) { S.phase = CP_FAIL; return; }
-        S.x = uniform_sample(normalize(p2 - p1), rng) * S.RIFp;
-        S.phase = CP_EVAL0;
-    }
-    // one traced ray of the connection p1 -> p2, and the algebra up to the next one.  S.phase = CP_NEW and S.weight set by the caller.
-    __device__ void unit(ConnState &S, f3 p1, f3 p2, Rng &rng, f3 &revDir) const {
-        if (S.phase == CP_NEW) {
-            S.iterations = 1; S.tempSol = f3(0, 0, 0); S.dir = f3(0, 0, 1); S.optDist = 0; S.dist = 0; S.it = 0; S.tries = 0; S.ok = 0;
-            S.cost = 0; S.lambda = 0; S.radius = 0; S.e = f3(0, 0, 0); S.xn = f3(0, 0, 0); S.J = m33(0.0f);
-            if (RIF == MER_RIF_BSPLINE3 && !inside_volume_limits(P.rif, p1)) { S.phase = CP_FAIL; return; }
-            S.RIFp = rif_value(p1);
-            S.x = uniform_sample(normalize(p2 - p1), rng) * S.RIFp;
-            S.phase = CP_EVAL0;
-        }
-        if (S.phase == CP_EVAL0 || S.phase == CP_TRIAL) {
-            const bool first = S.phase == CP_EVAL0;
-            f3 en; m33 Jn;
-            const bool okn = computefdf(first ? S.x : S.xn, p1, p2, en, Jn);            // the one call site
-            const float cn = 0.5f * dot(en, en);
-            if (first) { S.ok = okn; S.e = en; S.J = Jn; S.cost = cn; S.lambda = 1e-4f; S.radius = sqrtf(dot(S.x, S.x)); S.it = 0; S.tries = 0; }
-            else if (okn && cn < S.cost) { S.x = S.xn; S.e = en; S.J = Jn; S.cost = cn; S.lambda = fmaxf(S.lambda * 0.1f, 1e-9f); S.it++; S.tries = 0; }
-            else S.lambda *= 10;
-            if (next_candidate(S)) S.phase = CP_TRIAL; else end_solve(S, p1, p2, rng);
-            return;
-        }
-        if (S.phase == CP_PATHLEN) S.phase = path_lengths(p1, p2, S.dir, revDir, S.optDist, S.dist) ? CP_OK : CP_FAIL;
+        return ok ? cost : MER_INF;
     }
     // the reference's own Verlet step (:662-669)
     __device__ void verlet(f3 &p, f3 &v, float h) const {
@@ -334,7 +259,7 @@ template <int RIF, int BND = 0> struct Connector {
         const bool signOld = dot(p - p2, v) < 0.0f; bool signNew = signOld;
         for (int i = 0; i < maxSteps; i++) {
             oldp = p; oldv = v;
-            verlet(p, v, h); nsteps++;
+            verlet(p, v, h);
             signNew = dot(p - p2, v) < 0.0f;
 #ifdef MER_CONNECT_DEBUG
             dbg0 = (float) i;
@@ -367,12 +292,28 @@ template <int RIF, int BND = 0> struct Connector {
         const float z = u1, tmp = safe_sqrt(1.0f - z * z), phi = 2.0f * MER_PI * u2;
         return (cosf(phi) * tmp) * ax + (sinf(phi) * tmp) * ay + z * in;
     }
-    // makeDirectConnections (:1087-1163), run to completion (leaf entry point mer_connect)
-    __device__ bool connect(f3 p1, f3 p2, Rng &rng, float &weight, f3 &dirToP2, f3 &revDir, float &optDist, float &dist) const {
-        ConnState S; S.phase = CP_NEW; S.weight = weight;
-        while (S.phase != CP_OK && S.phase != CP_FAIL) unit(S, p1, p2, rng, revDir);
-        weight = S.weight; dirToP2 = S.dir; optDist = S.optDist; dist = S.dist;
-        return S.phase == CP_OK;
+    // makeDirectConnections (:1087-1163)
+    __device__ bool connect(f3 p1, f3 p2, f3 d, Rng &rng, float &weight, f3 &dirToP2, f3 &revDir, float &optDist, float &dist) const {
+        f3 tempSol(0, 0, 0);
+        int iterations = 1;
+        if (RIF == MER_RIF_BSPLINE3 && !inside_volume_limits(P.rif, p1)) return false;
+        const float RIFp = rif_value(p1);
+        for (;;) {
+            f3 x = uniform_sample(d, rng) * RIFp;
+            const float cost = solve(x, p1, p2);
+            if (cost < tol) {
+                if (iterations == 1) { iterations++; tempSol = normalize(x); }
+                else iterations++;
+                dirToP2 = normalize(x);
+                if (dot(tempSol - dirToP2, tempSol - dirToP2) < 2 * tol) break;
+            }
+            if (rng.next1D() < rrweight) weight = weight / rrweight;
+            else { dirToP2 = normalize(x); return false; }
+            if (iterations > 64) return false;
+        }
+        dirToP2 = dirToP2 * RIFp;
+        weight *= (float) (iterations - 1);
+        return path_lengths(p1, p2, dirToP2, revDir, optDist, dist);
     }
 };
 
@@ -389,8 +330,7 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
     const int interactions = S.max_depth - depth - 1;
     const int nwalks = (SIGMA == MER_SIGMA_GRID && S.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
     C.nee++;
-    static_assert(!CURVED, "curved-ray connections run in K_connect");
-    {
+    if (!CURVED) {
         f3 dvec = pp - ps;
         const float dist = sqrtf(dot(dvec, dvec)), invDist = 1.0f / dist;
         dvec = dvec * invDist;
@@ -424,50 +364,43 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
         value = value * tr;
         if (is_zero(value)) return f3(0, 0, 0);
         return value * phase_eval(S.phase, S.g, wi, dvec);
-    }
-    return f3(0, 0, 0);       // curved rays: K_connect (Connector::unit per launch, then connection_value)
-}
-
-// The radiance a finished curved-ray connection carries from the point emitter to the scattering point ps (to be multiplied by the
-// path throughput): I / |pp - ps|^2 (the straight-line distance of PointEmitter::sampleDirect, which the reference keeps for curved
-// connections) x transmittance along the connecting ray (arc length dist, launched along dir) x solver weight x phase function.
-template <int RIF, int STEPPER, int SIGMA, int BND = 0>
-__device__ f3 connection_value(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi, f3 dir, float dist, float w) {
-    const mer_scene_desc &S = P.sc;
-    const f3 I(S.point_intensity[0], S.point_intensity[1], S.point_intensity[2]);
-    const f3 pp(S.point_position[0], S.point_position[1], S.point_position[2]);
-    const int nwalks = (SIGMA == MER_SIGMA_GRID && S.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
-    f3 tr;
-    if (SIGMA == MER_SIGMA_HOMOGENEOUS) tr = f3(expf(P.sigT.x * (-dist)), expf(P.sigT.y * (-dist)), expf(P.sigT.z * (-dist)));
-    else {
-        float result = 0.0f;
-        for (int wk = 0; wk < nwalks; ++wk) {
-            f3 p = ps, v = dir; float left = dist, Tr = 1.0f, opt = 0; CellCache cc; cc.reset();
-            for (;;) {
-                const float s = -logf(1 - rng.next1D()) * P.inv_max_density;
-                if (s >= left) break;
-                // trace(p, v, s): int(s/h) full steps + remainder, insideShape after each, one step back on exit (:671-691)
-                const float h = S.stepsize; int steps = (int) (s / h); const float rem = s - steps * h; bool inside = true;
-                for (int q = 0; q <= steps && inside; ++q) {
-                    const float hq = q < steps ? h : rem;
-                    er_step<RIF, STEPPER>(P.rif, cc, p, v, hq, opt); C.steps++;
-                    if (!inside_shape_b<BND>(P, p)) { er_step<RIF, STEPPER>(P.rif, cc, p, v, -hq, opt); C.steps++; inside = false; }
+    } else {
+        Connector<RIF, BND> K(P);
+        float w = 1.0f, od = 0, dist = 0; f3 dir(0, 0, 1), rev(0, 0, 1);
+        if (!K.connect(ps, pp, normalize(pp - ps), rng, w, dir, rev, od, dist)) return f3(0, 0, 0);
+        optLen = od;
+        f3 tr;
+        if (SIGMA == MER_SIGMA_HOMOGENEOUS) tr = f3(expf(P.sigT.x * (-dist)), expf(P.sigT.y * (-dist)), expf(P.sigT.z * (-dist)));
+        else {
+            float result = 0.0f;
+            for (int wk = 0; wk < nwalks; ++wk) {
+                f3 p = ps, v = dir; float left = dist, Tr = 1.0f, opt = 0; CellCache cc; cc.reset();
+                for (;;) {
+                    const float s = -logf(1 - rng.next1D()) * P.inv_max_density;
+                    if (s >= left) break;
+                    // trace(p, v, s): int(s/h) full steps + remainder, insideShape after each, one step back on exit (:671-691)
+                    const float h = S.stepsize; int steps = (int) (s / h); const float rem = s - steps * h; bool inside = true;
+                    for (int q = 0; q <= steps && inside; ++q) {
+                        const float hq = q < steps ? h : rem;
+                        er_step<RIF, STEPPER>(P.rif, cc, p, v, hq, opt); C.steps++;
+                        if (!inside_shape_b<BND>(P, p)) { er_step<RIF, STEPPER>(P.rif, cc, p, v, -hq, opt); C.steps++; inside = false; }
+                    }
+                    if (!inside) break;
+                    left -= s;
+                    const float sigma = lookup_float(P.density, p) * S.density_scale; C.tentative++;
+                    if (S.tr_estimator == MER_TR_RATIO) { Tr *= 1.0f - sigma * P.inv_max_density; if (Tr == 0.0f) break; }
+                    else if (sigma * P.inv_max_density > rng.next1D()) { Tr = 0.0f; break; }
                 }
-                if (!inside) break;
-                left -= s;
-                const float sigma = lookup_float(P.density, p) * S.density_scale; C.tentative++;
-                if (S.tr_estimator == MER_TR_RATIO) { Tr *= 1.0f - sigma * P.inv_max_density; if (Tr == 0.0f) break; }
-                else if (sigma * P.inv_max_density > rng.next1D()) { Tr = 0.0f; break; }
+                result += Tr;
             }
-            result += Tr;
+            const float tv = result / (float) nwalks; tr = f3(tv, tv, tv);
         }
-        const float tv = result / (float) nwalks; tr = f3(tv, tv, tv);
+        if (is_zero(tr)) return f3(0, 0, 0);
+        const f3 dv = pp - ps;                                         // straight-line distance, as PointEmitter::sampleDirect
+        const float invDist = 1.0f / sqrtf(dot(dv, dv));
+        const f3 value = I * (invDist * invDist) * tr * w;
+        return value * phase_eval(S.phase, S.g, wi, normalize(dir));
     }
-    if (is_zero(tr)) return f3(0, 0, 0);
-    const f3 dv = pp - ps;
-    const float invDist = 1.0f / sqrtf(dot(dv, dv));
-    const f3 value = I * (invDist * invDist) * tr * w;
-    return value * phase_eval(S.phase, S.g, wi, normalize(dir));
 }
 
 // leaf kernel: out stride 12: ok, weight, dirToP2[3], revDirToP1[3], dist, opticalDist, 0, 0; RNG stream (seed, i, 0)
@@ -479,7 +412,7 @@ __global__ void __launch_bounds__(64) connect_kernel(const Params P, const float
     Connector<RIF, BND> K(P);
     const f3 a(p1[3 * i], p1[3 * i + 1], p1[3 * i + 2]), b(p2[3 * i], p2[3 * i + 1], p2[3 * i + 2]);
     float w = 1.0f, od = 0, di = 0; f3 dir(0, 0, 0), rev(0, 0, 0);
-    const bool ok = K.connect(a, b, rng, w, dir, rev, od, di);
+    const bool ok = K.connect(a, b, normalize(b - a), rng, w, dir, rev, od, di);
     float *o = out + 12 * i;
     o[0] = ok ? 1.0f : 0.0f; o[1] = w; o[2] = dir.x; o[3] = dir.y; o[4] = dir.z;
     o[5] = ok ? rev.x : 0.0f; o[6] = ok ? rev.y : 0.0f; o[7] = ok ? rev.z : 0.0f; o[8] = ok ? di : 0.0f; o[9] = ok ? od : 0.0f; o[10] = o[11] = 0.0f;

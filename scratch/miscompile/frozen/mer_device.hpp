@@ -4,7 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/mer.h"
+#include "../../../include/mer.h"
 
 #define MER_EPSILON 1e-4f                 // include/mitsuba/core/constants.h:25-31 (single precision)
 #define MER_PI 3.14159265358979323846f
@@ -508,12 +508,11 @@ struct Params {
     uint32_t *live;                     // live[0]: number of finished slots
     SegQueue eq, mq[2], sq[2];          // event queue, march lists (by pass parity), starved lists (by pass parity)
     DGrid sdf; float sdf_eps;           // boundary = MER_BOUNDARY_SDF: signed-distance grid (negative inside), 1e-4 x its diagonal
-    SegQueue cq[2];                     // pending curved-ray connections (K_connect): launch l reads cq[l & 1] row l, re-queues into cq[(l+1) & 1] row l+1
-    uint32_t *cstate;                   // parked solver state of the pending connections, MER_CSTATE_WORDS per slot (mer_connect.hpp)
+    SegQueue cq;                        // connection requests of this pass (curved-ray point-emitter NEE, K_connect)
     unsigned long long *hitq; unsigned long long hitq_cap;     // ring of work ids that will march (power-of-two capacity)
     unsigned long long *hitq_ctr;       // [0] produced (tail), [1] consumed (head)
     int32_t gen_iters, gen_all;
-    uint32_t cq_row;                    // index l of the next K_connect launch: K_event appends its requests to cq[l & 1] row l
+    uint32_t cq_row;                    // row of the connection-request list that K_event appends to and the next K_connect drains
     int32_t mq_sort;                    // 1: march lists sorted by estimated steps to the boundary (option mq_sort = 0 turns it off for A/B runs)
     unsigned long long *chk;            // MER_BOUNDS_CHECK: violation record (NULL in the product build)
     uint64_t n_film, n_path_out;        // float counts of film / path_out: the extents the checks use

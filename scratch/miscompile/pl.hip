@@ -5,7 +5,7 @@
 // ROCm 7.2.0: "connect BND=1" finds 1 of 64 connections at -O3 (and -O2) with the branching form, 61 of 64 at -O1, and 61 of 64 at -O3
 // with the branch-free form that ships; BND=0 (no grid look-up in the inside test) finds 61 of 64 in every build.  With 64 identical
 // pairs (no lane divergence) the -O3 branching build is correct too.
-#include "../../mitsubaer_amd/csrc/mer_connect.hpp"
+#include "frozen/mer_connect.hpp"      // the headers as they were when the miscompile was found (the library has moved on)
 #include <cstdio>
 #include <vector>
 #include <cmath>
