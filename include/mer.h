@@ -34,7 +34,7 @@ enum { MER_STEP_VERLET = 0, MER_STEP_RK4 = 1 };
 enum { MER_BOUNDARY_AABB = 0, MER_BOUNDARY_SPHERE = 1, MER_BOUNDARY_SDF = 2 };
 enum { MER_PHASE_ISOTROPIC = 0, MER_PHASE_HG = 1 };
 enum { MER_TR_WOODCOCK2 = 0, MER_TR_RATIO = 1 };
-enum { MER_STRATEGY_BALANCE = 0, MER_STRATEGY_SINGLE = 1, MER_STRATEGY_MANUAL = 2 };
+enum { MER_STRATEGY_BALANCE = 0, MER_STRATEGY_SINGLE = 1, MER_STRATEGY_MANUAL = 2, MER_STRATEGY_MAXIMUM = 3 /* MaxExpDist, src/medium/maxexp.h */ };
 enum { MER_FILTER_BOX = 0, MER_FILTER_GAUSSIAN = 1 };
 enum { MER_ALBEDO_CONST = 0, MER_ALBEDO_GRID = 1 };
 /* device memory layout of an uploaded grid (the integer index contract stays (x,y,z)) */

@@ -3,6 +3,8 @@
 // every entry point that computes launches a kernel, and fails loudly when no device is present.
 #include "mer_internal.hpp"
 #include "mer_kernels.hpp"
+#include <algorithm>
+#include <functional>
 
 using namespace mer;
 
@@ -160,6 +162,22 @@ int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bool allo
         P.sampling_density = sT[channel];
     } else if (sc->strategy == MER_STRATEGY_MANUAL) {
         P.sampling_density = sc->sampling_density;
+    } else if (sc->strategy == MER_STRATEGY_MAXIMUM) {
+        // MaxExpDist's constructor (src/medium/maxexp.h:30-58), in the reference's float arithmetic
+        MaxExp &m = P.maxexp;
+        for (int i = 0; i < 3; i++) m.sigmaT[i] = sT[i];
+        std::sort(m.sigmaT, m.sigmaT + 3, std::greater<float>());
+        m.cdf[0] = 0;
+        for (int i = 0; i < 3; ++i) {
+            if (i > 0 && m.sigmaT[i] == m.sigmaT[i - 1]) return fail(ctx, "Internal error: sigmaT must vary across channels");
+            if (!(m.sigmaT[i] > 0)) return fail(ctx, "strategy maximum: sigmaT must be positive in every channel");
+            const float lower = (i == 0) ? -1 : -std::pow((m.sigmaT[i] / m.sigmaT[i - 1]), -m.sigmaT[i] / (m.sigmaT[i] - m.sigmaT[i - 1]));
+            const float upper = (i == 2) ? 0 : -std::pow((m.sigmaT[i + 1] / m.sigmaT[i]), -m.sigmaT[i] / (m.sigmaT[i + 1] - m.sigmaT[i]));
+            m.cdf[i + 1] = m.cdf[i] + (upper - lower);
+            m.intervalStart[i] = (i == 0) ? 0 : std::log(m.sigmaT[i] / m.sigmaT[i - 1]) / (m.sigmaT[i] - m.sigmaT[i - 1]);
+        }
+        m.normalization = m.cdf[3]; m.invNormalization = 1 / m.normalization;
+        for (int i = 0; i < 4; ++i) m.cdf[i] *= m.invNormalization;
     } else if (sc->strategy != MER_STRATEGY_BALANCE) {
         return fail(ctx, "Specified an unknown sampling strategy");                                                 // homogeneous.cpp:226
     }

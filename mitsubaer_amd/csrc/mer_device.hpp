@@ -481,6 +481,25 @@ struct SegQueue {
     unsigned long long *chk;  // MER_BOUNDS_CHECK: violation record (NULL in the product build)
 };
 
+// MaxExpDist (src/medium/maxexp.h:28-98): the distance distribution proportional to max_i sigma_i exp(-sigma_i t) over the three
+// channels (`strategy = maximum` of homogeneous / heterogeneousrefractive).  Tables built on the host (mer_api.hip) as :30-58.
+struct MaxExp {
+    float sigmaT[3], cdf[4], intervalStart[3], normalization, invNormalization;
+};
+__device__ __forceinline__ int maxexp_lower_bound(const float *a, int n, float v) { int k = 0; while (k < n && a[k] < v) k++; return k; }
+__device__ __forceinline__ float maxexp_sample(const MaxExp &m, float u, float &pdf) {                  // :60-75
+    const int index = max(0, maxexp_lower_bound(m.cdf, 4, u) - 1);
+    const float t = -logf(expf(-m.intervalStart[index] * m.sigmaT[index]) - m.normalization * (u - m.cdf[index])) / m.sigmaT[index];
+    pdf = m.sigmaT[index] * expf(-m.sigmaT[index] * t) * m.invNormalization;
+    return t;
+}
+__device__ __forceinline__ float maxexp_cdf(const MaxExp &m, float t) {                                  // :85-96
+    const int index = max(0, maxexp_lower_bound(m.intervalStart, 3, t) - 1);
+    const float lower = (index == 0) ? -1.0f : -powf(m.sigmaT[index] / m.sigmaT[max(index - 1, 0)], -m.sigmaT[index] / (m.sigmaT[index] - m.sigmaT[max(index - 1, 0)]));
+    const float upper = -expf(-m.sigmaT[index] * t);
+    return m.cdf[index] + (upper - lower) * m.invNormalization;
+}
+
 // Everything a render / leaf kernel needs, passed by value as the kernel argument.
 struct Params {
     mer_scene_desc sc;
@@ -488,6 +507,7 @@ struct Params {
     // derived
     f3    sigA, sigS, sigT;
     float medium_sampling_weight, sampling_density;
+    MaxExp maxexp;                      // strategy = maximum
     float inv_max_density;
     float cam[12], aspect, cot_half_fov, inv_res_x, inv_res_y;
     float fvalues[33], fradius, fscale;

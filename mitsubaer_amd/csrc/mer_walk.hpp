@@ -51,6 +51,7 @@ struct Walk {
         sdens = P.sampling_density;
         if (rand < P.medium_sampling_weight) {
             rand /= P.medium_sampling_weight;
+            if (P.sc.strategy == MER_STRATEGY_MAXIMUM) return maxexp_sample(P.maxexp, 1 - rand, sdens);    // :291: the pdf rides in sdens
             if (P.sc.strategy == MER_STRATEGY_BALANCE) {
                 const int channel = min((int) (rng.next1D() * 3), 2);
                 sdens = channel == 0 ? P.sigT.x : (channel == 1 ? P.sigT.y : P.sigT.z);
@@ -211,6 +212,9 @@ __device__ __forceinline__ void strategy_pdfs(const Params &P, float sampledDist
             pdfFailure += tmp; pdfSuccess += sT[i] * tmp;
         }
         pdfFailure /= 3; pdfSuccess /= 3;
+    } else if (P.sc.strategy == MER_STRATEGY_MAXIMUM) {       // :318-320; pdfSuccess was set by MaxExpDist::sample
+        pdfFailure = 1 - maxexp_cdf(P.maxexp, sampledDistance);
+        pdfSuccess = samplingDensity;
     } else {
         pdfFailure = expf(-samplingDensity * sampledDistance);
         pdfSuccess = samplingDensity * pdfFailure;

@@ -288,7 +288,7 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
             if (strategy == "balance") o->strategy = MER_STRATEGY_BALANCE;
             else if (strategy == "single") { o->strategy = MER_STRATEGY_SINGLE; o->channel = props.getInteger("channel", -1); }
             else if (strategy == "manual") { o->strategy = MER_STRATEGY_MANUAL; o->samplingDensity = props.getFloat("samplingDensity"); }
-            else if (strategy == "maximum") Log_EError("The 'maximum' sampling strategy is not supported on the GPU path");
+            else if (strategy == "maximum") o->strategy = MER_STRATEGY_MAXIMUM;                                   // homogeneous.cpp:215-220
             else Log_EError("Specified an unknown sampling strategy");
             o->mediumSamplingWeight = props.getFloat("mediumSamplingWeight", -1);
             if (type == "heterogeneousrefractive") {

@@ -16,7 +16,7 @@ STEP_VERLET, STEP_RK4 = 0, 1
 BOUNDARY_AABB, BOUNDARY_SPHERE, BOUNDARY_SDF = 0, 1, 2
 PHASE_ISOTROPIC, PHASE_HG = 0, 1
 TR_WOODCOCK2, TR_RATIO = 0, 1
-STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL = 0, 1, 2
+STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL, STRATEGY_MAXIMUM = 0, 1, 2, 3
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 ALBEDO_CONST, ALBEDO_GRID = 0, 1
 DECOMPOSITION_NONE, DECOMPOSITION_TRANSIENT = 0, 1

@@ -543,6 +543,46 @@ template <typename FLOAT> struct Rif {
     }
 };
 
+/* MaxExpDist (src/medium/maxexp.h:28-98): the distribution proportional to max_i sigma_i exp(-sigma_i t) over the channels,
+   restated for SPECTRUM_SAMPLES = 3 */
+struct MaxExpDist {
+    Float sigmaT[3], cdfv[4], intervalStart[3], normalization, invNormalization;
+    bool configure(const Float *s) {                                   /* :30-58 */
+        for (int i = 0; i < 3; i++) sigmaT[i] = s[i];
+        std::sort(sigmaT, sigmaT + 3, std::greater<Float>());
+        cdfv[0] = 0;
+        for (int i = 0; i < 3; ++i) {
+            if (i > 0 && sigmaT[i] == sigmaT[i - 1]) return false;     /* "Internal error: sigmaT must vary across channels" */
+            Float lower = (i == 0) ? -1 : -std::pow((sigmaT[i] / sigmaT[i - 1]), -sigmaT[i] / (sigmaT[i] - sigmaT[i - 1]));
+            Float upper = (i == 2) ? 0 : -std::pow((sigmaT[i + 1] / sigmaT[i]), -sigmaT[i] / (sigmaT[i + 1] - sigmaT[i]));
+            cdfv[i + 1] = cdfv[i] + (upper - lower);
+            intervalStart[i] = (i == 0) ? 0 : std::log(sigmaT[i] / sigmaT[i - 1]) / (sigmaT[i] - sigmaT[i - 1]);
+        }
+        normalization = cdfv[3]; invNormalization = 1 / normalization;
+        for (int i = 0; i < 4; ++i) cdfv[i] *= invNormalization;
+        return true;
+    }
+    static int lowerBoundIndex(const Float *a, int n, Float v) {       /* std::lower_bound(a, a + n, v) - a */
+        int k = 0; while (k < n && a[k] < v) k++; return k;
+    }
+    Float sample(Float u, Float &pdf) const {                           /* :60-75 */
+        const int index = std::max(0, lowerBoundIndex(cdfv, 4, u) - 1);
+        const Float t = -std::log(std::exp(-intervalStart[index] * sigmaT[index]) - normalization * (u - cdfv[index])) / sigmaT[index];
+        pdf = sigmaT[index] * std::exp(-sigmaT[index] * t) * invNormalization;
+        return t;
+    }
+    Float pdf(Float t) const {                                          /* :77-83 */
+        const int index = std::max(0, lowerBoundIndex(intervalStart, 3, t) - 1);
+        return sigmaT[index] * std::exp(-sigmaT[index] * t) * invNormalization;
+    }
+    Float cdf(Float t) const {                                          /* :85-96 */
+        const int index = std::max(0, lowerBoundIndex(intervalStart, 3, t) - 1);
+        Float lower = (index == 0) ? -1 : -std::pow((sigmaT[index] / sigmaT[index - 1]), -sigmaT[index] / (sigmaT[index] - sigmaT[index - 1]));
+        Float upper = -std::exp(-sigmaT[index] * t);
+        return cdfv[index] + (upper - lower) * invNormalization;
+    }
+};
+
 struct Scene {
     orc_scene s;
     Grid density, albedoGrid;
@@ -554,6 +594,7 @@ struct Scene {
     /* medium derived */
     Spec sigmaA, sigmaS, sigmaT;
     Float mediumSamplingWeight, samplingDensity;
+    MaxExpDist maxExp;
     Float maxDensity, invMaxDensity;
     bool curved;
     Grid sdfGrid; Float sdfEps = 0;
@@ -639,6 +680,9 @@ struct Scene {
             samplingDensity = sigmaT[channel];
         } else if (s.strategy == ORC_STRATEGY_MANUAL) {
             samplingDensity = s.sampling_density;
+        } else if (s.strategy == ORC_STRATEGY_MAXIMUM) {   /* homogeneous.cpp:215-220 == heterogeneousrefractive.cpp:286-291 */
+            Float c[3] = {sigmaT[0], sigmaT[1], sigmaT[2]};
+            if (!maxExp.configure(c)) { g_err = "Internal error: sigmaT must vary across channels"; return false; }
         }
         /* camera: src/sensors/perspective.cpp:130-158, analytic inverse of cameraToSample at z'=0 */
         for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) camM[i][j] = s.cam_to_world[i * 4 + j];
@@ -1251,6 +1295,10 @@ struct Walker {
             }
             mRec.pdfFailure /= 3; mRec.pdfSuccess /= 3;
             break;
+        case ORC_STRATEGY_MAXIMUM:                          /* :318-320; pdfSuccess was set by MaxExpDist::sample (carried in samplingDensity) */
+            mRec.pdfFailure = 1 - S.maxExp.cdf(sampledDistance);
+            mRec.pdfSuccess = samplingDensity;
+            break;
         default:
             mRec.pdfFailure = std::exp(-samplingDensity * sampledDistance);
             mRec.pdfSuccess = samplingDensity * mRec.pdfFailure;
@@ -1265,6 +1313,7 @@ struct Walker {
         samplingDensity = S.samplingDensity;
         if (rand < S.mediumSamplingWeight) {
             rand /= S.mediumSamplingWeight;
+            if (S.s.strategy == ORC_STRATEGY_MAXIMUM) return S.maxExp.sample(1 - rand, samplingDensity);   /* :291: the pdf rides in samplingDensity */
             if (S.s.strategy == ORC_STRATEGY_BALANCE) {
                 int channel = std::min((int) (rng.next1D() * 3), 2);
                 samplingDensity = S.sigmaT[channel];
@@ -1864,6 +1913,14 @@ void orc_connect(const orc_scene *s, const float *p1, const float *p2, int64_t n
         }
         o[10] = (float) (C.c[ORC_C_STEPS] - steps0);           /* eikonal / sensitivity steps this connection cost */
     }
+}
+
+/* MaxExpDist known answers: out[4*i..] = sample(u[i]) -> t, its pdf, pdf(t), cdf(t) */
+int orc_maxexp(const float sigma_t[3], const float *u, int64_t n, float *out) {
+    MaxExpDist m; Float c[3] = {sigma_t[0], sigma_t[1], sigma_t[2]};
+    if (!m.configure(c)) { g_err = "Internal error: sigmaT must vary across channels"; return 1; }
+    for (int64_t i = 0; i < n; i++) { Float pdf; const Float t = m.sample(u[i], pdf); out[4 * i] = t; out[4 * i + 1] = pdf; out[4 * i + 2] = m.pdf(t); out[4 * i + 3] = m.cdf(t); }
+    return 0;
 }
 
 void orc_rng_floats(uint64_t seed, uint32_t pixel, uint32_t sample, int32_t n, float *out) {

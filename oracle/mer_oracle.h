@@ -39,7 +39,7 @@ enum { ORC_STEP_VERLET = 0, ORC_STEP_RK4 = 1 };
 enum { ORC_BOUNDARY_AABB = 0, ORC_BOUNDARY_SPHERE = 1, ORC_BOUNDARY_SDF = 2 };
 enum { ORC_PHASE_ISOTROPIC = 0, ORC_PHASE_HG = 1 };
 enum { ORC_TR_WOODCOCK2 = 0, ORC_TR_RATIO = 1 };
-enum { ORC_STRATEGY_BALANCE = 0, ORC_STRATEGY_SINGLE = 1, ORC_STRATEGY_MANUAL = 2 };
+enum { ORC_STRATEGY_BALANCE = 0, ORC_STRATEGY_SINGLE = 1, ORC_STRATEGY_MANUAL = 2, ORC_STRATEGY_MAXIMUM = 3 };
 enum { ORC_FILTER_BOX = 0, ORC_FILTER_GAUSSIAN = 1 };
 enum { ORC_ALBEDO_CONST = 0, ORC_ALBEDO_GRID = 1 };
 
@@ -137,6 +137,7 @@ void orc_camera_rays(const orc_scene *s, const float *pos2, int64_t n, float *o,
 /* reconstruction-filter table (32 entries + terminal 0) */
 void orc_filter_table(int32_t rfilter, float param, float *values33, float *radius, float *scale);
 /* RNG known answers */
+int orc_maxexp(const float sigma_t[3], const float *u, int64_t n, float *out);
 void orc_rng_floats(uint64_t seed, uint32_t pixel, uint32_t sample, int32_t n, float *out);
 
 /* ---- full render (A10 + A11) ------------------------------------------------ */

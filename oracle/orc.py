@@ -18,7 +18,7 @@ STEP_VERLET, STEP_RK4 = 0, 1
 BOUNDARY_AABB, BOUNDARY_SPHERE = 0, 1
 PHASE_ISOTROPIC, PHASE_HG = 0, 1
 TR_WOODCOCK2, TR_RATIO = 0, 1
-STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL = 0, 1, 2
+STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL, STRATEGY_MAXIMUM = 0, 1, 2, 3
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 ALBEDO_CONST, ALBEDO_GRID = 0, 1
 C_PATHS, C_STEPS, C_RIF_EVALS, C_TENTATIVE, C_REAL, C_SEGMENTS, C_NEE = range(7)
@@ -301,6 +301,16 @@ def correlation(p, path_length):
     t = np.ascontiguousarray(path_length, np.float32)
     out = np.empty(t.shape[0], np.float32)
     lib().orc_correlation(C.byref(s), _fp(t), C.c_int64(t.shape[0]), _fp(out))
+    return out
+
+
+def maxexp(sigma_t, u):
+    """MaxExpDist (src/medium/maxexp.h): rows (t = sample(u), pdf from sample, pdf(t), cdf(t))"""
+    u = np.ascontiguousarray(u, np.float32); out = np.empty((u.shape[0], 4), np.float32)
+    st = (C.c_float * 3)(*[float(v) for v in sigma_t])
+    f = lib().orc_maxexp; f.restype = C.c_int
+    if f(st, _fp(u), C.c_int64(u.shape[0]), _fp(out)) != 0:
+        raise RuntimeError(lib().orc_last_error().decode())
     return out
 
 

@@ -151,12 +151,16 @@ def test_er_trace(ctx, orc, stepper, rifkind):
     assert np.abs(np.linalg.norm(ov, axis=1) - nv).max() < 5e-3
 
 
-@pytest.mark.parametrize("mode", ["woodcock", "homogeneous", "refractive_homog", "composed_rk4", "composed_verlet"])
+@pytest.mark.parametrize("mode", ["woodcock", "homogeneous", "homogeneous_maximum", "refractive_maximum", "refractive_homog", "composed_rk4", "composed_verlet"])
 def test_sample_distance(ctx, orc, mode):
     if mode == "woodcock":
         p = scenes.straight_scene(N=24)
     elif mode == "homogeneous":
         p = scenes.homogeneous_scene()
+    elif mode == "homogeneous_maximum":                  # strategy = maximum: MaxExpDist (src/medium/maxexp.h)
+        p = scenes.homogeneous_scene(strategy=P.STRATEGY_MAXIMUM)
+    elif mode == "refractive_maximum":
+        p = scenes.curved_scene(N=24, sigma_mode=P.SIGMA_HOMOGENEOUS, stepper=P.STEP_VERLET, strategy=P.STRATEGY_MAXIMUM)
     elif mode == "refractive_homog":
         p = scenes.curved_scene(N=24, sigma_mode=P.SIGMA_HOMOGENEOUS, stepper=P.STEP_VERLET)
     elif mode == "composed_rk4":

@@ -21,6 +21,8 @@ CASES = {
     "cfg2_straight_woodcock2": lambda: scenes.straight_scene(N=32, tr_estimator=P.TR_WOODCOCK2),
     "cfg1_homogeneous_isotropic": lambda: scenes.homogeneous_scene(),
     "cfg1_homogeneous_single": lambda: scenes.homogeneous_scene(strategy=P.STRATEGY_SINGLE, phase=P.PHASE_HG, g=0.7),
+    "cfg1_homogeneous_maximum": lambda: scenes.homogeneous_scene(strategy=P.STRATEGY_MAXIMUM),
+    "refractive_homogeneous_sigma_maximum": lambda: scenes.curved_scene(N=24, sigma_mode=P.SIGMA_HOMOGENEOUS, stepper=P.STEP_VERLET, strategy=P.STRATEGY_MAXIMUM),
     "cfg3_curved_rk4_trilinear": lambda: scenes.curved_scene(N=32),
     "cfg3_curved_verlet_trilinear": lambda: scenes.curved_scene(N=32, stepper=P.STEP_VERLET),
     "cfg4_radial_rk4": lambda: scenes.curved_scene(N=32, rif="radial"),
