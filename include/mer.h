@@ -51,6 +51,9 @@ typedef struct {
     int32_t channels;               /* 1 or 3 */
     int32_t dtype;                  /* MER_VOL_F32 | MER_VOL_U8 */
     float   aabb_min[3], aabb_max[3];
+    /* inverse of the plugin's `toWorld` (GridDataSource: m_worldToVolume = m_volumeToWorld.inverse(), src/volume/gridvolume.cpp:110,
+       188-195), row-major 3x4; all zeros = identity.  worldToGrid = scale((res-1)/extents) * translate(-min) * world_to_volume. */
+    float   world_to_volume[12];
 } mer_grid_desc;
 
 /* Flat scene: what Integrator::render() (include/mitsuba/render/integrator.h:74) sees through

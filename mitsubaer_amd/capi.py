@@ -29,7 +29,7 @@ SYMBOLS = [
 
 class GridDesc(C.Structure):
     _fields_ = [("res", C.c_int32 * 3), ("channels", C.c_int32), ("dtype", C.c_int32),
-                ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3)]
+                ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3), ("world_to_volume", C.c_float * 12)]
 
 
 class SceneDesc(C.Structure):
@@ -183,8 +183,9 @@ class Context:
 
     # ---- volumes -------------------------------------------------------------------------------
     @staticmethod
-    def _desc(shape, channels, dtype, aabb_min, aabb_max):
+    def _desc(shape, channels, dtype, aabb_min, aabb_max, to_world=None):
         d = GridDesc()
+        d.world_to_volume[:] = [float(v) for v in P.world_to_volume(to_world).reshape(-1)]
         d.res[:] = [shape[2], shape[1], shape[0]]
         d.channels = channels
         d.dtype = dtype
@@ -192,13 +193,13 @@ class Context:
         d.aabb_max[:] = [float(v) for v in aabb_max]
         return d
 
-    def upload_volume(self, data, aabb_min, aabb_max, layout=LAYOUT_DENSE):
-        """data[z][y][x](,c): float32 or uint8 numpy array."""
+    def upload_volume(self, data, aabb_min, aabb_max, layout=LAYOUT_DENSE, to_world=None):
+        """data[z][y][x](,c): float32 or uint8 numpy array; to_world: the volume plugin's `toWorld` (3x4 or 4x4), None = identity."""
         a = np.ascontiguousarray(data)
         if a.dtype != np.uint8:
             a = a.astype(np.float32, copy=False)
         ch = 1 if a.ndim == 3 else a.shape[3]
-        d = self._desc(a.shape, ch, P.VOL_U8 if a.dtype == np.uint8 else P.VOL_F32, aabb_min, aabb_max)
+        d = self._desc(a.shape, ch, P.VOL_U8 if a.dtype == np.uint8 else P.VOL_F32, aabb_min, aabb_max, to_world)
         h = C.c_int32()
         self._check(self.lib.mer_volume_upload(self.h, C.byref(d), _fp(a), C.c_int32(layout), C.byref(h)))
         return Volume(self, h.value, d, layout)
@@ -263,20 +264,20 @@ class Context:
         dens = alb = rif = None
         if p.sigma_mode == P.SIGMA_GRID and p.density is not None:
             dl = LAYOUT_CELL8 if layout in (LAYOUT_BRICK27, LAYOUT_BRICK125, LAYOUT_AUTO) else layout   # bricks are the RIF's layout; sigma_t keeps its cell records
-            dens = self.upload_volume(p.density, p.density_aabb[0], p.density_aabb[1], dl if np.asarray(p.density).dtype != np.uint8 else LAYOUT_DENSE)
+            dens = self.upload_volume(p.density, p.density_aabb[0], p.density_aabb[1], dl if np.asarray(p.density).dtype != np.uint8 else LAYOUT_DENSE, p.density_to_world)
             vols.append(dens)
         if p.albedo_mode == P.ALBEDO_GRID and p.albedo_grid is not None:
-            alb = self.upload_volume(p.albedo_grid, p.albedo_aabb[0], p.albedo_aabb[1])
+            alb = self.upload_volume(p.albedo_grid, p.albedo_aabb[0], p.albedo_aabb[1], to_world=p.albedo_to_world)
             vols.append(alb)
         if p.rif_mode not in (P.RIF_CONST, P.RIF_ACOUSTIC) and p.rif is not None:
             rl = layout if rif_layout is None else rif_layout
-            rif = self.upload_volume(p.rif, p.rif_aabb[0], p.rif_aabb[1], rl if p.rif_mode == P.RIF_TRILINEAR else LAYOUT_DENSE)
+            rif = self.upload_volume(p.rif, p.rif_aabb[0], p.rif_aabb[1], rl if p.rif_mode == P.RIF_TRILINEAR else LAYOUT_DENSE, p.rif_to_world)
             if p.rif_mode == P.RIF_BSPLINE3:
                 rif.build_spline()
             vols.append(rif)
         sdf = None
         if p.boundary == P.BOUNDARY_SDF and p.sdf is not None:
-            sdf = self.upload_volume(p.sdf, p.sdf_aabb[0], p.sdf_aabb[1], LAYOUT_DENSE)
+            sdf = self.upload_volume(p.sdf, p.sdf_aabb[0], p.sdf_aabb[1], LAYOUT_DENSE, p.sdf_to_world)
             vols.append(sdf)
         return self.scene_desc(p, dens, alb, rif, sdf), vols
 

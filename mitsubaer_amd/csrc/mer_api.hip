@@ -32,6 +32,12 @@ void fill_dgrid(const mer_context *ctx, const Volume &v, DGrid &g) {
         g.n_dense = (uint64_t) v.desc.res[0] * v.desc.res[1] * v.desc.res[2] * (uint64_t) v.desc.channels;
         g.chk = ctx->chk;
     }
+    // worldToVolume: the desc's matrix, all zeros = identity
+    float W[12]; bool zero = true;
+    for (int i = 0; i < 12; i++) { W[i] = v.desc.world_to_volume[i]; zero = zero && W[i] == 0.0f; }
+    if (zero) for (int i = 0; i < 12; i++) W[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    g.affine = 0;
+    for (int i = 0; i < 12; i++) { g.w2v[i] = W[i]; if (W[i] != ((i % 5 == 0) ? 1.0f : 0.0f)) g.affine = 1; }
     for (int i = 0; i < 3; i++) {
         g.res[i] = v.desc.res[i];
         g.bmin[i] = v.desc.aabb_min[i]; g.bmax[i] = v.desc.aabb_max[i];
@@ -39,10 +45,31 @@ void fill_dgrid(const mer_context *ctx, const Volume &v, DGrid &g) {
         const float s = (float) (g.res[i] - 1) / extent;
         g.s[i] = s;
         g.t[i] = s * (-g.bmin[i]);
+        // (scale * translate) * worldToVolume as Mitsuba's 4x4 product forms it (src/libcore/transform.cpp operator*): row i of the
+        // left factor is (s_i e_i, s_i * (-min_i)); the zero terms of the sums add exactly nothing
+        for (int j = 0; j < 3; j++) g.m[i * 4 + j] = s * W[i * 4 + j];
+        g.m[i * 4 + 3] = s * W[i * 4 + 3] + g.t[i];
         // SplineDataSource interpolatable limits (src/volume/splinevolume.cpp:280-281): stride = 1/xres
         const float stride = (float) (1.0 / s);
         g.lim_min[i] = g.bmin[i] + (2.0f * stride + MER_EPSILON);
         g.lim_max[i] = g.bmax[i] + (-2.0f * stride - MER_EPSILON);
+    }
+    {   // m_aabb: bounding box of the data box's corners under volumeToWorld (gridvolume.cpp:199-203); volumeToWorld = W^-1 by cofactors
+        // in double (the oracle forms it with the same expressions)
+        const double a = W[0], b = W[1], c = W[2], d = W[4], e = W[5], f = W[6], gg = W[8], h = W[9], k = W[10];
+        const double det = a * (e * k - f * h) - b * (d * k - f * gg) + c * (d * h - e * gg);
+        const double inv[9] = {(e * k - f * h) / det, (c * h - b * k) / det, (b * f - c * e) / det,
+                               (f * gg - d * k) / det, (a * k - c * gg) / det, (c * d - a * f) / det,
+                               (d * h - e * gg) / det, (b * gg - a * h) / det, (a * e - b * d) / det};
+        for (int i = 0; i < 3; i++) { g.wmin[i] = std::numeric_limits<float>::infinity(); g.wmax[i] = -std::numeric_limits<float>::infinity(); }
+        for (int corner = 0; corner < 8; corner++) {
+            const double q[3] = {((corner & 1) ? g.bmax[0] : g.bmin[0]) - (double) W[3], ((corner & 2) ? g.bmax[1] : g.bmin[1]) - (double) W[7],
+                                 ((corner & 4) ? g.bmax[2] : g.bmin[2]) - (double) W[11]};
+            for (int i = 0; i < 3; i++) {
+                const float w = (float) (inv[i * 3] * q[0] + inv[i * 3 + 1] * q[1] + inv[i * 3 + 2] * q[2]);
+                g.wmin[i] = std::min(g.wmin[i], w); g.wmax[i] = std::max(g.wmax[i], w);
+            }
+        }
     }
 }
 
@@ -132,6 +159,8 @@ int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bool allo
         // the fetch index (z * res_y + y) * res_x + x is formed with 24-bit multiplies (v_mul_u32_u24)
         if ((int64_t) P.rif.res[1] * P.rif.res[2] > ((int64_t) 1 << 24) || P.rif.res[0] > (1 << 24))
             return fail(ctx, "RIF volume: res_y * res_z must not exceed 2^24 (index arithmetic of the trilinear fetch)");
+        if (P.rif.affine && it->second.cell8)
+            return fail(ctx, "RIF volume with a toWorld transform: upload it in the dense layout (the CELL8 / BRICK record layouts carry no transform)");
         if (sc->rif_mode == MER_RIF_BSPLINE3) {
             for (int i = 0; i < 3; i++) if (P.rif.res[i] < 5) return fail(ctx, "splinevolume needs at least 5 nodes per axis");
             // the medium must lie inside the spline-safe box (gate: heterogeneousrefractive.cpp:461-466)
@@ -469,6 +498,13 @@ static int check_desc(mer_context *ctx, const mer_grid_desc *d) {
         if (!(d->aabb_min[i] < d->aabb_max[i])) return fail(ctx, "volume bounding box is empty");
     }
     if ((int64_t) d->res[0] * d->res[1] * d->res[2] > (int64_t) 1 << 31) return fail(ctx, "volume too large for the int32 index contract");
+    {   // world_to_volume: all zeros (identity) or an invertible affine map
+        const float *W = d->world_to_volume; bool zero = true, finite = true;
+        for (int i = 0; i < 12; i++) { zero = zero && W[i] == 0.0f; finite = finite && std::isfinite(W[i]); }
+        const double det = (double) W[0] * ((double) W[5] * W[10] - (double) W[6] * W[9]) - (double) W[1] * ((double) W[4] * W[10] - (double) W[6] * W[8]) +
+                           (double) W[2] * ((double) W[4] * W[9] - (double) W[5] * W[8]);
+        if (!zero && (!finite || !(std::fabs(det) > 1e-12))) return fail(ctx, "volume: the toWorld transform is not invertible");
+    }
     return 0;
 }
 

@@ -63,8 +63,19 @@ __device__ __forceinline__ void bspline_weights2(float t, float d2[4]) {
 }
 
 // Spline<3>::valueGradientAndHessian (basisspline.h:539-606) / Hessian of the trilinear interpolant (mixed terms only)
+template <int RIF> __device__ __forceinline__ void rif_value_grad_hess_vol(const DGrid &g, CellCache &cc, f3 p, float &val, f3 &grad, m33 &H);
+// value, gradient and Hessian in world space: H = Rot^T H_vol Rot for a grid with a `toWorld` (splinevolume.cpp:367,375)
 template <int RIF>
 __device__ __forceinline__ void rif_value_grad_hess(const DGrid &g, CellCache &cc, f3 p, float &val, f3 &grad, m33 &H) {
+    if (!rif_affine_capable<RIF>() || !g.affine) { rif_value_grad_hess_vol<RIF>(g, cc, p, val, grad, H); return; }
+    rif_value_grad_hess_vol<RIF>(g, cc, to_volume(g, p), val, grad, H);
+    grad = rot_t(g, grad);
+    m33 Rm, Rt;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Rm.m[i][j] = g.w2v[i * 4 + j]; Rt.m[j][i] = g.w2v[i * 4 + j]; }
+    H = mul(mul(Rt, H), Rm);
+}
+template <int RIF>
+__device__ __forceinline__ void rif_value_grad_hess_vol(const DGrid &g, CellCache &cc, f3 p, float &val, f3 &grad, m33 &H) {
     if (RIF == RIFK_ACOUSTIC) {
         // AcousticRIFVolume::hessian (src/volume/acousticrifvolume.cpp:254-308); its "x" is our z (cos phi = z / r), its "y" our y
         acoustic_value_grad(g, p, val, grad);
@@ -404,7 +415,7 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
         else if (SIGMA == MER_SIGMA_HOMOGENEOUS) tr = homogeneous_transmittance(P, 0.0f - L);
         else {
             float mint, maxt;                                            // heterogeneous.cpp:546-587
-            if (aabb_intersect(P.density.bmin, P.density.bmax, ps, dvec, mint, maxt)) {
+            if (aabb_intersect(P.density.wmin, P.density.wmax, ps, dvec, mint, maxt)) {
                 mint = fmaxf(mint, 0.0f); maxt = fminf(maxt, L);
                 float result = 0.0f;
                 for (int w = 0; w < nwalks; ++w) {

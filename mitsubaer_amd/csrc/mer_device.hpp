@@ -91,8 +91,12 @@ struct DGrid {
     const float *coeff;       // cubic B-spline coefficients (dense) or NULL
     int32_t res[3];
     int32_t channels, dtype, layout;
-    float   s[3], t[3];       // worldToGrid diagonal + translation (gridvolume.cpp:188-195, toWorld = identity)
-    float   bmin[3], bmax[3];
+    float   s[3], t[3];       // volumeToGrid: diagonal + translation (gridvolume.cpp:188-195 without the toWorld factor)
+    float   m[12];            // worldToGrid = scale((res-1)/extents) * translate(-min) * worldToVolume, row-major 3x4 (gridvolume.cpp:188-195)
+    float   w2v[12];          // worldToVolume (inverse of the plugin's toWorld); `affine` != 0 when it is not the identity
+    int32_t affine;
+    float   wmin[3], wmax[3]; // m_aabb: the world-space bounding box of the transformed data box (gridvolume.cpp:199-203)
+    float   bmin[3], bmax[3]; // the data box, in volume space
     float   lim_min[3], lim_max[3];   // spline interpolatable limits (splinevolume.cpp:280-281)
     uint32_t buf_bytes;               // byte size of data / cell8 when it fits a buffer descriptor (< 4 GiB), else 0
     float   ac_n_o, ac_n_max, ac_k_r; int32_t ac_mode;   // RIFK_ACOUSTIC: the analytic field of acousticrifvolume (no data)
@@ -133,9 +137,10 @@ __device__ __forceinline__ float grid_fetch(const DGrid &g, long long idx) {
 // toolchain miscompiled in K_connect: see sdf_value).  The bounds test is written so that it cannot wrap: v_cvt_i32_f32 saturates,
 // a coordinate of +inf (or >= 2^31) gives x1 = INT_MAX, and INT_MAX + 1 >= res would pass.
 __device__ __forceinline__ float lookup_float(const DGrid &g, f3 p, int *idx4 = nullptr) {
-    const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
+    const float px = g.m[0] * p.x + g.m[1] * p.y + g.m[2] * p.z + g.m[3], py = g.m[4] * p.x + g.m[5] * p.y + g.m[6] * p.z + g.m[7],
+                pz = g.m[8] * p.x + g.m[9] * p.y + g.m[10] * p.z + g.m[11];     // Transform::transformAffine (transform.h:147-155)
     const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
-    const bool inside = !(x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1);
+    const bool inside = !(x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1) && px == px && py == py && pz == pz;   // NaN: (int) is INT_MIN on the reference's x86, 0 here
     const int xc = min(max(x1, 0), g.res[0] - 2), yc = min(max(y1, 0), g.res[1] - 2), zc = min(max(z1, 0), g.res[2] - 2);
     const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
                 _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
@@ -161,9 +166,10 @@ __device__ __forceinline__ float lookup_float(const DGrid &g, f3 p, int *idx4 = 
 
 // GridDataSource::lookupSpectrum (gridvolume.cpp:390-421), 3 channels; branch-free as lookup_float
 __device__ __forceinline__ f3 lookup_spectrum(const DGrid &g, f3 p) {
-    const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
+    const float px = g.m[0] * p.x + g.m[1] * p.y + g.m[2] * p.z + g.m[3], py = g.m[4] * p.x + g.m[5] * p.y + g.m[6] * p.z + g.m[7],
+                pz = g.m[8] * p.x + g.m[9] * p.y + g.m[10] * p.z + g.m[11];     // Transform::transformAffine (transform.h:147-155)
     const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
-    const bool inside = !(x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1);
+    const bool inside = !(x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1) && px == px && py == py && pz == pz;   // NaN: (int) is INT_MIN on the reference's x86, 0 here
     const int xc = min(max(x1, 0), g.res[0] - 2), yc = min(max(y1, 0), g.res[1] - 2), zc = min(max(z1, 0), g.res[2] - 2);
     const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1,
                 _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
@@ -351,7 +357,17 @@ __device__ __forceinline__ void bspline_value_grad(const DGrid &g, f3 p, float &
     grad = f3(gx * g.s[0], gy * g.s[1], gz * g.s[2]);      // * dxres, basisspline.h:467-469
 }
 
+// world -> volume space of a grid with a `toWorld` transform (splinevolume.cpp:320-376: m_worldToVolume(pc)), and the gradient back:
+// m_worldToVolume_RotT * v (:343,359)
+__device__ __forceinline__ f3 to_volume(const DGrid &g, f3 p) {
+    return f3(g.w2v[0] * p.x + g.w2v[1] * p.y + g.w2v[2] * p.z + g.w2v[3], g.w2v[4] * p.x + g.w2v[5] * p.y + g.w2v[6] * p.z + g.w2v[7],
+              g.w2v[8] * p.x + g.w2v[9] * p.y + g.w2v[10] * p.z + g.w2v[11]);
+}
+__device__ __forceinline__ f3 rot_t(const DGrid &g, f3 v) {
+    return f3(g.w2v[0] * v.x + g.w2v[4] * v.y + g.w2v[8] * v.z, g.w2v[1] * v.x + g.w2v[5] * v.y + g.w2v[9] * v.z, g.w2v[2] * v.x + g.w2v[6] * v.y + g.w2v[10] * v.z);
+}
 __device__ __forceinline__ bool inside_volume_limits(const DGrid &g, f3 p) {   // splinevolume.cpp:319-324
+    if (g.affine) p = to_volume(g, p);
     return p.x > g.lim_min[0] && p.x < g.lim_max[0] && p.y > g.lim_min[1] && p.y < g.lim_max[1] &&
            p.z > g.lim_min[2] && p.z < g.lim_max[2];
 }
@@ -372,10 +388,17 @@ __device__ __forceinline__ void acoustic_value_grad(const DGrid &g, f3 pc, float
     gr = f3(0.0f, g.ac_n_max * (dbj * kr * py * invr * cosmp - bj * m * sinmp * pz * invr2),
             g.ac_n_max * (dbj * kr * pz * invr * cosmp + bj * m * sinmp * py * invr2));
 }
+// A RIF volume with a `toWorld` is read in the dense layout or as a spline: the record layouts of the hot path (CELL8 / BRICK27) carry
+// no transform, so that the bench kernels do not pay for the wave-uniform test (measured: 4 % of K_march) -- make_params refuses the
+// combination.
+template <int RIF> __device__ __forceinline__ constexpr bool rif_affine_capable() { return RIF == MER_RIF_TRILINEAR || RIF == RIFK_DENSE_BUF || RIF == MER_RIF_BSPLINE3; }
 template <int RIF> __device__ __forceinline__ void rif_value_grad(const DGrid &g, CellCache &cc, f3 p, float &n, f3 &gr) {
-    if (RIF == RIFK_ACOUSTIC) acoustic_value_grad(g, p, n, gr);
-    else if (RIF != MER_RIF_BSPLINE3) trilinear_value_grad<RIF>(g, cc, p, n, gr);
+    if (RIF == RIFK_ACOUSTIC) { acoustic_value_grad(g, p, n, gr); return; }
+    const bool affine = rif_affine_capable<RIF>() && g.affine;          // wave-uniform
+    if (affine) p = to_volume(g, p);
+    if (RIF != MER_RIF_BSPLINE3) trilinear_value_grad<RIF>(g, cc, p, n, gr);
     else bspline_value_grad(g, p, n, gr);
+    if (affine) gr = rot_t(g, gr);
 }
 
 // RK4 is new functionality: its 1/n is the hardware reciprocal (v_rcp_f32, <= 1 ulp) instead of the ~12-
@@ -618,7 +641,8 @@ __device__ __forceinline__ f3 shape_normal(const mer_scene_desc &s, f3 x) {
 // (scratch/miscompile/: 1 of 64 connections found against 61 at -O1).
 #ifdef MER_SDF_BRANCHING          // scratch/miscompile/pl.hip only: round 1's form, kept to reproduce the miscompile
 __device__ __forceinline__ float lookup_float_branching(const DGrid &g, f3 p, int *idx4 = nullptr) {
-    const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
+    const float px = g.m[0] * p.x + g.m[1] * p.y + g.m[2] * p.z + g.m[3], py = g.m[4] * p.x + g.m[5] * p.y + g.m[6] * p.z + g.m[7],
+                pz = g.m[8] * p.x + g.m[9] * p.y + g.m[10] * p.z + g.m[11];     // Transform::transformAffine (transform.h:147-155)
     const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
     if (idx4) { idx4[0] = x1; idx4[1] = y1; idx4[2] = z1; idx4[3] = -1; }
     // x2 = x1 + 1 >= res, written so that it cannot wrap: v_cvt_i32_f32 saturates, a coordinate of +inf (or >= 2^31) gives
@@ -652,9 +676,10 @@ __device__ __forceinline__ float sdf_value(const Params &P, f3 p) {
 #else
 __device__ __forceinline__ float sdf_value(const Params &P, f3 p) {
     const DGrid &g = P.sdf;
-    const float px = g.s[0] * p.x + g.t[0], py = g.s[1] * p.y + g.t[1], pz = g.s[2] * p.z + g.t[2];
+    const float px = g.m[0] * p.x + g.m[1] * p.y + g.m[2] * p.z + g.m[3], py = g.m[4] * p.x + g.m[5] * p.y + g.m[6] * p.z + g.m[7],
+                pz = g.m[8] * p.x + g.m[9] * p.y + g.m[10] * p.z + g.m[11];     // Transform::transformAffine (transform.h:147-155)
     const int x1 = (int) floorf(px), y1 = (int) floorf(py), z1 = (int) floorf(pz);
-    const bool inside = !(x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1);
+    const bool inside = !(x1 < 0 || y1 < 0 || z1 < 0 || x1 >= g.res[0] - 1 || y1 >= g.res[1] - 1 || z1 >= g.res[2] - 1) && px == px && py == py && pz == pz;   // NaN: (int) is INT_MIN on the reference's x86, 0 here
     const int xc = min(max(x1, 0), g.res[0] - 2), yc = min(max(y1, 0), g.res[1] - 2), zc = min(max(z1, 0), g.res[2] - 2);
     const float fx = px - (float) x1, fy = py - (float) y1, fz = pz - (float) z1, _fx = 1.0f - fx, _fy = 1.0f - fy, _fz = 1.0f - fz;
     const int base = (zc * g.res[1] + yc) * g.res[0] + xc, sy = g.res[0], sz = g.res[0] * g.res[1];
@@ -674,7 +699,7 @@ template <int BND> __device__ __forceinline__ bool inside_shape_b(const Params &
 template <int BND> __device__ __forceinline__ float intersect_shape_b(const Params &P, f3 o, f3 d, float mint, float maxt) {
     if (BND == 0) return intersect_shape(P.sc, o, d, mint, maxt);
     float nearT, farT;
-    if (!aabb_intersect(P.sdf.bmin, P.sdf.bmax, o, d, nearT, farT)) return -1.0f;
+    if (!aabb_intersect(P.sdf.wmin, P.sdf.wmax, o, d, nearT, farT)) return -1.0f;
     const float t0 = fmaxf(nearT, mint), t1 = fminf(farT, maxt), eps = P.sdf_eps;
     if (!(t0 <= t1)) return -1.0f;
     float t = t0, v = sdf_value(P, o + d * t);
@@ -695,7 +720,7 @@ template <int BND> __device__ __forceinline__ float intersect_shape_b(const Para
 template <int BND> __device__ __forceinline__ f3 shape_normal_b(const Params &P, f3 x) {
     if (BND == 0) return shape_normal(P.sc, x);
     float v; f3 g; CellCache cc; cc.reset();
-    trilinear_value_grad<MER_RIF_TRILINEAR>(P.sdf, cc, x, v, g);           // normalized SDF gradient (heterogeneousrefractive.cpp:980-984)
+    rif_value_grad<MER_RIF_TRILINEAR>(P.sdf, cc, x, v, g);                 // normalized SDF gradient (heterogeneousrefractive.cpp:980-984)
     return normalize(g);
 }
 
@@ -723,7 +748,7 @@ __device__ __forceinline__ bool dielectric_event(const Params &P, Rng &rng, f3 r
     float etaB = S.rif_const;
     if (CURVED) {
         f3 q = x; f3 g; CellCache cc; cc.reset();
-        if (RIF != RIFK_ACOUSTIC) {                              // the analytic field has no grid to stay inside of
+        if (RIF != RIFK_ACOUSTIC && !P.rif.affine) {             // the analytic field has no grid to stay inside of; a transformed one clamps its cell
             q.x = fminf(fmaxf(q.x, P.rif.bmin[0]), P.rif.bmax[0]); q.y = fminf(fmaxf(q.y, P.rif.bmin[1]), P.rif.bmax[1]);
             q.z = fminf(fmaxf(q.z, P.rif.bmin[2]), P.rif.bmax[2]);
         }

@@ -25,12 +25,14 @@ __global__ void rif_value_grad_kernel(DGrid g, int interp, const float *pts, int
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float v; f3 gr;
-    const f3 p(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    f3 p(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    if (g.affine) p = to_volume(g, p);                    // a `toWorld` on the volume plugin: splinevolume.cpp:320-376
     CellCache cc; cc.reset();
     if (interp == MER_RIF_BSPLINE3) bspline_value_grad(g, p, v, gr);
     else if (g.layout == MER_LAYOUT_BRICK27 || g.layout == MER_LAYOUT_BRICK125) { if (g.buf_bytes) trilinear_value_grad<RIFK_BRICK27_BUF>(g, cc, p, v, gr); else trilinear_value_grad<RIFK_BRICK27>(g, cc, p, v, gr); }
     else if (g.layout == MER_LAYOUT_CELL8) { if (g.buf_bytes) trilinear_value_grad<RIFK_CELL8_BUF>(g, cc, p, v, gr); else trilinear_value_grad<RIFK_CELL8>(g, cc, p, v, gr); }
     else { if (g.buf_bytes) trilinear_value_grad<RIFK_DENSE_BUF>(g, cc, p, v, gr); else trilinear_value_grad<MER_RIF_TRILINEAR>(g, cc, p, v, gr); }
+    if (g.affine) gr = rot_t(g, gr);
     val[i] = v; grad[3 * i] = gr.x; grad[3 * i + 1] = gr.y; grad[3 * i + 2] = gr.z;
 }
 

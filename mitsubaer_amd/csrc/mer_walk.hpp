@@ -116,7 +116,7 @@ struct Walk {
             p = o; v = d;
             if (SIGMA == MER_SIGMA_GRID) {
                 float mint, maxt;                                             // heterogeneous.cpp:626-630
-                if (!aabb_intersect(P.density.bmin, P.density.bmax, o, d, mint, maxt)) {
+                if (!aabb_intersect(P.density.wmin, P.density.wmax, o, d, mint, maxt)) {
                     if (k == K_FREE) return EV_FAIL;
                     return EV_TR_DONE;                                        // evalTransmittance returns 1 (:553-554)
                 }

@@ -243,7 +243,22 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
         } else if (type == "gridvolume" || type == "splinevolume") {                                        // gridvolume.cpp:108-129
             auto o = std::make_shared<GridVolume>();
             o->spline = type == "splinevolume";
-            requireIdentity(props, type.c_str());
+            {   // m_worldToVolume = m_volumeToWorld.inverse() (gridvolume.cpp:110,188-189): affine inverse by cofactors, in double
+                float m[16]; props.getTransform("toWorld", m);
+                bool ident = true; for (int i = 0; i < 16; i++) ident = ident && m[i] == ((i % 5 == 0) ? 1.0f : 0.0f);
+                if (!ident) {
+                    if (m[12] != 0 || m[13] != 0 || m[14] != 0 || m[15] != 1) Log_EError(type + ": 'toWorld' must be an affine transform");
+                    const double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], k = m[10];
+                    const double det = a * (e * k - f * h) - b * (d * k - f * g) + c * (d * h - e * g);
+                    if (!(std::fabs(det) > 1e-12)) Log_EError(type + ": 'toWorld' is not invertible");
+                    const double inv[9] = {(e * k - f * h) / det, (c * h - b * k) / det, (b * f - c * e) / det, (f * g - d * k) / det, (a * k - c * g) / det,
+                                           (c * d - a * f) / det, (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+                    for (int i = 0; i < 3; i++) {
+                        for (int j = 0; j < 3; j++) o->worldToVolume[i * 4 + j] = (float) inv[i * 3 + j];
+                        o->worldToVolume[i * 4 + 3] = (float) -(inv[i * 3] * m[3] + inv[i * 3 + 1] * m[7] + inv[i * 3 + 2] * m[11]);
+                    }
+                }
+            }
             bool given = props.hasProperty("min") && props.hasProperty("max");
             if (given) {
                 Vec3 a = props.getPoint("min"), b = props.getPoint("max");
@@ -535,6 +550,15 @@ struct Loader {
             else if (c.tag == "scale") {
                 if (c.attr.count("value")) { float v = toFloat(subst(c.attr.at("value")), "scale"); t[0] = t[5] = t[10] = v; }
                 else { t[0] = opt("x", 1); t[5] = opt("y", 1); t[10] = opt("z", 1); }
+            } else if (c.tag == "rotate") {                                  // Transform::rotate(axis, angle in degrees), src/libcore/transform.cpp:65-91
+                float ax = opt("x", 0), ay = opt("y", 0), az = opt("z", 0); const float ang = toFloat(attr(c, "angle"), "angle");
+                const float len = std::sqrt(ax * ax + ay * ay + az * az);
+                if (len == 0) Log_EError("<rotate>: the axis must not be the zero vector");
+                ax /= len; ay /= len; az /= len;
+                const float rad = ang * 3.14159265358979323846f / 180.0f, sn = std::sin(rad), cs = std::cos(rad);
+                t[0] = ax * ax + (1 - ax * ax) * cs; t[1] = ax * ay * (1 - cs) - az * sn; t[2] = ax * az * (1 - cs) + ay * sn;
+                t[4] = ax * ay * (1 - cs) + az * sn; t[5] = ay * ay + (1 - ay * ay) * cs; t[6] = ay * az * (1 - cs) - ax * sn;
+                t[8] = ax * az * (1 - cs) - ay * sn; t[9] = ay * az * (1 - cs) + ax * sn; t[10] = az * az + (1 - az * az) * cs;
             } else if (c.tag == "matrix") {
                 auto f = parseFloats(attr(c, "value"));
                 if (f.size() != 16) Log_EError("<matrix>: expected 16 values");
@@ -690,7 +714,9 @@ std::vector<float> Integrator::render(const Scene &scene, int device, int spp, u
     auto fail = [&](void) { std::string msg = mer_last_error(ctx); mer_context_destroy(ctx); Log_EError(msg); };
     const Medium &m = *([&]() -> const Shape * { for (auto &s : scene.shapes) if (s->interior) return s.get(); return (const Shape *) NULL; }())->interior;
     auto upload = [&](const VolumeDataSource &v, int lay) -> mer_volume {
-        mer_grid_desc g; for (int i = 0; i < 3; i++) { g.res[i] = v.res[i]; g.aabb_min[i] = v.aabb_min[i]; g.aabb_max[i] = v.aabb_max[i]; }
+        mer_grid_desc g; std::memset(&g, 0, sizeof(g));
+        for (int i = 0; i < 3; i++) { g.res[i] = v.res[i]; g.aabb_min[i] = v.aabb_min[i]; g.aabb_max[i] = v.aabb_max[i]; }
+        for (int i = 0; i < 12; i++) g.world_to_volume[i] = v.worldToVolume[i];
         g.channels = v.channels; g.dtype = v.dtype;
         mer_volume h = 0;
         if (mer_volume_upload(ctx, &g, v.data.data(), lay, &h)) fail();

@@ -90,6 +90,7 @@ public:
     virtual bool isAcoustic() const { return false; }           // acousticrifvolume: analytic, no payload
     float ac_n_o = 1.3333f, ac_n_max = 0.0f, ac_k_r = 0.0f; int ac_mode = 0;
     float aabb_min[3] = {0, 0, 0}, aabb_max[3] = {0, 0, 0};
+    float worldToVolume[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // inverse of `toWorld`, row-major 3x4; all zeros = identity (gridvolume.cpp:110,188-189)
     int res[3] = {0, 0, 0}, channels = 0, dtype = MER_VOL_F32;
     std::vector<unsigned char> data;          // dense payload (gridvolume / splinevolume)
     Spectrum constant{};                      // constvolume

@@ -39,6 +39,26 @@ def look_at(origin, target, up):
     return m
 
 
+def world_to_volume(to_world):
+    """inverse of a volume plugin's `toWorld` (GridDataSource::configure, src/volume/gridvolume.cpp:188-189) as the row-major 3x4
+    float32 matrix the grid descs carry; None = identity (all zeros in the desc)."""
+    if to_world is None:
+        return np.zeros((3, 4), np.float32)
+    m = np.eye(4); t = np.asarray(to_world, np.float64); m[:t.shape[0], :4] = t
+    return np.linalg.inv(m)[:3, :4].astype(np.float32)
+
+
+def rotation(axis, angle_deg, translate=(0, 0, 0)):
+    """Transform::translate(t) * Transform::rotate(axis, angle) as a 4x4 (src/libcore/transform.cpp)"""
+    a = np.asarray(axis, np.float64); a = a / np.linalg.norm(a); th = np.deg2rad(angle_deg); c, s_ = np.cos(th), np.sin(th)
+    x, y, z = a
+    r = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s_, x * z * (1 - c) + y * s_],
+                  [y * x * (1 - c) + z * s_, c + y * y * (1 - c), y * z * (1 - c) - x * s_],
+                  [z * x * (1 - c) - y * s_, z * y * (1 - c) + x * s_, c + z * z * (1 - c)]])
+    m = np.eye(4); m[:3, :3] = r; m[:3, 3] = translate
+    return m
+
+
 class SceneParams:
     """Attribute bag; defaults follow the reference plugin defaults."""
 
@@ -64,6 +84,8 @@ class SceneParams:
         self.strategy = STRATEGY_BALANCE; self.channel = -1; self.sampling_density = 0.0
         self.medium_sampling_weight = -1.0
         self.density = None; self.density_aabb = ([-1, -1, -1], [1, 1, 1]); self.density_scale = 4.0
+        # `toWorld` of the volume plugins (3x4 / 4x4, None = identity): src/volume/gridvolume.cpp:110,188-195
+        self.density_to_world = None; self.albedo_to_world = None; self.rif_to_world = None; self.sdf_to_world = None
         self.albedo_mode = ALBEDO_CONST; self.albedo = [0.9, 0.9, 0.9]
         self.albedo_grid = None; self.albedo_aabb = ([-1, -1, -1], [1, 1, 1])
         self.rif_mode = RIF_CONST; self.rif_const = 1.0

@@ -118,6 +118,10 @@ struct Grid {
     const void *data;
     Float bmin[3], bmax[3];
     Float m[3][4];          /* worldToGrid, gridvolume.cpp:188-195 */
+    Float w2v[3][4];        /* worldToVolume = toWorld^-1 */
+    Float s[3], t[3];       /* volumeToGrid: scale((res-1)/extents) * translate(-min) */
+    Float wmin[3], wmax[3]; /* m_aabb: world-space box of the transformed data box, gridvolume.cpp:199-203 */
+    bool affine;
     Float stepSize;         /* gridvolume.cpp:196-198 */
     Float densityMap[256];  /* gridvolume.cpp:204-214 */
     bool valid;
@@ -128,13 +132,37 @@ struct Grid {
         for (int i = 0; i < 3; ++i) { res[i] = g.res[i]; bmin[i] = g.aabb_min[i]; bmax[i] = g.aabb_max[i]; }
         channels = g.channels; dtype = g.dtype; data = g.data;
         std::memset(m, 0, sizeof(m));
+        bool zero = true; affine = false;
+        for (int i = 0; i < 12; i++) zero = zero && g.world_to_volume[i] == 0.0f;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) {
+            w2v[i][j] = zero ? (i == j ? 1.0f : 0.0f) : g.world_to_volume[i * 4 + j];
+            if (w2v[i][j] != (i == j ? 1.0f : 0.0f)) affine = true;
+        }
         stepSize = std::numeric_limits<Float>::infinity();
         for (int i = 0; i < 3; ++i) {
             Float extent = bmax[i] - bmin[i];
             Float s = (Float) (res[i] - 1) / extent;       /* Transform::scale((res-1)/extents) */
-            m[i][i] = s;
-            m[i][3] = s * (-bmin[i]);                       /* * Transform::translate(-min); toWorld = identity */
+            /* (scale * translate(-min)) * worldToVolume: the 4x4 products of src/libcore/transform.cpp; zero terms add nothing */
+            this->s[i] = s; t[i] = s * (-bmin[i]);
+            for (int j = 0; j < 3; j++) m[i][j] = s * w2v[i][j];
+            m[i][3] = s * w2v[i][3] + t[i];
             stepSize = std::min(stepSize, 0.5f * extent / (Float) (res[i] - 1));
+        }
+        {   /* m_aabb (gridvolume.cpp:199-203): corners of the data box under volumeToWorld = W^-1 (cofactors, double) */
+            const double a = w2v[0][0], b = w2v[0][1], c = w2v[0][2], d = w2v[1][0], e = w2v[1][1], f = w2v[1][2], gg = w2v[2][0], h = w2v[2][1], k = w2v[2][2];
+            const double det = a * (e * k - f * h) - b * (d * k - f * gg) + c * (d * h - e * gg);
+            const double inv[9] = {(e * k - f * h) / det, (c * h - b * k) / det, (b * f - c * e) / det,
+                                   (f * gg - d * k) / det, (a * k - c * gg) / det, (c * d - a * f) / det,
+                                   (d * h - e * gg) / det, (b * gg - a * h) / det, (a * e - b * d) / det};
+            for (int i = 0; i < 3; i++) { wmin[i] = std::numeric_limits<Float>::infinity(); wmax[i] = -std::numeric_limits<Float>::infinity(); }
+            for (int corner = 0; corner < 8; corner++) {
+                const double q[3] = {((corner & 1) ? bmax[0] : bmin[0]) - (double) w2v[0][3], ((corner & 2) ? bmax[1] : bmin[1]) - (double) w2v[1][3],
+                                     ((corner & 4) ? bmax[2] : bmin[2]) - (double) w2v[2][3]};
+                for (int i = 0; i < 3; i++) {
+                    const Float w = (Float) (inv[i * 3] * q[0] + inv[i * 3 + 1] * q[1] + inv[i * 3 + 2] * q[2]);
+                    wmin[i] = std::min(wmin[i], w); wmax[i] = std::max(wmax[i], w);
+                }
+            }
         }
         for (int i = 0; i < 255; ++i) densityMap[i] = i / 255.0f;
         densityMap[255] = 1.0f;
@@ -189,7 +217,17 @@ struct Grid {
     }
     /* include/mitsuba/core/aabb.h:308-339 */
     inline bool rayIntersect(const Vec &o, const Vec &d, Float &nearT, Float &farT) const {
-        return aabbIntersect(bmin, bmax, o, d, nearT, farT);
+        return aabbIntersect(wmin, wmax, o, d, nearT, farT);          /* m_aabb: world space */
+    }
+    /* splinevolume.cpp:320-376: p = m_worldToVolume(pc); gradients come back through m_worldToVolume_RotT */
+    template <typename FLOAT> inline V3<FLOAT> toVolume(const V3<FLOAT> &p) const {
+        return V3<FLOAT>((FLOAT) w2v[0][0] * p.x + (FLOAT) w2v[0][1] * p.y + (FLOAT) w2v[0][2] * p.z + (FLOAT) w2v[0][3],
+                         (FLOAT) w2v[1][0] * p.x + (FLOAT) w2v[1][1] * p.y + (FLOAT) w2v[1][2] * p.z + (FLOAT) w2v[1][3],
+                         (FLOAT) w2v[2][0] * p.x + (FLOAT) w2v[2][1] * p.y + (FLOAT) w2v[2][2] * p.z + (FLOAT) w2v[2][3]);
+    }
+    template <typename FLOAT> inline V3<FLOAT> rotT(const V3<FLOAT> &v) const {
+        return V3<FLOAT>((FLOAT) w2v[0][0] * v.x + (FLOAT) w2v[1][0] * v.y + (FLOAT) w2v[2][0] * v.z, (FLOAT) w2v[0][1] * v.x + (FLOAT) w2v[1][1] * v.y + (FLOAT) w2v[2][1] * v.z,
+                         (FLOAT) w2v[0][2] * v.x + (FLOAT) w2v[1][2] * v.y + (FLOAT) w2v[2][2] * v.z);
     }
     static inline bool aabbIntersect(const Float mn[3], const Float mx[3], const Vec &o, const Vec &d, Float &nearT, Float &farT) {
         nearT = -std::numeric_limits<Float>::infinity();
@@ -217,9 +255,10 @@ struct Grid {
    restatement: fused lerps lerp(a,b,f) = fma(f, b-a, a), the same expression tree the HIP kernel uses. */
 template <typename FLOAT>
 inline void trilinearValueGrad(const Grid &g, const V3<FLOAT> &pw, FLOAT &val, V3<FLOAT> &grad) {
-    const FLOAT px = std::fma((FLOAT) g.m[0][0], pw.x, (FLOAT) g.m[0][3]);
-    const FLOAT py = std::fma((FLOAT) g.m[1][1], pw.y, (FLOAT) g.m[1][3]);
-    const FLOAT pz = std::fma((FLOAT) g.m[2][2], pw.z, (FLOAT) g.m[2][3]);
+    /* pw: the point in VOLUME space (Rif applies worldToVolume first when the grid has a toWorld) */
+    const FLOAT px = std::fma((FLOAT) g.s[0], pw.x, (FLOAT) g.t[0]);
+    const FLOAT py = std::fma((FLOAT) g.s[1], pw.y, (FLOAT) g.t[1]);
+    const FLOAT pz = std::fma((FLOAT) g.s[2], pw.z, (FLOAT) g.t[2]);
     int x1 = (int) std::floor(px), y1 = (int) std::floor(py), z1 = (int) std::floor(pz);
     x1 = std::min(std::max(x1, 0), g.res[0] - 2);
     y1 = std::min(std::max(y1, 0), g.res[1] - 2);
@@ -239,7 +278,7 @@ inline void trilinearValueGrad(const Grid &g, const V3<FLOAT> &pw, FLOAT &val, V
     const FLOAT gy = std::fma(fz, dy1 - dy0, dy0);
     const FLOAT gxa = std::fma(fy, dx01 - dx00, dx00), gxb = std::fma(fy, dx11 - dx10, dx10);
     const FLOAT gx = std::fma(fz, gxb - gxa, gxa);
-    grad = V3<FLOAT>(gx * (FLOAT) g.m[0][0], gy * (FLOAT) g.m[1][1], gz * (FLOAT) g.m[2][2]);
+    grad = V3<FLOAT>(gx * (FLOAT) g.s[0], gy * (FLOAT) g.s[1], gz * (FLOAT) g.s[2]);
 }
 
 /* ------------------------------------------------------------------ A5 cubic B-spline (basisspline.h) */
@@ -488,37 +527,53 @@ template <typename FLOAT> struct Rif {
         }
     }
     /* splinevolume.cpp:319-324 */
-    inline bool insideVolumeLimits(const V3<FLOAT> &p) const {
+    inline bool insideVolumeLimits(const V3<FLOAT> &pw) const {
         if (mode != ORC_RIF_BSPLINE3) return true;
+        const V3<FLOAT> p = grid.affine ? grid.toVolume(pw) : pw;
         return p.x > limMin[0] && p.x < limMax[0] && p.y > limMin[1] && p.y < limMax[1] && p.z > limMin[2] && p.z < limMax[2];
     }
-    inline FLOAT value(const V3<FLOAT> &p, Counters &C) const {
+    inline FLOAT value(const V3<FLOAT> &pw, Counters &C) const {
         C.c[ORC_C_RIF_EVALS]++;
         if (mode == ORC_RIF_CONST) return cst;
-        if (mode == ORC_RIF_ACOUSTIC) { FLOAT v; V3<FLOAT> g; ac.valueAndGradient(p, v, g); return v; }
+        if (mode == ORC_RIF_ACOUSTIC) { FLOAT v; V3<FLOAT> g; ac.valueAndGradient(pw, v, g); return v; }
+        const V3<FLOAT> p = grid.affine ? grid.toVolume(pw) : pw;
         if (mode == ORC_RIF_TRILINEAR) { FLOAT v; V3<FLOAT> g; trilinearValueGrad<FLOAT>(grid, p, v, g); return v; }
         FLOAT x[3] = {p.x, p.y, p.z};
         return spline.value(x);              /* splinevolume.cpp:330-337 */
     }
-    inline void valueAndGradient(const V3<FLOAT> &p, FLOAT &n, V3<FLOAT> &g, Counters &C) const {
+    inline void valueAndGradient(const V3<FLOAT> &pw, FLOAT &n, V3<FLOAT> &g, Counters &C) const {
         C.c[ORC_C_RIF_EVALS]++;
         if (mode == ORC_RIF_CONST) { n = cst; g = V3<FLOAT>(0, 0, 0); return; }
-        if (mode == ORC_RIF_ACOUSTIC) { ac.valueAndGradient(p, n, g); return; }
-        if (mode == ORC_RIF_TRILINEAR) { trilinearValueGrad<FLOAT>(grid, p, n, g); return; }
-        FLOAT x[3] = {p.x, p.y, p.z};
-        spline.valueAndGradient(x, n, g);    /* splinevolume.cpp:354-360 (rotation = identity) */
+        if (mode == ORC_RIF_ACOUSTIC) { ac.valueAndGradient(pw, n, g); return; }
+        const V3<FLOAT> p = grid.affine ? grid.toVolume(pw) : pw;
+        if (mode == ORC_RIF_TRILINEAR) trilinearValueGrad<FLOAT>(grid, p, n, g);
+        else { FLOAT x[3] = {p.x, p.y, p.z}; spline.valueAndGradient(x, n, g); }    /* splinevolume.cpp:354-360 */
+        if (grid.affine) g = grid.rotT(g);                                            /* v = m_worldToVolume_RotT * v (:359) */
     }
-    inline V3<FLOAT> gradient(const V3<FLOAT> &p, Counters &C) const {
+    inline V3<FLOAT> gradient(const V3<FLOAT> &pw, Counters &C) const {
         C.c[ORC_C_RIF_EVALS]++;
         if (mode == ORC_RIF_CONST) return V3<FLOAT>(0, 0, 0);
-        if (mode == ORC_RIF_ACOUSTIC) { FLOAT v; V3<FLOAT> g; ac.valueAndGradient(p, v, g); return g; }
-        if (mode == ORC_RIF_TRILINEAR) { FLOAT v; V3<FLOAT> g; trilinearValueGrad<FLOAT>(grid, p, v, g); return g; }
-        FLOAT x[3] = {p.x, p.y, p.z};
-        return spline.gradient(x);           /* splinevolume.cpp:338-344 */
+        if (mode == ORC_RIF_ACOUSTIC) { FLOAT v; V3<FLOAT> g; ac.valueAndGradient(pw, v, g); return g; }
+        const V3<FLOAT> p = grid.affine ? grid.toVolume(pw) : pw;
+        V3<FLOAT> g;
+        if (mode == ORC_RIF_TRILINEAR) { FLOAT v; trilinearValueGrad<FLOAT>(grid, p, v, g); }
+        else { FLOAT x[3] = {p.x, p.y, p.z}; g = spline.gradient(x); }               /* splinevolume.cpp:338-344 */
+        return grid.affine ? grid.rotT(g) : g;
     }
     /* splinevolume.cpp:370-376 valueGradientAndHessian; H row-major.  Trilinear: Hessian of the interpolant (only the
        mixed terms are non-zero inside a cell) -- new, SURVEY D2. */
-    inline void valueGradientAndHessian(const V3<FLOAT> &p, FLOAT &n, V3<FLOAT> &g, FLOAT H[9], Counters &C) const {
+    inline void valueGradientAndHessian(const V3<FLOAT> &pw, FLOAT &n, V3<FLOAT> &g, FLOAT H[9], Counters &C) const {
+        if (mode == ORC_RIF_CONST || mode == ORC_RIF_ACOUSTIC || !grid.affine) { valueGradientAndHessianVol(pw, n, g, H, C); return; }
+        valueGradientAndHessianVol(grid.toVolume(pw), n, g, H, C);
+        g = grid.rotT(g);
+        /* M = m_worldToVolume_RotT * M * m_worldToVolume_Rot (splinevolume.cpp:367,375) */
+        FLOAT Rm[3][3], T1[3][3];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rm[i][j] = (FLOAT) grid.w2v[i][j];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { FLOAT a = 0; for (int k = 0; k < 3; k++) a += Rm[k][i] * H[k * 3 + j]; T1[i][j] = a; }
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { FLOAT a = 0; for (int k = 0; k < 3; k++) a += T1[i][k] * Rm[k][j]; H[i * 3 + j] = a; }
+    }
+    /* in volume space */
+    inline void valueGradientAndHessianVol(const V3<FLOAT> &p, FLOAT &n, V3<FLOAT> &g, FLOAT H[9], Counters &C) const {
         C.c[ORC_C_RIF_EVALS]++;
         for (int i = 0; i < 9; i++) H[i] = 0;
         if (mode == ORC_RIF_CONST) { n = cst; g = V3<FLOAT>(0, 0, 0); return; }
@@ -526,8 +581,8 @@ template <typename FLOAT> struct Rif {
         if (mode == ORC_RIF_BSPLINE3) { FLOAT x[3] = {p.x, p.y, p.z}; spline.valueGradientAndHessian(x, n, g, H); return; }
         trilinearValueGrad<FLOAT>(grid, p, n, g);
         const Grid &G = grid;
-        const FLOAT px = std::fma((FLOAT) G.m[0][0], p.x, (FLOAT) G.m[0][3]), py = std::fma((FLOAT) G.m[1][1], p.y, (FLOAT) G.m[1][3]),
-                    pz = std::fma((FLOAT) G.m[2][2], p.z, (FLOAT) G.m[2][3]);
+        const FLOAT px = std::fma((FLOAT) G.s[0], p.x, (FLOAT) G.t[0]), py = std::fma((FLOAT) G.s[1], p.y, (FLOAT) G.t[1]),
+                    pz = std::fma((FLOAT) G.s[2], p.z, (FLOAT) G.t[2]);
         int x1 = std::min(std::max((int) std::floor(px), 0), G.res[0] - 2), y1 = std::min(std::max((int) std::floor(py), 0), G.res[1] - 2),
             z1 = std::min(std::max((int) std::floor(pz), 0), G.res[2] - 2);
         const FLOAT fx = px - x1, fy = py - y1, fz = pz - z1;
@@ -535,7 +590,7 @@ template <typename FLOAT> struct Rif {
         const int base = (z1 * G.res[1] + y1) * G.res[0] + x1, sy = G.res[0], sz = G.res[0] * G.res[1];
         const FLOAT d000 = D[base], d001 = D[base + 1], d010 = D[base + sy], d011 = D[base + sy + 1],
                     d100 = D[base + sz], d101 = D[base + sz + 1], d110 = D[base + sz + sy], d111 = D[base + sz + sy + 1];
-        const FLOAT sx = G.m[0][0], syy = G.m[1][1], szz = G.m[2][2];
+        const FLOAT sx = G.s[0], syy = G.s[1], szz = G.s[2];
         const FLOAT hxy = ((d011 - d010 - d001 + d000) * (1 - fz) + (d111 - d110 - d101 + d100) * fz) * sx * syy;
         const FLOAT hyz = ((d110 - d100 - d010 + d000) * (1 - fx) + (d111 - d101 - d011 + d001) * fx) * syy * szz;
         const FLOAT hzx = ((d101 - d100 - d001 + d000) * (1 - fy) + (d111 - d110 - d011 + d010) * fy) * szz * sx;
@@ -746,7 +801,7 @@ struct Scene {
         if (s.boundary == ORC_BOUNDARY_SDF) {
             /* sphere tracing on the signed-distance grid (new: the reference intersects the mesh; the SDF is its inside test).  A start
                point near the surface counts as inside (eps = 1e-4 x grid diagonal): the walk then looks for the exit */
-            if (!Grid::aabbIntersect(sdfGrid.bmin, sdfGrid.bmax, o, d, nearT, farT)) return -1;
+            if (!Grid::aabbIntersect(sdfGrid.wmin, sdfGrid.wmax, o, d, nearT, farT)) return -1;
             const Float t0 = std::max(nearT, mint), t1 = std::min(farT, maxt);
             if (!(t0 <= t1)) return -1;
             Float t = t0;
@@ -813,7 +868,8 @@ struct Scene {
         if (s.rif_mode == ORC_RIF_CONST) return s.rif_const;
         Counters dummy; Vec q = x;
         const Float *mn = s.rif.aabb_min, *mx = s.rif.aabb_max;
-        if (s.rif_mode != ORC_RIF_ACOUSTIC) {                    /* the analytic field has no grid to stay inside of */
+        bool w = false; for (int i = 0; i < 12; i++) w = w || (s.rif.world_to_volume[i] != 0.0f && s.rif.world_to_volume[i] != ((i % 5 == 0) ? 1.0f : 0.0f));
+        if (s.rif_mode != ORC_RIF_ACOUSTIC && !w) {              /* the analytic field has no grid to stay inside of; a transformed one clamps its cell */
             q.x = std::min(std::max(q.x, mn[0]), mx[0]); q.y = std::min(std::max(q.y, mn[1]), mx[1]); q.z = std::min(std::max(q.z, mn[2]), mx[2]);
         }
         return s.rif_double ? (Float) rifD.value(V3<double>(q), dummy) : rifF.value(V3<float>(q), dummy);

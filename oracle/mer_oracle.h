@@ -30,6 +30,7 @@ typedef struct {
     int32_t channels;          /* 1 or 3 */
     int32_t dtype;             /* ORC_VOL_F32 | ORC_VOL_U8 */
     float   aabb_min[3], aabb_max[3];
+    float   world_to_volume[12];   /* inverse of the plugin's toWorld, row-major 3x4; all zeros = identity (gridvolume.cpp:110,188-195) */
     const void *data;          /* x fastest: data[((z*yres+y)*xres+x)*ch+c] */
 } orc_grid;
 

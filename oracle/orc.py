@@ -27,7 +27,7 @@ C_COUNT = 16
 
 class Grid(C.Structure):
     _fields_ = [("res", C.c_int32 * 3), ("channels", C.c_int32), ("dtype", C.c_int32),
-                ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3), ("data", C.c_void_p)]
+                ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3), ("world_to_volume", C.c_float * 12), ("data", C.c_void_p)]
 
 
 class Scene(C.Structure):
@@ -88,11 +88,14 @@ def _fp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def make_grid(data, aabb_min, aabb_max, keep):
-    """data: numpy array indexed [z][y][x] (or [z][y][x][c]); float32 or uint8."""
+def make_grid(data, aabb_min, aabb_max, keep, to_world=None):
+    """data: numpy array indexed [z][y][x] (or [z][y][x][c]); float32 or uint8; to_world: the plugin's toWorld (None = identity)."""
     g = Grid()
     if data is None:
         return g
+    if to_world is not None:
+        m = np.eye(4); t = np.asarray(to_world, np.float64); m[:t.shape[0], :4] = t
+        g.world_to_volume[:] = [float(v) for v in np.linalg.inv(m)[:3, :4].astype(np.float32).reshape(-1)]
     a = np.ascontiguousarray(data)
     keep.append(a)
     ch = 1 if a.ndim == 3 else a.shape[3]
@@ -134,16 +137,16 @@ def make_scene(p):
     s.sigma_a[:] = p.sigma_a; s.sigma_s[:] = p.sigma_s
     s.strategy, s.channel, s.sampling_density = p.strategy, p.channel, p.sampling_density
     s.medium_sampling_weight = p.medium_sampling_weight
-    s.density = make_grid(p.density, p.density_aabb[0], p.density_aabb[1], keep) if p.density is not None else Grid()
+    s.density = make_grid(p.density, p.density_aabb[0], p.density_aabb[1], keep, getattr(p, "density_to_world", None)) if p.density is not None else Grid()
     s.density_scale = p.density_scale
     s.albedo_mode = p.albedo_mode
     s.albedo[:] = p.albedo
-    s.albedo_grid = make_grid(p.albedo_grid, p.albedo_aabb[0], p.albedo_aabb[1], keep) if p.albedo_grid is not None else Grid()
+    s.albedo_grid = make_grid(p.albedo_grid, p.albedo_aabb[0], p.albedo_aabb[1], keep, getattr(p, "albedo_to_world", None)) if p.albedo_grid is not None else Grid()
     s.rif_mode, s.rif_const = p.rif_mode, p.rif_const
-    s.rif = make_grid(p.rif, p.rif_aabb[0], p.rif_aabb[1], keep) if (p.rif is not None and p.rif_mode != 8) else Grid()
+    s.rif = make_grid(p.rif, p.rif_aabb[0], p.rif_aabb[1], keep, getattr(p, "rif_to_world", None)) if (p.rif is not None and p.rif_mode != 8) else Grid()
     s.ac_n_o, s.ac_n_max, s.ac_k_r, s.ac_mode = (float(getattr(p, "ac_n_o", 1.0)), float(getattr(p, "ac_n_max", 0.0)),
                                                  float(getattr(p, "ac_k_r", 1.0)), int(getattr(p, "ac_mode", 0)))
-    s.sdf = make_grid(p.sdf, p.sdf_aabb[0], p.sdf_aabb[1], keep) if p.sdf is not None else Grid()
+    s.sdf = make_grid(p.sdf, p.sdf_aabb[0], p.sdf_aabb[1], keep, getattr(p, "sdf_to_world", None)) if p.sdf is not None else Grid()
     s.stepper, s.stepsize, s.rif_double = p.stepper, p.stepsize, int(getattr(p, "rif_double", 0))
     s.phase, s.g = p.phase, p.g
     s.tr_estimator = p.tr_estimator
@@ -158,9 +161,9 @@ def make_scene(p):
     return s, keep
 
 
-def lookup_trilinear(data, aabb_min, aabb_max, pts):
+def lookup_trilinear(data, aabb_min, aabb_max, pts, to_world=None):
     keep = []
-    g = make_grid(data, aabb_min, aabb_max, keep)
+    g = make_grid(data, aabb_min, aabb_max, keep, to_world)
     pts = np.ascontiguousarray(pts, np.float32)
     n = pts.shape[0]
     val = np.empty(n, np.float32)
@@ -169,9 +172,9 @@ def lookup_trilinear(data, aabb_min, aabb_max, pts):
     return val, idx
 
 
-def lookup_trilinear_rgb(data, aabb_min, aabb_max, pts):
+def lookup_trilinear_rgb(data, aabb_min, aabb_max, pts, to_world=None):
     keep = []
-    g = make_grid(data, aabb_min, aabb_max, keep)
+    g = make_grid(data, aabb_min, aabb_max, keep, to_world)
     pts = np.ascontiguousarray(pts, np.float32)
     n = pts.shape[0]
     out = np.empty((n, 3), np.float32)

@@ -236,3 +236,48 @@ def test_curved_ray_connection(ctx, orc, kind):
     assert (a[ok, 8] >= chord - 5e-3).all()                      # h = 0.043 here; closest approach within sqrt(2 tol2) of p2
     n1, _ = ctx.rif_value_grad([v for v in vols if v is not None][1 if kind == "trilinear_sdf" else -1], P.RIF_BSPLINE3 if kind == "bspline" else P.RIF_TRILINEAR, p1[ok])
     assert np.abs(np.linalg.norm(a[ok, 2:5], axis=1) - n1).max() < 1e-4       # |v0| = n(p1)
+
+
+def test_lookups_under_a_rotated_data_box(ctx, orc):
+    """A2 with the volume plugin's `toWorld` (gridvolume.cpp:110,188-195): worldToGrid = scale * translate * toWorld^-1 is a full
+    affine map.  The integer contract (cell, bounds test, linear index) stays bit-exact against the oracle; values to rounding."""
+    rng = np.random.RandomState(5)
+    data = rng.rand(17, 19, 23).astype(np.float32)
+    rgb = rng.rand(9, 8, 7, 3).astype(np.float32)
+    tw = P.rotation([1, 2, 3], 35.0, [0.05, -0.1, 0.08])
+    mn, mx = [-1, -0.8, -0.6], [1, 0.9, 0.7]
+    pts = scenes.rand_points(200000, -1.3, 1.3, seed=9)
+    for lay in (capi.LAYOUT_DENSE, capi.LAYOUT_CELL8):
+        v = ctx.upload_volume(data, mn, mx, lay, to_world=tw)
+        val, idx = ctx.lookup_trilinear(v, pts)
+        rv, ri = orc.lookup_trilinear(data, mn, mx, pts, to_world=tw)
+        assert np.array_equal(idx, ri) and (ri[:, 3] >= 0).mean() > 0.2 and (ri[:, 3] < 0).mean() > 0.2
+        assert np.array_equal(val.view(np.uint32), rv.view(np.uint32))
+        v.destroy()
+    v = ctx.upload_volume(rgb, mn, mx, to_world=tw)
+    assert np.array_equal(ctx.lookup_trilinear_rgb(v, pts).view(np.uint32), orc.lookup_trilinear_rgb(rgb, mn, mx, pts, to_world=tw).view(np.uint32))
+    v.destroy()
+    with pytest.raises(capi.MerError, match="not invertible"):
+        ctx.upload_volume(data, mn, mx, to_world=np.diag([1e20, 1.0, 1.0, 1.0]))        # its inverse has determinant 1e-20
+
+
+@pytest.mark.parametrize("interp", ["trilinear", "bspline"])
+def test_rif_value_and_gradient_under_a_rotated_data_box(ctx, orc, interp):
+    """RIF volumes with a `toWorld`: the point goes through worldToVolume, the gradient comes back through its rotation transposed
+    (splinevolume.cpp:343,359); the gradient of a field that is linear in VOLUME space is the rotated constant vector."""
+    N = 20
+    tw = P.rotation([0, 0, 1], 30.0, [0.1, 0.0, -0.05])
+    ax = np.linspace(-1.3, 1.3, N)
+    z, y, x = np.meshgrid(ax, ax, ax, indexing="ij")
+    data = (1.4 + 0.1 * x - 0.05 * y + 0.02 * z).astype(np.float32)
+    p = scenes.bspline_scene(N=16) if interp == "bspline" else scenes.curved_scene(N=16)
+    p = p.copy(rif=data, rif_aabb=([-1.3] * 3, [1.3] * 3), rif_to_world=tw)
+    sc, vols = ctx.upload_scene(p)
+    pts = scenes.rand_points(4096, -0.55, 0.55, seed=3)                  # inside the spline-safe box also after the rotation
+    val, grad = ctx.rif_value_grad(vols[-1], P.RIF_BSPLINE3 if interp == "bspline" else P.RIF_TRILINEAR, pts)
+    rv, rg, _ = orc.rif_eval(p, pts)
+    assert np.abs(val - rv).max() < 2e-5 and np.abs(grad - rg).max() < 2e-4
+    g_world = np.asarray(tw)[:3, :3] @ np.array([0.1, -0.05, 0.02])
+    assert np.abs(grad - g_world[None, :]).max() < 2e-3
+    for v in vols:
+        v.destroy()
