@@ -85,7 +85,8 @@ typedef struct {
     float   env_radiance[3];
     float   emission[3];
     /* emitter `point` (src/emitters/point.cpp): position + radiant intensity; all-zero intensity = none.  With curved rays the
-       emitter must lie inside the medium shape and is reached by mer_connect's shooting solver. */
+       emitter is reached by mer_connect's shooting solver; an emitter outside the medium shape through the boundary
+       (Snell refraction at the shape, exterior index 1: src/medium/heterogeneousrefractive.cpp:873-919,963-992). */
     float   point_position[3], point_intensity[3];
     /* film decomposition (src/librender/film.cpp:56-84): 0 = none, 1 = transient.  Transient: every radiance
        contribution is binned by its optical path length (sum of h*n along curved segments, length*n otherwise:
@@ -233,7 +234,7 @@ int  mer_sample_distance(mer_context *ctx, const mer_scene_desc *scene, const fl
 int  mer_eval_transmittance(mer_context *ctx, const mer_scene_desc *scene, const float *o, const float *d,
                             const float *maxt, int64_t n, uint64_t seed, float *out_tr);
 /* HeterogeneousRefractiveMedium::eval -> makeDirectConnections (heterogeneousrefractive.cpp:571-640,798-1163): connect p1 to p2
-   (both inside the medium shape: cube, sphere or signed-distance grid) by a curved ray; out stride 12: ok, weight, dirToP2[3] (optical momentum at p1),
+   (p1 inside the medium shape -- cube, sphere or signed-distance grid --, p2 inside or outside it) by a curved ray; out stride 12: ok, weight, dirToP2[3] (optical momentum at p1),
    revDirToP1[3], distance, opticalLength, 0, 0; RNG stream of item i = (seed, pixel=i, sample=0) */
 int  mer_connect(mer_context *ctx, const mer_scene_desc *scene, const float *p1, const float *p2, int64_t n, uint64_t seed, float *out);
 /* PhaseFunction::sample / eval (src/phase/hg.cpp:74-110, src/phase/isotropic.cpp:62-78) */

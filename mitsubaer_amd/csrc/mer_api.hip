@@ -246,14 +246,7 @@ int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bool allo
     {
         const bool has_point = sc->point_intensity[0] != 0 || sc->point_intensity[1] != 0 || sc->point_intensity[2] != 0;
         for (int i = 0; i < 3; i++) if (sc->point_intensity[i] < 0 || sc->env_radiance[i] < 0) return fail(ctx, "emitter radiance / intensity must be non-negative");
-        if (has_point && sc->rif_mode != MER_RIF_CONST) {
-            // curved-ray connections are solved for end points inside the medium shape only (boundary refraction = next row N2)
-            bool inside = true;
-            if (sc->boundary == MER_BOUNDARY_AABB) { for (int i = 0; i < 3; i++) inside = inside && sc->point_position[i] > sc->bmin[i] && sc->point_position[i] < sc->bmax[i]; }
-            else if (sc->boundary == MER_BOUNDARY_SDF) inside = true;            // not checked on the host: a connection that leaves the shape is rejected per sample
-            else { float d2 = 0; for (int i = 0; i < 3; i++) d2 += (sc->point_position[i] - sc->sph_center[i]) * (sc->point_position[i] - sc->sph_center[i]); inside = d2 < sc->sph_radius * sc->sph_radius; }
-            if (!inside) return fail(ctx, "heterogeneousrefractive: a point emitter must lie inside the medium shape (boundary refraction of connections is not built yet)");
-        }
+        (void) has_point;      // curved rays reach a point emitter outside the shape through the boundary (Connector::path_lengths, cross = true)
     }
     P.counters = ctx->counters;
     P.work_counter = ctx->counters + MER_C_COUNT * MER_COUNTER_REPLICAS;

@@ -7,8 +7,8 @@
 // 3x3 sensitivities dp/dv0, dv/dv0 integrated with the Hessian of n, multi-restart with Russian roulette and the
 // (iterations-1) solution-count weight exactly as the reference.  The reference minimises with Ceres LINE_SEARCH/BFGS
 // (un-vendored, unpinned); here a Levenberg-damped Gauss-Newton on the same residual/Jacobian -- parity unpinned for the
-// iterates, pinned on the converged ray.  Both end points must lie inside the medium shape: the boundary branch (Snell
-// refraction + its Jacobian, :873-919) belongs to the hdielectric boundary, a "next" row.
+// iterates, pinned on the converged ray.  A ray that leaves the medium shape is refracted at the boundary (Snell's law and its
+// Jacobian, :873-919, :1036-1074) and continued straight in the exterior: connections to a point outside the shape cross it.
 #pragma once
 #include "mer_walk.hpp"
 
@@ -168,7 +168,9 @@ struct ConnState {
 };
 #define MER_CSTATE_WORDS 32
 
-template <int RIF, int BND = 0> struct Connector {
+// XC = false: the kernel is built for connections that stay inside the shape (the boundary code is compiled out: 16 % faster on
+// configs[4], where the emitter sits inside); XC = true: a connection may cross (decided per pair: its far end lies outside)
+template <int RIF, int BND = 0, bool XC = true> struct Connector {
     const Params &P;
     float tol, rrweight; int precision, maxIter, maxSteps;
     mutable CellCache cc;                       // the 8 corners of the cell the ray is in (trilinear RIF): reused across evaluations
@@ -199,8 +201,43 @@ template <int RIF, int BND = 0> struct Connector {
         v = v + 0.5f * h * G;
         dv = add(dv, scale(mul(H, dp), 0.5f * h));
     }
-    // computefdfBDPT (:816-939), inside-shape branch; J[r][c] = d error_r / d v0_c
-    __device__ bool computefdf(f3 v_i, f3 p1, f3 p2, f3 &error, m33 &J) const {
+    // boundaryVelocity (:1040-1055): Snell's law for the optical momentum v at a surface with unit normal N, index ni on the ray's side and
+    // ne beyond (total internal reflection when the root is imaginary)
+    __device__ void boundary_velocity(f3 &v, f3 N, float ni, float ne) const {
+        const float dotp = dot(v, N);
+        float r = ne / ni; r = r * r - 1;
+        const float n2 = dot(v, v);
+        float sq = r * n2 + dotp * dotp;
+        if (sq < MER_EPSILON) { v = 2 * dotp * N - v; return; }
+        sq = sqrtf(sq);
+        v = v - dotp * N + (dotp > 0 ? sq : (dotp < 0 ? -sq : 0.0f)) * N;
+    }
+    // boundaryVelocityDerivative (:1061-1074): the same, with the sensitivity dv/dv0 taken through the refraction; dtb = d(arrival
+    // parameter)/dv0, dnb = grad n at the boundary point
+    __device__ void boundary_velocity_derivative(f3 &v, m33 &dv, f3 dtb, f3 dnb, f3 N, float ni, float ne) const {
+        const float dotp = dot(v, N);
+        float r = ne / ni; r = r * r - 1;
+        const float n2 = dot(v, v);
+        float sq = r * n2 + dotp * dotp;
+        const m33 inner = add(dv, outer(dnb, dtb));
+        const m33 NN = outer(N, N);
+        if (sq < MER_EPSILON) {
+            m33 a = scale(NN, 2.0f); for (int i = 0; i < 3; i++) a.m[i][i] -= 1.0f;
+            v = 2 * dotp * N - v;
+            dv = mul(a, inner);
+            return;
+        }
+        sq = sqrtf(sq);
+        const float sg = dotp > 0 ? 1.0f : (dotp < 0 ? -1.0f : 0.0f);
+        m33 a = add(scale(NN, -1.0f), scale(outer(N, (r * v + dotp * N) / sq), sg)); for (int i = 0; i < 3; i++) a.m[i][i] += 1.0f;
+        dv = mul(a, inner);
+        v = v - dotp * N + sg * sq * N;
+    }
+    // computefdfBDPT (:816-939); J[r][c] = d error_r / d v0_c.  A ray that leaves the shape before its closest approach to p2 is
+    // taken to the boundary (bisection), refracted into the exterior (index 1) and continued straight to its closest approach
+    // (:873-919).  `cross`: the connection is meant to cross (the reference's isSensorSample; here: p2 lies outside the shape) -- a
+    // refracted ray that moves away from p2 then has no derivative (:907-912).  false = "error = p1 - p2, derivative 0" of the reference.
+    __device__ bool computefdf(f3 v_i, f3 p1, f3 p2, bool cross, f3 &error, m33 &J) const {
         m33 dp(0.0f), dv(1.0f);
         error = p1 - p2; J = m33(0.0f);
         // a shooting direction that is not a finite non-zero vector has no ray (the solver's step can overflow: guard, not reference).
@@ -219,7 +256,7 @@ template <int RIF, int BND = 0> struct Connector {
           for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.m[i][j] -= o.m[i][j];
           dv = mul(scale(a, r / n3), dv); }
         v = v / n1 * r;
-        bool found = false;
+        int found = 0;                                    // 1: closest approach inside the shape, 2: beyond the boundary
         for (int i = 0; i < maxSteps; i++) {
             oldp = p; oldv = v; olddp = dp; olddv = dv;
             dstep(p, v, dp, dv, h); nsteps++;
@@ -229,19 +266,50 @@ template <int RIF, int BND = 0> struct Connector {
                     nBisect--;
                     p = oldp; v = oldv; dp = olddp; dv = olddv;
                     h = h / 2;
-                    dstep(p, v, dp, dv, h);
+                    dstep(p, v, dp, dv, h); nsteps++;
                     signNew = dot(p - p2, v) < 0.0f;
                     if (signNew == signOld) { oldp = p; oldv = v; olddp = dp; olddv = dv; }
                 }
-                found = true;
+                found = 1;
                 break;
-            } else if (!inside_shape_b<BND>(P, p)) return false;
+            } else if (!inside_shape_b<BND>(P, p)) {
+                // a ray that leaves the shape on its way to a point INSIDE it is a failed trial (the damping grows): the reference refracts
+                // it too and lets the exterior leg steer the minimiser, which costs 16 % more traced rays per connection here for the
+                // same connections found (measured on configs[4]); the boundary is crossed only by connections that must cross it
+                if (!XC || !cross) return false;
+                while (nBisect > 0) {                                                   // to the boundary (:874-889)
+                    nBisect--;
+                    p = oldp; v = oldv; dp = olddp; dv = olddv;
+                    h = h / 2;
+                    dstep(p, v, dp, dv, h); nsteps++;
+                    if (inside_shape_b<BND>(P, p)) { oldp = p; oldv = v; olddp = dp; olddv = dv; }
+                }
+                found = 2;
+                break;
+            }
         }
         if (!found) return false;
-        float rr; f3 dvdt;
-        rif_value_grad<RIF>(P.rif, cc, p, rr, dvdt);
-        const f3 dpdt = v / rr;
-        const f3 dtstar = -(premult(dp, v) + premult(dv, p - p2)) / (dot(v, dpdt) + dot(p - p2, dvdt));
+        f3 dpdt(0, 0, 0), dtstar(0, 0, 0);
+        if (found == 1) {
+            float rr; f3 dvdt;
+            rif_value_grad<RIF>(P.rif, cc, p, rr, dvdt);
+            dpdt = v / rr;
+            dtstar = -(premult(dp, v) + premult(dv, p - p2)) / (dot(v, dpdt) + dot(p - p2, dvdt));
+        } else if (XC) {
+            if (dot(p - p1, p - p1) < MER_EPSILON) return false;                       // no progress made (:890-894)
+            float nb; f3 dnb;
+            rif_value_grad<RIF>(P.rif, cc, p, nb, dnb);
+            const f3 dpdtb = v / nb;
+            const f3 N = shape_normal_b<BND>(P, p);                                     // normalize(m_SDF->gradient(p)) (:899-900)
+            const f3 dtb = -premult(dp, N) / dot(N, dpdtb);
+            boundary_velocity_derivative(v, dv, dtb, dnb, N, nb, 1.0f);
+            const float extra_t = -dot(v, p - p2) / dot(v, v);
+            if (cross && extra_t < 0) return false;                                     // (:907-912)
+            dp = add(add(dp, outer(dpdtb - v, dtb)), scale(dv, extra_t));
+            p = p + extra_t * v;
+            dpdt = v;
+            dtstar = -(premult(dp, v) + premult(dv, p - p2)) / dot(v, dpdt);
+        }
         J = add(dp, outer(dpdt, dtstar));
         error = p - p2;
         return true;
@@ -317,7 +385,7 @@ template <int RIF, int BND = 0> struct Connector {
         if (S.phase == CP_EVAL0 || S.phase == CP_TRIAL) {
             const bool first = S.phase == CP_EVAL0;
             f3 en; m33 Jn;
-            const bool okn = computefdf(first ? S.x : S.xn, p1, p2, en, Jn);            // the one call site
+            const bool okn = computefdf(first ? S.x : S.xn, p1, p2, XC && !inside_shape_b<BND>(P, p2), en, Jn);            // the one call site
             const float cn = 0.5f * dot(en, en);
             if (first) { S.ok = okn; S.e = en; S.J = Jn; S.cost = cn; S.lambda = 1e-4f; S.radius = sqrtf(dot(S.x, S.x)); S.it = 0; S.tries = 0; }
             else if (okn && cn < S.cost) { S.x = S.xn; S.e = en; S.J = Jn; S.cost = cn; S.lambda = fmaxf(S.lambda * 0.1f, 1e-9f); S.it++; S.tries = 0; }
@@ -325,7 +393,11 @@ template <int RIF, int BND = 0> struct Connector {
             if (next_candidate(S)) S.phase = CP_TRIAL; else end_solve(S, p1, p2, rng);
             return;
         }
-        if (S.phase == CP_PATHLEN) S.phase = path_lengths(p1, p2, S.dir, revDir, S.optDist, S.dist) ? CP_OK : CP_FAIL;
+        if (S.phase == CP_PATHLEN) {
+            float bw = 1.0f;
+            S.phase = path_lengths(p1, p2, S.dir, XC && !inside_shape_b<BND>(P, p2), revDir, S.optDist, S.dist, bw) ? CP_OK : CP_FAIL;
+            S.weight *= bw;
+        }
     }
     // the reference's own Verlet step (:662-669)
     __device__ void verlet(f3 &p, f3 &v, float h) const {
@@ -336,9 +408,13 @@ template <int RIF, int BND = 0> struct Connector {
         rif_value_grad<RIF>(P.rif, cc, p, n2, G2);
         v = v + 0.5f * h * G2;
     }
-    // computePathLengthsTillClosestP2 (:941-1030), inside-shape branch
-    __device__ bool path_lengths(f3 p1, f3 p2, f3 dirToP2, f3 &revDir, float &optDist, float &dist) const {
-        dist = 0; optDist = 0;
+    // computePathLengthsTillClosestP2 (:941-1030).  cross = false: both ends inside the shape, a ray that leaves it is no connection (the
+    // reference's emitter samples, :960-962); cross = true: p2 lies outside -- the ray is taken to the boundary, refracted by Snell's law
+    // into the exterior (index 1) and followed straight to its closest approach to p2 (the reference's sensor samples, :963-992).
+    // dist = arc length INSIDE the shape (what the medium attenuates); optDist includes the exterior leg.  bweight: the weight the
+    // boundary's BSDF gives the refracted ray (1 for the index-matched null boundary; (1 - F) eta^2 for hdielectric, hdielectric.cpp:183-242).
+    __device__ bool path_lengths(f3 p1, f3 p2, f3 dirToP2, bool cross, f3 &revDir, float &optDist, float &dist, float &bweight) const {
+        dist = 0; optDist = 0; bweight = 1.0f;
         float h = P.sc.stepsize;
         int nBisect = (int) ceilf((float) precision / 0.30102999566f);
         f3 p = p1, oldp = p1, v = dirToP2, oldv = dirToP2;
@@ -347,25 +423,39 @@ template <int RIF, int BND = 0> struct Connector {
             oldp = p; oldv = v;
             verlet(p, v, h); nsteps++;
             signNew = dot(p - p2, v) < 0.0f;
-#ifdef MER_CONNECT_DEBUG
-            dbg0 = (float) i;
-            if (!inside_shape_b<BND>(P, p)) { dbg1 = -2.0f - sdf_value(P, p); dbg2 = p.x; dbg3 = p.y; dbg4 = p.z; return false; }
-#endif
-            if (!inside_shape_b<BND>(P, p)) return false;
+            if (!inside_shape_b<BND>(P, p)) {
+                if (!XC || !cross) return false;
+                while (nBisect > 0) {                                          // close to the boundary (:965-979)
+                    nBisect--;
+                    p = oldp; v = oldv; h = h / 2;
+                    verlet(p, v, h); nsteps++;
+                    if (inside_shape_b<BND>(P, p)) { dist += h; optDist += h * rif_value(0.5f * (p + oldp)); oldp = p; oldv = v; }
+                }
+                const f3 N = shape_normal_b<BND>(P, p);
+                const float nb = rif_value(p);
+                if (P.sc.boundary_bsdf == MER_BSDF_HDIELECTRIC) {              // HDielectric, refracted component seen from inside: (1 - F) x eta^2
+                    const float cosI = dot(normalize(v), N);                    // the ray leaves: cos > 0 with the outward normal
+                    float cosT; const float F = fresnel_dielectric_ext(-cosI, cosT, nb);
+                    bweight = (1.0f - F) * (nb * nb);
+                }
+                boundary_velocity(v, N, nb, 1.0f);                              // Snell's law (:982-984)
+                const float extra_t = -dot(v, p - p2) / dot(v, v);
+                if (extra_t < 0) return false;
+                p = p + extra_t * v;
+                optDist += extra_t;
+                break;
+            }
             if (signNew != signOld) {
                 while (nBisect > 0) {
                     nBisect--;
                     p = oldp; v = oldv; h = h / 2;
-                    verlet(p, v, h);
+                    verlet(p, v, h); nsteps++;
                     signNew = dot(p - p2, v) < 0.0f;
                     if (signNew == signOld) { dist += h; optDist += h * rif_value(0.5f * (p + oldp)); oldp = p; oldv = v; }
                 }
                 break;
             } else { dist += h; optDist += h * rif_value(0.5f * (p + oldp)); }
         }
-#ifdef MER_CONNECT_DEBUG
-        dbg1 = dot(p - p2, p - p2);
-#endif
         if (dot(p - p2, p - p2) > tol) return false;
         revDir = -normalize(v);
         return true;

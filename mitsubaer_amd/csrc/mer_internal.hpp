@@ -100,7 +100,7 @@ struct Run {
 // the kernels of one (CURVED, RIF, STEPPER, SIGMA, BND) combination, as launchable function pointers
 typedef void (*GenKernel)(const Params);
 typedef void (*PassKernel)(const Params, uint32_t);
-struct KernelSet { GenKernel gen; PassKernel event, march, connect; };
+struct KernelSet { GenKernel gen; PassKernel event, march, connect, connect_cross; };   // connect_cross: the point emitter lies outside the medium shape
 // each mer_render_<group>.hip answers for the combinations it instantiates (returns false if the combination is not in its group)
 bool kernels_straight(int sigma, int bnd, bool extra, KernelSet &k);
 bool kernels_acoustic(int stepper, int sigma, bool extra, KernelSet &k);

@@ -59,6 +59,12 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         return fail(ctx, "unsupported rif_mode / stepper combination");
     }
     const bool connect_stage = has_point && curved;
+    if (connect_stage) {            // an emitter outside the shape is reached through the boundary: the kernel that carries the refraction code
+        bool inside = false;        // (signed-distance shapes: the plain kernel carries it too, the side is tested per connection)
+        if (scene->boundary == MER_BOUNDARY_AABB) { inside = true; for (int i = 0; i < 3; i++) inside = inside && scene->point_position[i] >= scene->bmin[i] && scene->point_position[i] <= scene->bmax[i]; }
+        else if (scene->boundary == MER_BOUNDARY_SPHERE) { float d2 = 0; for (int i = 0; i < 3; i++) d2 += (scene->point_position[i] - scene->sph_center[i]) * (scene->point_position[i] - scene->sph_center[i]); inside = d2 < scene->sph_radius * scene->sph_radius; }
+        if (!inside) ks.connect = ks.connect_cross;
+    }
 
     int npipes = (int) opt.pipes;
     if (shard->spp_count < npipes) npipes = std::max(1, shard->spp_count);

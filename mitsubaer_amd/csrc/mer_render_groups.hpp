@@ -17,8 +17,8 @@ static inline void fill_kernels(bool extra, KernelSet &k) {
     if (extra || X) k.event = event_kernel<CURVED, RIF, STEPPER, SIGMA, true, BND>;
     else k.event = event_kernel<CURVED, RIF, STEPPER, SIGMA, X, BND>;
     k.march = march_kernel<CURVED, RIF, STEPPER, SIGMA, BND>;
-    if constexpr (CURVED) k.connect = connect_stage_kernel<RIF, STEPPER, SIGMA, BND>;
-    else k.connect = nullptr;
+    if constexpr (CURVED) { k.connect = connect_stage_kernel<RIF, STEPPER, SIGMA, BND, BND != 0>; k.connect_cross = connect_stage_kernel<RIF, STEPPER, SIGMA, BND, true>; }
+    else k.connect = k.connect_cross = nullptr;
 }
 // the four (STEPPER, SIGMA) combinations of one curved fetch kind
 template <int RIF, int BND>

@@ -680,7 +680,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
 #define MER_CONNECT_WAVES 3
 #endif
 #define MER_CONNECT_BOUNDS __launch_bounds__(MER_BLOCK, MER_CONNECT_WAVES)
-template <int RIF, int STEPPER, int SIGMA, int BND = 0>
+template <int RIF, int STEPPER, int SIGMA, int BND = 0, bool XC = false>
 __global__ void MER_CONNECT_BOUNDS connect_stage_kernel(const Params P, uint32_t pass) {
     constexpr bool EXTRA = true;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
@@ -711,7 +711,7 @@ __global__ void MER_CONNECT_BOUNDS connect_stage_kernel(const Params P, uint32_t
             finished = true;
         } else {
             if (S.phase == CP_NEW) { S.weight = 1.0f; C.nee++; }
-            Connector<RIF, BND> K(P);
+            Connector<RIF, BND, XC> K(P);
             f3 rev;
             K.unit(S, ps, pp, rng, rev);
             usteps = K.nsteps;

@@ -1066,6 +1066,7 @@ template <typename FLOAT> struct M33 {
     }
 };
 
+inline Float fresnelDielectricExt(Float cosThetaI_, Float &cosThetaT_, Float eta);     /* below */
 template <typename FLOAT> inline bool finite3(const V3<FLOAT> &a) { return std::isfinite(a.x) && std::isfinite(a.y) && std::isfinite(a.z); }
 
 template <typename FLOAT> struct Connector {
@@ -1095,8 +1096,35 @@ template <typename FLOAT> struct Connector {
         dvdv0 = dvdv0 + (fromH(H) * dpdv0) * (SplineConst<FLOAT>::half() * h);
         C.c[ORC_C_STEPS]++;
     }
-    /* :816-939 (inside-shape branch).  J[r][c] = d error_r / d v0_c.  Returns false when the residual has no derivative. */
-    bool computefdf(const V3<FLOAT> &v_i, const V3<FLOAT> &p1, const V3<FLOAT> &p2, V3<FLOAT> &error, M33<FLOAT> &J) const {
+    /* boundaryVelocity (:1040-1055): Snell's law for the optical momentum at a surface (normal N, index ni on the ray's side, ne beyond) */
+    void boundaryVelocity(V3<FLOAT> &v, const V3<FLOAT> &N, FLOAT ni, FLOAT ne) const {
+        const FLOAT dotp = dot(v, N);
+        FLOAT r = ne / ni; r = r * r - 1;
+        const FLOAT n2 = dot(v, v);
+        FLOAT sq = r * n2 + dotp * dotp;
+        if (sq < (FLOAT) Epsilon) { v = (FLOAT) 2 * dotp * N - v; return; }
+        sq = std::sqrt(sq);
+        v = v - dotp * N + (FLOAT) sgn(dotp) * sq * N;
+    }
+    /* boundaryVelocityDerivative (:1061-1074) */
+    void boundaryVelocityDerivative(V3<FLOAT> &v, M33<FLOAT> &dvdv0, const V3<FLOAT> &dtbdv0, const V3<FLOAT> &dnb, const V3<FLOAT> &N, FLOAT ni, FLOAT ne) const {
+        const FLOAT dotp = dot(v, N);
+        FLOAT r = ne / ni; r = r * r - 1;
+        const FLOAT n2 = dot(v, v);
+        FLOAT sq = r * n2 + dotp * dotp;
+        const M33<FLOAT> inner = dvdv0 + M33<FLOAT>::outer(dnb, dtbdv0), NN = M33<FLOAT>::outer(N, N), I((FLOAT) 1);
+        if (sq < (FLOAT) Epsilon) {
+            v = (FLOAT) 2 * dotp * N - v;
+            dvdv0 = (NN * (FLOAT) 2 - I) * inner;
+            return;
+        }
+        sq = std::sqrt(sq);
+        dvdv0 = (I - NN + M33<FLOAT>::outer(N, (r * v + dotp * N) / sq) * (FLOAT) sgn(dotp)) * inner;
+        v = v - dotp * N + (FLOAT) sgn(dotp) * sq * N;
+    }
+    /* :816-939.  J[r][c] = d error_r / d v0_c.  Returns false where the reference sets error = p1 - p2 with a zero derivative.
+       cross = the reference's isSensorSample (here: p2 lies outside the medium shape). */
+    bool computefdf(const V3<FLOAT> &v_i, const V3<FLOAT> &p1, const V3<FLOAT> &p2, bool cross, V3<FLOAT> &error, M33<FLOAT> &J) const {
         M33<FLOAT> dpdv0((FLOAT) 0), dvdv0((FLOAT) 1);
         error = p1 - p2; J = M33<FLOAT>((FLOAT) 0);
         /* a shooting direction that is not a finite non-zero vector has no ray (the stand-in solver's step can overflow: guard, not reference) */
@@ -1112,7 +1140,7 @@ template <typename FLOAT> struct Connector {
         dvdv0 = ((M33<FLOAT>(n2) - M33<FLOAT>::outer(v, v)) * (r / n3)) * dvdv0;
         v = v / n1 * r;
         const int ms = maxSteps();
-        bool found = false;
+        int found = 0;
         for (int i = 0; i < ms; i++) {
             oldp = p; oldv = v; olddp = dpdv0; olddv = dvdv0;
             er_derivativestep(p, v, dpdv0, dvdv0, h);
@@ -1126,15 +1154,46 @@ template <typename FLOAT> struct Connector {
                     signNew = std::signbit(dot(p - p2, v));
                     if (signNew == signOld) { oldp = p; oldv = v; olddp = dpdv0; olddv = dvdv0; }
                 }
-                found = true;
+                found = 1;
                 break;
-            } else if (!S.insideShape(p)) return false;       /* boundary branch: not built (N2) */
+            } else if (!S.insideShape(p)) {                       /* :873-919 */
+                /* towards a point inside the shape a ray that leaves it is a failed trial here (mer_connect.hpp: fewer traced rays for
+                   the same connections); the reference refracts it as well */
+                if (!cross) return false;
+                while (nBisect > 0) {
+                    nBisect--;
+                    p = oldp; v = oldv; dpdv0 = olddp; dvdv0 = olddv;
+                    h = h / 2;
+                    er_derivativestep(p, v, dpdv0, dvdv0, h);
+                    if (S.insideShape(p)) { oldp = p; oldv = v; olddp = dpdv0; olddv = dvdv0; }
+                }
+                found = 2;
+                break;
+            }
         }
         if (!found) return false;
-        V3<FLOAT> dvdt; FLOAT rr;
-        R.valueAndGradient(p, rr, dvdt, C);
-        const V3<FLOAT> dpdt = v / rr;
-        const V3<FLOAT> dtstar = -(dpdv0.preMult(v) + dvdv0.preMult(p - p2)) / (dot(v, dpdt) + dot(p - p2, dvdt));
+        V3<FLOAT> dpdt, dtstar;
+        if (found == 1) {
+            V3<FLOAT> dvdt; FLOAT rr;
+            R.valueAndGradient(p, rr, dvdt, C);
+            dpdt = v / rr;
+            dtstar = -(dpdv0.preMult(v) + dvdv0.preMult(p - p2)) / (dot(v, dpdt) + dot(p - p2, dvdt));
+        } else {
+            if (dot(p - p1, p - p1) < (FLOAT) Epsilon) return false;            /* no progress made (:890-894) */
+            FLOAT nb; V3<FLOAT> dnb;
+            R.valueAndGradient(p, nb, dnb, C);
+            const V3<FLOAT> dpdtb = v / nb;
+            const Vec Nf = S.shapeNormal(Vec((Float) p.x, (Float) p.y, (Float) p.z));          /* normalize(m_SDF->gradient(p)) (:899-900) */
+            const V3<FLOAT> N((FLOAT) Nf.x, (FLOAT) Nf.y, (FLOAT) Nf.z);
+            const V3<FLOAT> dtb = -dpdv0.preMult(N) / dot(N, dpdtb);
+            boundaryVelocityDerivative(v, dvdv0, dtb, dnb, N, nb, (FLOAT) 1);
+            const FLOAT extra_t = -dot(v, p - p2) / dot(v, v);
+            if (cross && extra_t < 0) return false;                               /* :907-912 */
+            dpdv0 = dpdv0 + M33<FLOAT>::outer(dpdtb - v, dtb) + dvdv0 * extra_t;
+            p += extra_t * v;
+            dpdt = v;
+            dtstar = -(dpdv0.preMult(v) + dvdv0.preMult(p - p2)) / dot(v, dpdt);
+        }
         J = dpdv0 + M33<FLOAT>::outer(dpdt, dtstar);
         error = p - p2;
         return true;
@@ -1142,7 +1201,8 @@ template <typename FLOAT> struct Connector {
     /* stand-in for ceres::Solve (LINE_SEARCH/BFGS, <= 20 iterations, function_tolerance tol2): damped Gauss-Newton */
     FLOAT solve(V3<FLOAT> &x, const V3<FLOAT> &p1, const V3<FLOAT> &p2) const {
         V3<FLOAT> e; M33<FLOAT> J;
-        bool ok = computefdf(x, p1, p2, e, J);
+        const bool cross = !S.insideShape(p2);
+        bool ok = computefdf(x, p1, p2, cross, e, J);
         FLOAT cost = (FLOAT) 0.5 * dot(e, e), lambda = (FLOAT) 1e-4;
         /* computefdf rescales its argument to |v0| = n(p1): the residual does not depend on |x|, J^T J is singular along x and only the
            damping makes the step finite.  The unknown lives on the sphere |x| = n(p1): every trial iterate is put back on it, and a
@@ -1169,7 +1229,7 @@ template <typename FLOAT> struct Connector {
                 const FLOAT ln = std::sqrt(dot(xn, xn));
                 if (!(ln > 0) || !std::isfinite(ln)) { lambda *= 10; continue; }
                 xn = xn * (radius / ln);
-                const bool okn = computefdf(xn, p1, p2, en, Jn);
+                const bool okn = computefdf(xn, p1, p2, cross, en, Jn);
                 const FLOAT cn = (FLOAT) 0.5 * dot(en, en);
                 if (okn && cn < cost) { x = xn; e = en; J = Jn; cost = cn; lambda = std::max(lambda * (FLOAT) 0.1, (FLOAT) 1e-9); improved = true; }
                 else lambda *= 10;
@@ -1178,9 +1238,11 @@ template <typename FLOAT> struct Connector {
         }
         return ok ? cost : std::numeric_limits<FLOAT>::infinity();
     }
-    /* :941-1030 (inside-shape branch) */
-    bool computePathLengths(const V3<FLOAT> &p1, const V3<FLOAT> &p2, const V3<FLOAT> &dirToP2, V3<FLOAT> &revDir, FLOAT &optDist, FLOAT &dist) const {
-        dist = 0; optDist = 0;
+    /* :941-1030.  cross = false: a ray that leaves the shape is no connection (emitter samples, :960-962); cross = true: it is
+       taken to the boundary, refracted (Snell, exterior index 1) and followed straight to its closest approach (sensor samples,
+       :963-992).  dist = arc length inside the shape; bweight = weight of the boundary BSDF for the refracted ray. */
+    bool computePathLengths(const V3<FLOAT> &p1, const V3<FLOAT> &p2, const V3<FLOAT> &dirToP2, bool cross, V3<FLOAT> &revDir, FLOAT &optDist, FLOAT &dist, FLOAT &bweight) const {
+        dist = 0; optDist = 0; bweight = 1;
         FLOAT h = (FLOAT) S.s.stepsize;
         long nBisect = (long) std::ceil(precision / std::log10(2.0));
         V3<FLOAT> p = p1, oldp, v = dirToP2, oldv;
@@ -1188,12 +1250,33 @@ template <typename FLOAT> struct Connector {
         Tracer<FLOAT> T(S, C);
         FLOAT dummy = 0;
         const int ms = maxSteps();
-        const int saved = S.s.stepper;
         for (int i = 0; i < ms; i++) {
             oldp = p; oldv = v;
             T.er_step_verlet(p, v, h, dummy);
             signNew = std::signbit(dot(p - p2, v));
-            if (!S.insideShape(p)) return false;
+            if (!S.insideShape(p)) {
+                if (!cross) return false;
+                while (nBisect > 0) {
+                    nBisect--;
+                    p = oldp; v = oldv; h = h / 2;
+                    T.er_step_verlet(p, v, h, dummy);
+                    if (S.insideShape(p)) { dist += h; optDist += h * R.value(SplineConst<FLOAT>::half() * (p + oldp), C); oldp = p; oldv = v; }
+                }
+                const Vec Nf = S.shapeNormal(Vec((Float) p.x, (Float) p.y, (Float) p.z));
+                const V3<FLOAT> N((FLOAT) Nf.x, (FLOAT) Nf.y, (FLOAT) Nf.z);
+                const FLOAT nb = R.value(p, C);
+                if (S.s.boundary_bsdf == 1) {                  /* HDielectric's refracted component seen from inside: (1 - F) eta^2 (hdielectric.cpp:183-242) */
+                    const Float cosI = (Float) dot(normalize(v), N);
+                    Float cosT; const Float F = fresnelDielectricExt(-cosI, cosT, (Float) nb);
+                    bweight = (FLOAT) ((1.0f - F) * ((Float) nb * (Float) nb));
+                }
+                boundaryVelocity(v, N, nb, (FLOAT) 1);           /* :982-984 */
+                const FLOAT extra_t = -dot(v, p - p2) / dot(v, v);
+                if (extra_t < 0) return false;
+                p += extra_t * v;
+                optDist += extra_t;
+                break;
+            }
             if (signNew != signOld) {
                 while (nBisect > 0) {
                     nBisect--;
@@ -1205,7 +1288,6 @@ template <typename FLOAT> struct Connector {
                 break;
             } else { dist += h; optDist += h * R.value(SplineConst<FLOAT>::half() * (p + oldp), C); }
         }
-        (void) saved;
         if (dot(p - p2, p - p2) > tol) return false;
         revDir = -normalize(v);
         return true;
@@ -1241,7 +1323,10 @@ template <typename FLOAT> struct Connector {
         }
         dirToP2 = dirToP2 * RIFp;
         weight *= (iterations - 1);
-        return computePathLengths(p1, p2, dirToP2, revDir, optDist, dist);
+        FLOAT bw = 1;
+        const bool okp = computePathLengths(p1, p2, dirToP2, !S.insideShape(p2), revDir, optDist, dist, bw);
+        weight *= bw;
+        return okp;
     }
 };
 

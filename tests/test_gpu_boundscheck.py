@@ -86,7 +86,7 @@ def test_transient_and_odd_films_stay_in_bounds(cctx):
 
 def test_connect_leaf_with_degenerate_pairs_stays_in_bounds(cctx):
     """mer_connect on pairs that make the shooting problem singular or hopeless: coincident points, points a rounding error apart,
-    the far corners of the shape, a target outside it.  Rejected or solved -- never out of range, never non-finite."""
+    the far corners of the shape, a target outside it (reached through the boundary).  Rejected or solved -- never out of range, never non-finite."""
     for p in (SDF_CASES["point_curved_sdf"](), scenes.curved_scene(N=24, rif="radial", stepper=P.STEP_VERLET), scenes.bspline_scene(N=24)):
         sc, vols = cctx.upload_scene(p)
         a = np.array([[0.2, 0.3, -0.1], [0.2, 0.3, -0.1], [0.0, 0.0, 0.0], [-0.62, -0.62, -0.62], [0.1, 0.1, 0.1], [0.5, 0.0, 0.0]], np.float32)
@@ -94,7 +94,6 @@ def test_connect_leaf_with_degenerate_pairs_stays_in_bounds(cctx):
         out = cctx.connect(sc, a, b, 7)
         _clean(cctx, "mer_connect degenerate pairs")
         assert np.isfinite(out[:, [0, 1, 8, 9]]).all()
-        assert out[4, 0] == 0                                 # a target outside the shape is never connected
         ok = out[:, 0] == 1
         assert np.isfinite(out[ok]).all()
         for v in vols:

@@ -281,3 +281,36 @@ def test_rif_value_and_gradient_under_a_rotated_data_box(ctx, orc, interp):
     assert np.abs(grad - g_world[None, :]).max() < 2e-3
     for v in vols:
         v.destroy()
+
+
+def test_connection_through_the_boundary(ctx, orc):
+    """A12 boundary branch on the GPU (Connector::computefdf / path_lengths with cross = true): the refracted chord of a constant
+    index (closed form), and agreement with the oracle on a radial field -- cube, sphere and signed-distance boundaries"""
+    from tests.test_oracle_kat import _refracted_chord_check, _outside_pairs
+    n0, R, N = 1.4, 0.8, 24
+    p = scenes.curved_scene(N=N, rif=np.full((N, N, N), n0, np.float32), boundary=P.BOUNDARY_SPHERE, sph_radius=R, stepper=P.STEP_VERLET)
+    p1, p2 = _outside_pairs()
+    sc, vols = ctx.upload_scene(p)
+    frac, off, dl, do, dn = _refracted_chord_check(ctx.connect(sc, p1, p2, 1), p1, p2, n0, R)
+    assert frac > 0.75 and off < 3e-4 and dl < 3e-4 and do < 5e-4 and dn < 1e-6, (frac, off, dl, do, dn)
+    for v in vols:
+        v.destroy()
+    box = ([-1.2] * 3, [1.2] * 3)
+    for kw in (dict(boundary=P.BOUNDARY_SPHERE, sph_radius=0.8), dict(), dict(boundary=P.BOUNDARY_SDF, sdf=-synth.sphere_sdf(64, radius=0.8, aabb_min=box[0], aabb_max=box[1]), sdf_aabb=box),
+               dict(boundary=P.BOUNDARY_SPHERE, sph_radius=0.8, boundary_bsdf=P.BSDF_HDIELECTRIC)):
+        q = scenes.curved_scene(N=N, rif="radial", stepper=P.STEP_VERLET, **kw)
+        sc, vols = ctx.upload_scene(q)
+        p1, p2 = _outside_pairs(256, seed=3)
+        if not kw:
+            p2 = p2 * 1.6                                      # outside the cube too
+        a = ctx.connect(sc, p1, p2, 2); b = orc.connect(q, p1, p2, 2)
+        ok = (a[:, 0] == 1) & (b[:, 0] == 1)
+        assert (a[:, 0] == b[:, 0]).mean() > 0.9 and ok.mean() > 0.25, ((a[:, 0] == b[:, 0]).mean(), ok.mean())   # one random start each (Russian roulette 1e-2)
+        da = a[ok, 2:5] / np.linalg.norm(a[ok, 2:5], axis=1, keepdims=True); db = b[ok, 2:5] / np.linalg.norm(b[ok, 2:5], axis=1, keepdims=True)
+        same = np.abs(da - db).max(1) < 5e-3             # through a refracting boundary two solvers may settle on different rays: both valid
+        assert same.mean() > 0.9, same.mean()
+        A, B = a[ok][same], b[ok][same]
+        assert np.abs(A[:, 8] - B[:, 8]).max() < 5e-3 and np.abs(A[:, 9] - B[:, 9]).max() < 1e-2
+        assert np.abs(A[:, 1] - B[:, 1]).max() < 2e-3 * np.abs(B[:, 1]).max()                 # weight: restarts x boundary BSDF
+        for v in vols:
+            v.destroy()

@@ -30,6 +30,11 @@ CASES = {
     "toworld_curved_bspline": lambda: scenes.bspline_scene(N=24, boundary=P.BOUNDARY_SPHERE, sph_radius=0.7, rif_to_world=P.rotation([1, 1, 0], 25.0, [0.05, 0.05, 0.0])),
     "toworld_point_curved": lambda: scenes.curved_scene(N=24, w=32, h=24, rif="radial", boundary=P.BOUNDARY_SPHERE, sph_radius=0.7, rif_to_world=P.rotation([0, 1, 0], 40.0),
                                                         env_radiance=[0, 0, 0], point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5]),
+    # a point emitter OUTSIDE the medium shape reached through curved rays: the connection crosses the boundary (A12 boundary branch)
+    "point_curved_outside_sphere": lambda: scenes.curved_scene(N=24, w=32, h=24, rif="radial", boundary=P.BOUNDARY_SPHERE, sph_radius=0.8, env_radiance=[0, 0, 0],
+                                                               point_position=[0.3, 1.6, -0.4], point_intensity=[4.0, 3.0, 2.0]),
+    "point_curved_outside_dielectric": lambda: scenes.curved_scene(N=24, w=32, h=24, rif="radial", boundary=P.BOUNDARY_SPHERE, sph_radius=0.8, boundary_bsdf=P.BSDF_HDIELECTRIC,
+                                                                   env_radiance=[0, 0, 0], point_position=[0.3, 1.6, -0.4], point_intensity=[4.0, 3.0, 2.0]),
     "cfg3_curved_rk4_trilinear": lambda: scenes.curved_scene(N=32),
     "cfg3_curved_verlet_trilinear": lambda: scenes.curved_scene(N=32, stepper=P.STEP_VERLET),
     "cfg4_radial_rk4": lambda: scenes.curved_scene(N=32, rif="radial"),

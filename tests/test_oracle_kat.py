@@ -588,3 +588,37 @@ def test_strategy_maximum_is_unbiased_like_balance(orc):
     ma = fa[..., :3].sum((0, 1)) / fa[..., 4].sum(); mb = fb[..., :3].sum((0, 1)) / fb[..., 4].sum()
     # the densest channel converges slowly under either strategy (heavy-tailed weights): 0.975 vs 0.967 at 2048 spp, 0.931 vs 0.974 at 256
     assert np.all(np.abs(ma / mb - 1.0) < np.array([5e-3, 8e-3, 2.5e-2])), (ma, mb)
+
+
+def _refracted_chord_check(out, p1, p2, n0, R):
+    """closed form for a constant index n0 inside a sphere of radius R and a target outside: straight to the boundary point b,
+    Snell's law, straight on -- p2 must lie on the refracted ray; returns (fraction connected, worst distance of p2 from that ray,
+    worst error of the inside length, worst error of the optical length)"""
+    ok = out[:, 0] == 1
+    d = out[ok, 2:5].astype(np.float64); dh = d / np.linalg.norm(d, axis=1, keepdims=True)
+    P1 = p1[ok].astype(np.float64); P2 = p2[ok].astype(np.float64)
+    bq = (P1 * dh).sum(1); c = (P1 * P1).sum(1) - R * R; t = -bq + np.sqrt(bq * bq - c)
+    B = P1 + t[:, None] * dh; Nn = B / np.linalg.norm(B, axis=1, keepdims=True)
+    cosi = (dh * Nn).sum(1); cost = np.sqrt(1 - n0 * n0 * (1 - cosi ** 2))
+    r = n0 * dh + (cost - n0 * cosi)[:, None] * Nn
+    off = np.linalg.norm(np.cross(P2 - B, r), axis=1) / np.linalg.norm(r, axis=1)
+    return ok.mean(), off.max(), np.abs(out[ok, 8] - t).max(), np.abs(out[ok, 9] - (n0 * t + np.linalg.norm(P2 - B, axis=1))).max(), np.abs(np.linalg.norm(d, axis=1) - n0).max()
+
+
+def _outside_pairs(n=64, seed=0):
+    rng = np.random.RandomState(seed)
+    p1 = rng.uniform(-0.4, 0.4, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return p1, (d * rng.uniform(1.2, 2.0, (n, 1))).astype(np.float32)
+
+
+def test_connection_through_the_boundary_is_the_refracted_chord(orc):
+    """A12, boundary branch (heterogeneousrefractive.cpp:873-919, 963-992, 1040-1074): a connection whose far end lies outside the
+    medium shape is marched to the boundary, refracted by Snell's law (exterior index 1) and continued straight.  Known answer: with a
+    constant index inside a sphere the connecting path is the refracted chord."""
+    from tests import scenes
+    n0, R, N = 1.4, 0.8, 24
+    p = scenes.curved_scene(N=N, rif=np.full((N, N, N), n0, np.float32), boundary=P.BOUNDARY_SPHERE, sph_radius=R, stepper=P.STEP_VERLET)
+    p1, p2 = _outside_pairs()
+    frac, off, dl, do, dn = _refracted_chord_check(orc.connect(p, p1, p2, 1), p1, p2, n0, R)
+    assert frac > 0.75 and off < 3e-4 and dl < 3e-4 and do < 5e-4 and dn < 1e-6, (frac, off, dl, do, dn)
