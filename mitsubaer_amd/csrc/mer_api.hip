@@ -446,7 +446,9 @@ int mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu_
 static int volume_finish(mer_context *ctx, Volume &v, int32_t layout, mer_volume *out) {
     if (layout == MER_LAYOUT_AUTO) {
         const int64_t nodes = (int64_t) v.desc.res[0] * v.desc.res[1] * v.desc.res[2];
-        layout = (v.desc.channels != 1 || v.desc.dtype != MER_VOL_F32) ? MER_LAYOUT_DENSE : (nodes <= ((int64_t) 1 << 28) ? MER_LAYOUT_BRICK27 : MER_LAYOUT_CELL8);
+        bool affine = false, zero = true;          // a toWorld transform: the record layouts carry none
+        for (int i = 0; i < 12; i++) { const float w = v.desc.world_to_volume[i]; zero = zero && w == 0; affine = affine || w != ((i % 5 == 0) ? 1.0f : 0.0f); }
+        layout = (v.desc.channels != 1 || v.desc.dtype != MER_VOL_F32 || (affine && !zero)) ? MER_LAYOUT_DENSE : (nodes <= ((int64_t) 1 << 28) ? MER_LAYOUT_BRICK27 : MER_LAYOUT_CELL8);
     }
     if (layout == MER_LAYOUT_CELL8) {
         if (v.desc.channels != 1 || v.desc.dtype != MER_VOL_F32) return fail(ctx, "CELL8 layout needs a 1-channel float32 grid");

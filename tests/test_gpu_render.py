@@ -256,6 +256,20 @@ def test_auto_layout_and_list_sorting_change_nothing_per_path(ctx, monkeypatch):
         v.destroy()
 
 
+def test_auto_layout_keeps_a_transformed_rif_dense(ctx):
+    """The CELL8 / BRICK27 records carry no toWorld transform: MER_LAYOUT_AUTO must leave a rotated RIF volume in the dense layout (and render
+    it), while asking for a record layout explicitly is an error naming the reason."""
+    p = scenes.curved_scene(N=24, rif="radial", boundary=P.BOUNDARY_SPHERE, sph_radius=0.7, rif_to_world=P.rotation([0, 0, 1], 30.0, [0.1, 0.0, -0.05]))
+    sc, vols = ctx.upload_scene(p, layout=capi.LAYOUT_DENSE)
+    sc2, vols2 = ctx.upload_scene(p, layout=capi.LAYOUT_AUTO)
+    assert np.array_equal(ctx.render_paths(sc, 0, seed=4), ctx.render_paths(sc2, 0, seed=4))
+    sc3, vols3 = ctx.upload_scene(p, layout=capi.LAYOUT_BRICK27)
+    with pytest.raises(RuntimeError, match="dense layout"):
+        ctx.render_paths(sc3, 0, seed=4)
+    for v in vols + vols2 + vols3:
+        v.destroy()
+
+
 @pytest.mark.parametrize("name", ["curved", "straight", "point_curved"])
 def test_concurrent_pipelines_render_the_same_film(ctx, monkeypatch, name):
     """mer_render cuts a shard into `pipes` (option) independent pipelines (own slots, lists, stream; shared film): same samples, same paths --
