@@ -159,7 +159,8 @@ int  mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu
      nslots         path-state slots over all pipelines (0 = 4 x the resident lanes of the chip)
      ksteps         eikonal steps / tentative collisions per lane per K_march launch (default 128)
      mq_sort        march lists sorted by steps-to-boundary class: -1 by field size (default), 0 off, 1 on
-     cell_sort      march lists additionally ordered by coarse spatial cell: -1 by field size (default), 0 off, 1 on
+     lds_bricks     1 = K_march keeps every lane's current BRICK27 record in LDS (BRICK27 fields below 4 GiB) instead of re-gathering cells
+                    through L1 / L2 (default 0: measured slower)
      connect_launches  K_connect launches per pass: each runs one solver unit (one traced ray) per pending curved-ray connection (default 2)
      adaptive_k     longer passes in the tail of a render (default 1)
      pass_events    per-pass HIP events feeding mer_last_render_stats (default 1)

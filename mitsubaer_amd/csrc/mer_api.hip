@@ -159,6 +159,8 @@ int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bool allo
         // the fetch index (z * res_y + y) * res_x + x is formed with 24-bit multiplies (v_mul_u32_u24)
         if ((int64_t) P.rif.res[1] * P.rif.res[2] > ((int64_t) 1 << 24) || P.rif.res[0] > (1 << 24))
             return fail(ctx, "RIF volume: res_y * res_z must not exceed 2^24 (index arithmetic of the trilinear fetch)");
+        if ((int64_t) P.rif.res[0] * P.rif.res[1] * P.rif.res[2] >= ((int64_t) 1 << 31))
+            return fail(ctx, "RIF volume: more than 2^31 nodes (the cell id of the trilinear fetch is a 32-bit integer)");
         if (P.rif.affine && it->second.cell8)
             return fail(ctx, "RIF volume with a toWorld transform: upload it in the dense layout (the CELL8 / BRICK record layouts carry no transform)");
         if (sc->rif_mode == MER_RIF_BSPLINE3) {
@@ -369,7 +371,7 @@ static int64_t *option_slot(mer_context *ctx, const char *name) {
     const struct { const char *n; int64_t *p; } table[] = {
         {"pipes", &o.pipes}, {"nslots", &o.nslots}, {"ksteps", &o.ksteps}, {"mq_sort", &o.mq_sort}, {"connect_launches", &o.connect_launches},
         {"adaptive_k", &o.adaptive_k}, {"pass_events", &o.pass_events}, {"buffer_loads", &o.buffer_loads}, {"gen_all", &o.gen_all},
-        {"prefilter", &o.prefilter}, {"verbose", &o.verbose}, {"debug_pixel", &o.debug_pixel}, {"cell_sort", &o.cell_sort}};
+        {"prefilter", &o.prefilter}, {"verbose", &o.verbose}, {"debug_pixel", &o.debug_pixel}, {"lds_bricks", &o.lds_bricks}};
     for (const auto &t : table) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }

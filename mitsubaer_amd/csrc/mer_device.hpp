@@ -198,7 +198,8 @@ struct CellCache {
     int cell;                 // linear index of the cached cell's base corner, -1 = empty
     float cx, cy, cz;         // the cached cell's base corner in grid coordinates (exact small integers)
     float d000, d001, d010, d011, d100, d101, d110, d111;
-    __device__ __forceinline__ void reset() { cell = -1; cx = cy = cz = -1.0e30f; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f; }
+    int brick;                // RIFK_BRICK27_LDS: the brick whose record this lane holds in LDS, -1 = none
+    __device__ __forceinline__ void reset() { cell = -1; brick = -1; cx = cy = cz = -1.0e30f; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f; }
 };
 
 // Internal fetch kinds of the trilinear RIF (template parameter RIF of the kernels):
@@ -207,8 +208,10 @@ struct CellCache {
 // Buffer loads take a 32-bit byte offset against a wave-uniform descriptor: one VGPR of address arithmetic per
 // fetch instead of eight 64-bit adds, and the +row / +slice strides ride in the scalar offset operand.
 #define RIFK_ACOUSTIC 8          // == MER_RIF_ACOUSTIC: analytic Bessel-mode field, no fetch
+#define MER_BLOCK 256            // threads per block of every wavefront kernel
 #define RIFK_BRICK27_BUF 6
 #define RIFK_BRICK27 7
+#define RIFK_BRICK27_LDS 9       // K_march only (never a scene's fetch kind): BRICK27 records below 4 GiB, every lane keeps its current brick's record in LDS
 #define RIFK_DENSE_BUF 3
 #define RIFK_CELL8 4
 #define RIFK_CELL8_BUF 5
@@ -221,80 +224,126 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #else
 #define MER_CELL_TEST(cond) (cond)
 #endif
+// the slow path of the trilinear fetch: (px, py, pz) in grid coordinates has left the cached cell -- clamp, form the cell's index and gather its
+// 8 corners into the register cache.  The loads are issued here and first used by the caller's evaluation.
+template <int RIFK>
+__device__ __forceinline__ void cell_fill(const DGrid &g, CellCache &cc, float px, float py, float pz) {
+    // clamp in the float domain (exact: the operands are small integers), one v_med3_f32 per axis
+    cc.cx = __builtin_amdgcn_fmed3f(floorf(px), 0.0f, (float) (g.res[0] - 2));
+    cc.cy = __builtin_amdgcn_fmed3f(floorf(py), 0.0f, (float) (g.res[1] - 2));
+    cc.cz = __builtin_amdgcn_fmed3f(floorf(pz), 0.0f, (float) (g.res[2] - 2));
+    const int x1 = (int) cc.cx, y1 = (int) cc.cy, z1 = (int) cc.cz;
+    const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);      // make_params: res[1] * res[2] <= 2^24
+    if (RIFK == RIFK_BRICK27_LDS) {
+        // Brick staging in LDS (option lds_bricks, off by default: measured 19 % slower than the register cell cache, profiles/round2/
+        // ab_lds_brick_staging.txt).  The rays of a wave are incoherent (a few hundred thousand rays in flight over 2^21 ... 2^27 bricks: no
+        // two share one), so what LDS can hold is each lane's OWN current brick: 27 corners = 7 x 16 bytes per lane, [chunk][lane] so that a
+        // wave's writes are contiguous; 28 KiB per block of 256, five blocks per CU.  A ray crosses ~4 cells per brick: the first gathers
+        // the record (7 loads of 16 bytes, one 128-byte line, DMA'd into LDS), the others read LDS instead of going back to L1 / L2, which
+        // do not hold a line that long (L2 hit rate 0.3).  No barrier: a lane reads only what it wrote itself.  Why it loses: the line
+        // leaves the fabric once either way, but 7 vector-memory instructions per brick change instead of 4 per cell change load the
+        // texture-address / L1 pipeline (busy 50 % / 81 % of the time already) more than the saved L2 requests relieve it.
+        __shared__ u32x4 brick_lds[MER_BLOCK / 64][7][64];
+        if (base != cc.cell) {
+            cc.cell = base;
+            const int brick = (int) (__umul24(__umul24(z1 >> 1, g.nby) + (y1 >> 1), g.nbx) + (x1 >> 1));
+            const int lane = threadIdx.x & 63; u32x4 (*rec)[64] = brick_lds[__builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6))];   // wave-uniform: the addresses stay in SGPRs
+            if (brick != cc.brick) {
+                cc.brick = brick;
+                const int o = (int) MER_CHK(g.chk, CHK_GRID_RECORD, (uint32_t) brick * 32u, g.n_record - 31u);
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
+                // straight into LDS (buffer_load_dwordx4 ... lds: lane L's 16 bytes land at M0 + 16 L, no registers in between; the chunk's
+                // byte offset rides in the scalar offset, which moves the buffer address only -- the instruction's immediate offset would
+                // move the LDS address too); the reads below are this lane's own, once the loads have landed (vmcnt)
+#define MER_BRICK_DMA(k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *) &rec[k][0], 16, o * 4, (k) * 16, 0, 0)
+                MER_BRICK_DMA(0); MER_BRICK_DMA(1); MER_BRICK_DMA(2); MER_BRICK_DMA(3); MER_BRICK_DMA(4); MER_BRICK_DMA(5); MER_BRICK_DMA(6);
+#undef MER_BRICK_DMA
+                __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+            }
+            const int w = ((z1 & 1) * 3 + (y1 & 1)) * 3 + (x1 & 1);            // word of the cell's corner (0,0,0) in the record
+            const uint32_t *words = (const uint32_t *) rec;
+#define MER_BRICK_WORD(i) __uint_as_float(words[(((w + (i)) >> 2) * 64 + lane) * 4 + ((w + (i)) & 3)])
+            cc.d000 = MER_BRICK_WORD(0); cc.d001 = MER_BRICK_WORD(1); cc.d010 = MER_BRICK_WORD(3); cc.d011 = MER_BRICK_WORD(4);
+            cc.d100 = MER_BRICK_WORD(9); cc.d101 = MER_BRICK_WORD(10); cc.d110 = MER_BRICK_WORD(12); cc.d111 = MER_BRICK_WORD(13);
+#undef MER_BRICK_WORD
+        }
+    } else
+    if (RIFK == RIFK_BRICK27 || RIFK == RIFK_BRICK27_BUF) {
+        if (base != cc.cell) {
+            // the cell's 8 corners as four x-pairs out of its brick's record (2^3 cells: 27 corners, one 128-byte line; 4^3 cells: 125
+            // corners, 512 bytes): a cell change inside the brick is an L1 hit, only a change of line goes to L2 / the fabric
+            cc.cell = base;
+            const int bs = g.bshift, bm = (1 << bs) - 1, bw = g.bw;
+            const int brick = (int) (__umul24(__umul24(z1 >> bs, g.nby) + (y1 >> bs), g.nbx) + (x1 >> bs));
+            // word index of the cell's corner (0,0,0): 64 bits, a 1024^3 field has 2^32 record words (below 4 GiB, the buffer form, 32 suffice)
+            const size_t o64 = (size_t) MER_CHK(g.chk, CHK_GRID_RECORD, (size_t) (uint32_t) brick * (uint32_t) g.recw + (uint32_t) (((z1 & bm) * bw + (y1 & bm)) * bw + (x1 & bm)),
+                                                g.n_record - (uint64_t) (bw * bw + bw) - 1u);
+            const int o = (int) o64;
+            u32x2 r00, r01, r10, r11;
+            if (RIFK == RIFK_BRICK27_BUF) {
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
+                r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, 0, 0);
+                r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * 4, 0);
+                r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * bw * 4, 0);
+                r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, (bw * bw + bw) * 4, 0);
+            } else {
+                const float *q = g.cell8 + o64;
+                r00 = u32x2{__float_as_uint(q[0]), __float_as_uint(q[1])}; r01 = u32x2{__float_as_uint(q[bw]), __float_as_uint(q[bw + 1])};
+                r10 = u32x2{__float_as_uint(q[bw * bw]), __float_as_uint(q[bw * bw + 1])}; r11 = u32x2{__float_as_uint(q[bw * bw + bw]), __float_as_uint(q[bw * bw + bw + 1])};
+            }
+            cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
+            cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
+        }
+    } else
+    if (MER_CELL_TEST(base != cc.cell)) {
+        cc.cell = base;
+        const int dbase = (int) MER_CHK(g.chk, CHK_GRID_DENSE, (uint32_t) base, g.n_dense - (uint32_t) (g.res[0] * g.res[1] + g.res[0]) - 1u); (void) dbase;
+        if (RIFK == RIFK_CELL8 || RIFK == RIFK_CELL8_BUF) {
+            const int cell = (int) MER_CHK(g.chk, CHK_GRID_RECORD, (uint32_t) (__umul24(__umul24(z1, g.res[1] - 1) + y1, g.res[0] - 1) + x1), g.n_record >> 3);
+            float4 a, b;
+            if (RIFK == RIFK_CELL8_BUF) {
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
+                const u32x4 ua = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cell * 32, 0, 0);
+                const u32x4 ub = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cell * 32 + 16, 0, 0);
+                a = make_float4(__uint_as_float(ua.x), __uint_as_float(ua.y), __uint_as_float(ua.z), __uint_as_float(ua.w));
+                b = make_float4(__uint_as_float(ub.x), __uint_as_float(ub.y), __uint_as_float(ub.z), __uint_as_float(ub.w));
+            } else {
+                const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
+                a = c[0]; b = c[1];
+            }
+            cc.d000 = a.x; cc.d001 = a.y; cc.d010 = a.z; cc.d011 = a.w; cc.d100 = b.x; cc.d101 = b.y; cc.d110 = b.z; cc.d111 = b.w;
+        } else if (RIFK == RIFK_DENSE_BUF) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.data, 0, (int) g.buf_bytes, 0x00020000);
+            const int sy4 = g.res[0] * 4, sz4 = g.res[0] * g.res[1] * 4;
+            const u32x2 r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, 0, 0);
+            const u32x2 r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sy4, 0);
+            const u32x2 r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sz4, 0);
+            const u32x2 r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sz4 + sy4, 0);
+            cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
+            cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
+        } else {
+            const float *D = (const float *) g.data;
+            const int sy = g.res[0], sz = g.res[0] * g.res[1];
+            cc.d000 = D[dbase]; cc.d001 = D[dbase + 1]; cc.d010 = D[dbase + sy]; cc.d011 = D[dbase + sy + 1];
+            cc.d100 = D[dbase + sz]; cc.d101 = D[dbase + sz + 1]; cc.d110 = D[dbase + sz + sy]; cc.d111 = D[dbase + sz + sy + 1];
+        }
+    }
+
+}
+// all three of (q - corner) in [0,1)  <=>  the largest of the three bit patterns, compared as unsigned, is below that of 1.0f (a negative
+// value has the sign bit set; NaN and -0.0f take the slow path, which is always correct)
+__device__ __forceinline__ bool cell_left(float fx, float fy, float fz) {
+    return MER_CELL_TEST(max(__float_as_uint(fx), max(__float_as_uint(fy), __float_as_uint(fz))) >= 0x3F800000u);
+}
 template <int RIFK>
 __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &cc, f3 p, float &val, f3 &grad) {
     const float px = __builtin_fmaf(g.s[0], p.x, g.t[0]), py = __builtin_fmaf(g.s[1], p.y, g.t[1]), pz = __builtin_fmaf(g.s[2], p.z, g.t[2]);
     // fast path: the point is still in the cached cell  <=>  0 <= q - corner < 1 on every axis (the subtraction is
     // exact, so this is the same decision as floor(q) == corner); the four RK4 stages of a half-voxel step mostly are
     float fx = px - cc.cx, fy = py - cc.cy, fz = pz - cc.cz;
-    // all three in [0,1)  <=>  the largest of the three bit patterns, compared as unsigned, is below that of 1.0f (a negative
-    // value has the sign bit set; NaN and -0.0f take the slow path, which is always correct)
-    if (MER_CELL_TEST(max(__float_as_uint(fx), max(__float_as_uint(fy), __float_as_uint(fz))) >= 0x3F800000u)) {
-        // clamp in the float domain (exact: the operands are small integers), one v_med3_f32 per axis
-        cc.cx = __builtin_amdgcn_fmed3f(floorf(px), 0.0f, (float) (g.res[0] - 2));
-        cc.cy = __builtin_amdgcn_fmed3f(floorf(py), 0.0f, (float) (g.res[1] - 2));
-        cc.cz = __builtin_amdgcn_fmed3f(floorf(pz), 0.0f, (float) (g.res[2] - 2));
-        const int x1 = (int) cc.cx, y1 = (int) cc.cy, z1 = (int) cc.cz;
+    if (cell_left(fx, fy, fz)) {
+        cell_fill<RIFK>(g, cc, px, py, pz);
         fx = px - cc.cx; fy = py - cc.cy; fz = pz - cc.cz;
-        const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);      // make_params: res[1] * res[2] <= 2^24
-        if (RIFK == RIFK_BRICK27 || RIFK == RIFK_BRICK27_BUF) {
-            if (base != cc.cell) {
-                // the cell's 8 corners as four x-pairs out of its brick's record (2^3 cells: 27 corners, one 128-byte line; 4^3 cells: 125
-                // corners, 512 bytes): a cell change inside the brick is an L1 hit, only a change of line goes to L2 / the fabric
-                cc.cell = base;
-                const int bs = g.bshift, bm = (1 << bs) - 1, bw = g.bw;
-                const int brick = (int) (__umul24(__umul24(z1 >> bs, g.nby) + (y1 >> bs), g.nbx) + (x1 >> bs));
-                const int o = (int) MER_CHK(g.chk, CHK_GRID_RECORD, (uint32_t) (brick * g.recw + ((z1 & bm) * bw + (y1 & bm)) * bw + (x1 & bm)),
-                                            g.n_record - (uint32_t) (bw * bw + bw) - 1u);   // word index of the cell's corner (0,0,0)
-                u32x2 r00, r01, r10, r11;
-                if (RIFK == RIFK_BRICK27_BUF) {
-                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
-                    r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, 0, 0);
-                    r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * 4, 0);
-                    r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * bw * 4, 0);
-                    r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, (bw * bw + bw) * 4, 0);
-                } else {
-                    const float *q = g.cell8 + (size_t) o;
-                    r00 = u32x2{__float_as_uint(q[0]), __float_as_uint(q[1])}; r01 = u32x2{__float_as_uint(q[bw]), __float_as_uint(q[bw + 1])};
-                    r10 = u32x2{__float_as_uint(q[bw * bw]), __float_as_uint(q[bw * bw + 1])}; r11 = u32x2{__float_as_uint(q[bw * bw + bw]), __float_as_uint(q[bw * bw + bw + 1])};
-                }
-                cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
-                cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
-            }
-        } else
-        if (MER_CELL_TEST(base != cc.cell)) {
-            cc.cell = base;
-            const int dbase = (int) MER_CHK(g.chk, CHK_GRID_DENSE, (uint32_t) base, g.n_dense - (uint32_t) (g.res[0] * g.res[1] + g.res[0]) - 1u); (void) dbase;
-            if (RIFK == RIFK_CELL8 || RIFK == RIFK_CELL8_BUF) {
-                const int cell = (int) MER_CHK(g.chk, CHK_GRID_RECORD, (uint32_t) (__umul24(__umul24(z1, g.res[1] - 1) + y1, g.res[0] - 1) + x1), g.n_record >> 3);
-                float4 a, b;
-                if (RIFK == RIFK_CELL8_BUF) {
-                    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
-                    const u32x4 ua = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cell * 32, 0, 0);
-                    const u32x4 ub = __builtin_amdgcn_raw_buffer_load_b128(rsrc, cell * 32 + 16, 0, 0);
-                    a = make_float4(__uint_as_float(ua.x), __uint_as_float(ua.y), __uint_as_float(ua.z), __uint_as_float(ua.w));
-                    b = make_float4(__uint_as_float(ub.x), __uint_as_float(ub.y), __uint_as_float(ub.z), __uint_as_float(ub.w));
-                } else {
-                    const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
-                    a = c[0]; b = c[1];
-                }
-                cc.d000 = a.x; cc.d001 = a.y; cc.d010 = a.z; cc.d011 = a.w; cc.d100 = b.x; cc.d101 = b.y; cc.d110 = b.z; cc.d111 = b.w;
-            } else if (RIFK == RIFK_DENSE_BUF) {
-                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.data, 0, (int) g.buf_bytes, 0x00020000);
-                const int sy4 = g.res[0] * 4, sz4 = g.res[0] * g.res[1] * 4;
-                const u32x2 r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, 0, 0);
-                const u32x2 r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sy4, 0);
-                const u32x2 r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sz4, 0);
-                const u32x2 r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sz4 + sy4, 0);
-                cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
-                cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
-            } else {
-                const float *D = (const float *) g.data;
-                const int sy = g.res[0], sz = g.res[0] * g.res[1];
-                cc.d000 = D[dbase]; cc.d001 = D[dbase + 1]; cc.d010 = D[dbase + sy]; cc.d011 = D[dbase + sy + 1];
-                cc.d100 = D[dbase + sz]; cc.d101 = D[dbase + sz + 1]; cc.d110 = D[dbase + sz + sy]; cc.d111 = D[dbase + sz + sy + 1];
-            }
-        }
     }
     const float dx00 = cc.d001 - cc.d000, dx01 = cc.d011 - cc.d010, dx10 = cc.d101 - cc.d100, dx11 = cc.d111 - cc.d110;
     const float c00 = __builtin_fmaf(fx, dx00, cc.d000), c01 = __builtin_fmaf(fx, dx01, cc.d010),
@@ -846,7 +895,6 @@ __device__ __forceinline__ void film_contribute(const Params &P, float px, float
 // Work decode: w -> (pixel, sample).  Sample-major; inside a pass pixels go by 32x32 image tiles (the
 // reference's block size, src/mitsuba/mitsuba.cpp:80-81) and by 8x8 sub-tiles so that the 64 lanes of a
 // fresh wavefront start on one 8x8 pixel patch (coherent camera rays, distinct film pixels per lane).
-#define MER_BLOCK 256
 #define MER_TILE 32
 __device__ __forceinline__ bool decode_work(const Params &P, uint64_t w, int &x, int &y, uint32_t &sample) {
     const uint32_t npix = (uint32_t) P.ntiles_mine * (MER_TILE * MER_TILE);

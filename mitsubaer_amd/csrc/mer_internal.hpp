@@ -49,7 +49,7 @@ struct Options {
     int64_t prefilter = 0;        // K_prefilter form: 0 register windows, 1 one thread per line, 2 two kernels per axis, 3 strided x pass, 4 LDS x pass
     int64_t verbose = 0;
     int64_t debug_pixel = -1;
-    int64_t cell_sort = -1;       // march lists additionally ordered by coarse spatial cell: -1 = by field size, 0 / 1 = off / on
+    int64_t lds_bricks = 0;       // K_march keeps every lane's current BRICK27 record in LDS (BRICK27 below 4 GiB only; measured slower)
 };
 
 }  // namespace mer
@@ -100,7 +100,8 @@ struct Run {
 // the kernels of one (CURVED, RIF, STEPPER, SIGMA, BND) combination, as launchable function pointers
 typedef void (*GenKernel)(const Params);
 typedef void (*PassKernel)(const Params, uint32_t);
-struct KernelSet { GenKernel gen; PassKernel event, march, connect, connect_cross; };   // connect_cross: the point emitter lies outside the medium shape
+struct KernelSet { GenKernel gen; PassKernel event, march, connect, connect_cross, march_lds; };   // connect_cross: the point emitter lies outside the medium shape;
+                                                                                                    // march_lds: K_march with LDS-staged BRICK27 records (or null)
 // each mer_render_<group>.hip answers for the combinations it instantiates (returns false if the combination is not in its group)
 bool kernels_straight(int sigma, int bnd, bool extra, KernelSet &k);
 bool kernels_acoustic(int stepper, int sigma, bool extra, KernelSet &k);

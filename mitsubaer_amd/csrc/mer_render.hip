@@ -58,6 +58,10 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         if (scene->boundary == MER_BOUNDARY_SDF && curved) return fail(ctx, "signed-distance boundary: the RIF must be dense, cell8 below 4 GiB, or a B-spline volume");
         return fail(ctx, "unsupported rif_mode / stepper combination");
     }
+    if (opt.lds_bricks && ks.march_lds && curved) {      // LDS staging holds 27-corner records: BRICK27, not BRICK125
+        auto it = ctx->volumes.find(scene->rif);
+        if (it != ctx->volumes.end() && it->second.layout == MER_LAYOUT_BRICK27) ks.march = ks.march_lds;
+    }
     const bool connect_stage = has_point && curved;
     if (connect_stage) {            // an emitter outside the shape is reached through the boundary: the kernel that carries the refraction code
         bool inside = false;        // (signed-distance shapes: the plain kernel carries it too, the side is tested per connection)

@@ -17,6 +17,8 @@ static inline void fill_kernels(bool extra, KernelSet &k) {
     if (extra || X) k.event = event_kernel<CURVED, RIF, STEPPER, SIGMA, true, BND>;
     else k.event = event_kernel<CURVED, RIF, STEPPER, SIGMA, X, BND>;
     k.march = march_kernel<CURVED, RIF, STEPPER, SIGMA, BND>;
+    if constexpr (RIF == RIFK_BRICK27_BUF) k.march_lds = march_kernel<CURVED, RIFK_BRICK27_LDS, STEPPER, SIGMA, BND>;
+    else k.march_lds = nullptr;
     if constexpr (CURVED) { k.connect = connect_stage_kernel<RIF, STEPPER, SIGMA, BND, BND != 0>; k.connect_cross = connect_stage_kernel<RIF, STEPPER, SIGMA, BND, true>; }
     else k.connect = k.connect_cross = nullptr;
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick A/B across grid sizes for the library given in MER_LIB (default libmer.so): scratch/ab_quick.sh [bench options]
-for cfg in "--res 256" "--res 512" "--workload cfg4 --res 1024 --size 1024 --spp 8"; do
+for cfg in "--res 256" "--res 512" "--workload cfg4 --res 1024 --size 1024 --spp 8"; do [ -n "$AB_SKIP_1024" ] && [[ "$cfg" == *1024* ]] && continue
   echo "== ${MER_LIB:-libmer.so} $cfg $*"
   python bench.py $cfg --no-cpu-baseline --no-target-512 --steps 2 --warmup 1 "$@" 2>/dev/null | python3 -c "
 import json,sys

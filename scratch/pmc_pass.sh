@@ -7,9 +7,9 @@ prog=$1; shift
 case "$prog" in /*) ;; *) prog=$GRAFT_REPO_ROOT/$prog;; esac
 cd /tmp && export TMPDIR=/tmp
 if [[ "$prog" == *.py ]]; then
-  timeout -k 10 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -- python3 $prog "$@" > $out/stdout.txt 2> $out/stderr.txt
+  timeout -k 5 ${PMC_TIMEOUT:-900} rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -- python3 $prog "$@" > $out/stdout.txt 2> $out/stderr.txt
 else
-  timeout -k 10 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -- $prog "$@" > $out/stdout.txt 2> $out/stderr.txt
+  timeout -k 5 ${PMC_TIMEOUT:-900} rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -- $prog "$@" > $out/stdout.txt 2> $out/stderr.txt
 fi
 rc=$?
 cd $GRAFT_REPO_ROOT

@@ -174,3 +174,8 @@ def test_configs3_at_1024_cubed(ctx):
     assert np.abs(np.linalg.norm(ov, axis=1) - n1).max() < 2e-4                             # |v| = n along the ray
     for v in vols:
         v.destroy()
+    # the same field as BRICK27 records: 2^27 bricks x 32 words = 2^32 words, the record index needs more than 32 bits
+    sb, vb = bench.upload(ctx, "cfg4", NN, p, capi.LAYOUT_BRICK27)
+    assert np.array_equal(ctx.render_paths(sb, 0, seed=5), a)
+    for v in vb:
+        v.destroy()

@@ -256,6 +256,25 @@ def test_auto_layout_and_list_sorting_change_nothing_per_path(ctx, monkeypatch):
         v.destroy()
 
 
+@pytest.mark.parametrize("stepper", [P.STEP_RK4, P.STEP_VERLET])
+@pytest.mark.parametrize("shape", [(24, 24, 24), (9, 12, 17)])
+def test_lds_staged_bricks_are_bit_identical(ctx, stepper, shape):
+    """lds_bricks=1: K_march DMAs every lane's current BRICK27 record into LDS and reads the cells of that brick from there.  Storage
+    again: the film and the per-path radiance are bit-identical to the register cell cache."""
+    rng = np.random.RandomState(11)
+    rif = (1.3 + 0.3 * rng.rand(*shape)).astype(np.float32)
+    p = scenes.curved_scene(N=16, rif=rif, stepper=stepper, stepsize=0.03, w=48, h=40)
+    sc, vols = ctx.upload_scene(p, layout=capi.LAYOUT_BRICK27)
+    with ctx.options(lds_bricks=0):
+        a = [ctx.render_paths(sc, s, seed=3) for s in (0, 1)]; fa = ctx.render_to_host(sc, 0, 4, seed=3)
+    with ctx.options(lds_bricks=1):
+        b = [ctx.render_paths(sc, s, seed=3) for s in (0, 1)]; fb = ctx.render_to_host(sc, 0, 4, seed=3)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and a[0].max() > 0
+    assert np.allclose(fa, fb, rtol=1e-5, atol=1e-6)           # film: atomic accumulation order
+    for v in vols:
+        v.destroy()
+
+
 def test_auto_layout_keeps_a_transformed_rif_dense(ctx):
     """The CELL8 / BRICK27 records carry no toWorld transform: MER_LAYOUT_AUTO must leave a rotated RIF volume in the dense layout (and render
     it), while asking for a record layout explicitly is an error naming the reason."""
