@@ -88,11 +88,13 @@ typedef struct {
        emitter is reached by mer_connect's shooting solver; an emitter outside the medium shape through the boundary
        (Snell refraction at the shape, exterior index 1: src/medium/heterogeneousrefractive.cpp:873-919,963-992). */
     float   point_position[3], point_intensity[3];
-    /* film decomposition (src/librender/film.cpp:56-84): 0 = none, 1 = transient.  Transient: every radiance
+    /* film decomposition (src/librender/film.cpp:56-84): 0 = none, 1 = transient, 2 = bounce.  Transient: every radiance
        contribution is binned by its optical path length (sum of h*n along curved segments, length*n otherwise:
        src/integrators/bdpt/bdpt_proc.cpp:151-176,449-470) into frames = ceil((max_bound-min_bound)/bin_width) RGB slices.
        The film then is float[height][width][frames*3 + 2]: RGB per frame, alpha, weight (bdpt_proc.cpp:230-245,484-485).
-       calibrated_transient != 0 leaves the camera edge out of the path length (bdpt_proc.cpp:163-170). */
+       calibrated_transient != 0 leaves the camera edge out of the path length (bdpt_proc.cpp:163-170).
+       Bounce: the same film, binned by the number of path edges instead -- every edge counts 1.0 where transient adds its optical
+       length (bdpt_proc.cpp:179-187,335-381); no modulation. */
     int32_t decomposition; float min_bound, max_bound, bin_width; int32_t calibrated_transient;
     /* path-length modulation of a transient film (continuous-wave time of flight; PathLengthSampler,
        src/librender/pathlengthsampler.cpp:12-114): MER_MODULATION_*; lambda, phase in degrees, P, neighbors.  With a
@@ -122,7 +124,7 @@ typedef struct {
 enum { MER_BSDF_NULL = 0, MER_BSDF_HDIELECTRIC = 1 };
 enum { MER_MODULATION_NONE = 0, MER_MODULATION_SINE, MER_MODULATION_SQUARE, MER_MODULATION_HAMILTONIAN, MER_MODULATION_MSEQ,
        MER_MODULATION_DEPTHSELECTIVE };
-enum { MER_DECOMPOSITION_NONE = 0, MER_DECOMPOSITION_TRANSIENT = 1 };
+enum { MER_DECOMPOSITION_NONE = 0, MER_DECOMPOSITION_TRANSIENT = 1, MER_DECOMPOSITION_BOUNCE = 2 };
 
 /* which part of the image-sample space this call renders (multi-GPU sharding):
    sample indices spp_begin + k*spp_stride, k in [0, spp_count); 32x32 image tiles t with

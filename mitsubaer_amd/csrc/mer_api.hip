@@ -106,10 +106,10 @@ static int film_frames(mer_context *ctx, const mer_scene_desc *sc, int &frames) 
         return fail(ctx, "film: modulation needs lambda > 0, P >= 1, neighbors >= 0");
     if (sc->decomposition == MER_DECOMPOSITION_NONE) return 0;
     if (sc->decomposition == MER_DECOMPOSITION_TRANSIENT && sc->modulation != MER_MODULATION_NONE) return 0;  // film.cpp:76-78: one frame
-    if (sc->decomposition != MER_DECOMPOSITION_TRANSIENT)
-        return fail(ctx, "The \"decomposition\" parameter must be equal toeither \"none\", \"transient\", or \"bounce\"!");   // film.cpp:66-68 (bounce: not built)
+    if (sc->decomposition != MER_DECOMPOSITION_TRANSIENT && sc->decomposition != MER_DECOMPOSITION_BOUNCE)
+        return fail(ctx, "The \"decomposition\" parameter must be equal toeither \"none\", \"transient\", or \"bounce\"!");   // film.cpp:66-68
     const float f = std::ceil((sc->max_bound - sc->min_bound) / sc->bin_width);                                               // film.cpp:74
-    if (!(f >= 1.0f) || f > 4096.0f) return fail(ctx, "film: transient decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames");
+    if (!(f >= 1.0f) || f > 4096.0f) return fail(ctx, "film: a decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames");
     frames = (int) f;
     return 0;
 }

@@ -909,6 +909,11 @@ __device__ __forceinline__ bool decode_work(const Params &P, uint64_t w, int &x,
     return x < P.sc.width && y < P.sc.height;
 }
 
+// what one path edge adds to the quantity a decomposed film bins by: its optical length (transient) or 1 (bounce: bdpt_proc.cpp:179-187)
+__device__ __forceinline__ float edge_length(const Params &P, float optical_length) {
+    return P.sc.decomposition == MER_DECOMPOSITION_BOUNCE ? 1.0f : optical_length;
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

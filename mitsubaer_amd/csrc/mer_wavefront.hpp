@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
                     bool medium = true;
                     if (!CURVED) { const f3 ro = o + d * itsT; medium = intersect_shape_b<BND>(P, ro, d, MER_EPSILON, MER_INF) >= 0; }
                     if (!(2 <= maxDepth || maxDepth < 0)) { }
-                    else if (!medium) { if (!S.hide_emitters) L = env; if (!S.calibrated_transient) plen = itsT; }
+                    else if (!medium) { if (!S.hide_emitters) L = env; if (!S.calibrated_transient) plen = edge_length(P, itsT); }
                     else hit = true;
                 }
                 if (!hit) {
@@ -434,7 +434,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             } else if (depth >= maxDepth && maxDepth != -1) ev = EV_PATH_DONE;
             else if (dielectric) {
                 // hdielectric boundary (N2): reflect away (the ray escapes: environment, weight 1) or refract into the medium
-                if (!S.calibrated_transient) plen += itsT;
+                if (!S.calibrated_transient) plen += edge_length(P, itsT);
                 f3 x, wo;
                 if (!dielectric_event<CURVED, RIF, BND>(P, rng, o, d, itsT, false, T, etaPath, x, wo)) {
                     L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen);
@@ -447,7 +447,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
                 }
             } else {
                 (void) rng.next1D(); (void) rng.next1D();                      // null bsdf->sample(..., nextSample2D())
-                if (!S.calibrated_transient) plen += itsT;                     // the camera edge (bdpt_proc.cpp:163-176)
+                if (!S.calibrated_transient) plen += edge_length(P, itsT);     // the camera edge (bdpt_proc.cpp:163-176)
                 const f3 ro = o + d * itsT;
                 bool medium = true;
                 if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
@@ -488,7 +488,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             }
             if (!success) { ev = EV_FAIL; continue; }
             C.real++;
-            plen += CURVED ? m.opticalLength : m.t * S.rif_const;                     // bdpt_proc.cpp:158-176
+            plen += edge_length(P, CURVED ? m.opticalLength : m.t * S.rif_const);                     // bdpt_proc.cpp:158-176
             if (depth >= maxDepth && maxDepth != -1) { ev = EV_PATH_DONE; continue; }
             if (hasEmission && SIGMA == MER_SIGMA_GRID) {
                 const f3 c = T * f3(S.emission[0], S.emission[1], S.emission[2]) * m.refRatioSq;
@@ -529,8 +529,8 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
                     if (phaseVal != 0) {
                         const float weight = mi_weight(dpdf, phaseVal);              // env emitter is "on surface": constant.cpp:47
                         const f3 c = T * value * phaseVal * weight;
-                        L = L + mod_weight<EXTRA>(P, c, plen + trOpt);
-                        film_contribute(P, px, py, c, plen + trOpt);
+                        L = L + mod_weight<EXTRA>(P, c, plen + edge_length(P, trOpt));
+                        film_contribute(P, px, py, c, plen + edge_length(P, trOpt));
                     }
                 }
                 ev = EV_PHASE;
@@ -541,8 +541,8 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
                 if (!blocked && !is_zero(tr)) {
                     const f3 value = tr * env;
                     const f3 c = T * value * mi_weight(phasePdf, MER_INV_FOURPI);
-                    L = L + mod_weight<EXTRA>(P, c, plen + trOpt);
-                    film_contribute(P, px, py, c, plen + trOpt);
+                    L = L + mod_weight<EXTRA>(P, c, plen + edge_length(P, trOpt));
+                    film_contribute(P, px, py, c, plen + edge_length(P, trOpt));
                 }
                 ev = EV_AFTER_LOOKUP;
             }
@@ -558,8 +558,8 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
                 }
                 float optLen = 0.0f;
                 const f3 c = T * point_nee<false, RIF, STEPPER, SIGMA, BND>(P, rng, C, ps, wi, depth, optLen);
-                L = L + mod_weight<EXTRA>(P, c, plen + optLen);
-                film_contribute(P, px, py, c, plen + optLen);
+                L = L + mod_weight<EXTRA>(P, c, plen + edge_length(P, optLen));
+                film_contribute(P, px, py, c, plen + edge_length(P, optLen));
             }
             // ---- phase function sampling: volpath.cpp:149-160
             const float p2x = rng.next1D(), p2y = rng.next1D();
@@ -595,7 +595,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             // ---- no medium interaction: volpath.cpp:183-201,289-301
             MRec m;
             finish_free_flight(P, C, W, false, 0.0f, m);
-            plen += CURVED ? m.opticalLength : itsT * S.rif_const;
+            plen += edge_length(P, CURVED ? m.opticalLength : itsT * S.rif_const);
             T = T * (m.transmittance / m.pdfFailure);
             if (CURVED) { T = T * m.refRatioSq; SET_FLAG(F_ITSVALID, true); }         // edge.cpp:45-60
             ev = EV_PATH_DONE;
@@ -704,7 +704,7 @@ __global__ void MER_CONNECT_BOUNDS connect_stage_kernel(const Params P, uint32_t
             // the connecting ray is known: transmittance along it, emitter value, phase function -- the luminaire sample of this vertex
             const f3 T(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ)), wi(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
             const f3 c0 = T * connection_value<RIF, STEPPER, SIGMA, BND>(P, rng, C, ps, wi, S.dir, S.dist, S.weight);
-            const float plen = SLOTF(CO_PLEN) + S.optDist;
+            const float plen = SLOTF(CO_PLEN) + edge_length(P, S.optDist);
             film_contribute(P, SLOTF(CO_PXF), SLOTF(CO_PYF), c0, plen);
             const f3 c = mod_weight<EXTRA>(P, c0, plen);
             SLOT(CO_LX) = __float_as_uint(SLOTF(CO_LX) + c.x); SLOT(CO_LY) = __float_as_uint(SLOTF(CO_LY) + c.y); SLOT(CO_LZ) = __float_as_uint(SLOTF(CO_LZ) + c.z);

@@ -373,7 +373,7 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
         const std::string dec = lower(props.getString("decomposition", "none"));                         // film.cpp:56-84
         if (dec == "none") o->decomposition = MER_DECOMPOSITION_NONE;
         else if (dec == "transient") o->decomposition = MER_DECOMPOSITION_TRANSIENT;
-        else if (dec == "bounce") Log_EError("film: decomposition \"bounce\" is not built on the GPU path");
+        else if (dec == "bounce") o->decomposition = MER_DECOMPOSITION_BOUNCE;
         else Log_EError("The \"decomposition\" parameter must be equal toeither \"none\", \"transient\", or \"bounce\"!");
         o->minBound = props.getFloat("minBound", 0.0f); o->maxBound = props.getFloat("maxBound", 0.0f);
         o->binWidth = props.getFloat("binWidth", 1.0f);
@@ -389,8 +389,8 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
             if (o->modulation != MER_MODULATION_NONE && o->decomposition != MER_DECOMPOSITION_TRANSIENT)
                 Log_EError("film: a path-length modulation needs decomposition = transient");
         }
-        if (o->decomposition == MER_DECOMPOSITION_TRANSIENT && !(o->frames() >= 1 && o->frames() <= 4096))
-            Log_EError("film: transient decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames");
+        if (o->decomposition != MER_DECOMPOSITION_NONE && !(o->frames() >= 1 && o->frames() <= 4096))
+            Log_EError("film: a decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames");
         out = o;
     } else if (tag == "rfilter") {
         auto o = std::make_shared<ReconstructionFilter>();

@@ -162,7 +162,7 @@ public:
     int decomposition = MER_DECOMPOSITION_NONE; float minBound = 0.0f, maxBound = 0.0f, binWidth = 1.0f; bool calibratedTransient = false;
     /// PathLengthSampler (src/librender/pathlengthsampler.cpp:12-40)
     int modulation = MER_MODULATION_NONE; float lambda = 1.0f, phase = 0.0f; int P = 32, neighbors = 3;
-    int frames() const { return (decomposition == MER_DECOMPOSITION_TRANSIENT && modulation == MER_MODULATION_NONE) ? (int) std::ceil((maxBound - minBound) / binWidth) : 1; }
+    int frames() const { return (decomposition != MER_DECOMPOSITION_NONE && modulation == MER_MODULATION_NONE) ? (int) std::ceil((maxBound - minBound) / binWidth) : 1; }
     int channels() const { return frames() * 3 + 2; }
     std::shared_ptr<ReconstructionFilter> rfilter;
 };

@@ -19,7 +19,7 @@ TR_WOODCOCK2, TR_RATIO = 0, 1
 STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL, STRATEGY_MAXIMUM = 0, 1, 2, 3
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 ALBEDO_CONST, ALBEDO_GRID = 0, 1
-DECOMPOSITION_NONE, DECOMPOSITION_TRANSIENT = 0, 1
+DECOMPOSITION_NONE, DECOMPOSITION_TRANSIENT, DECOMPOSITION_BOUNCE = 0, 1, 2
 BSDF_NULL, BSDF_HDIELECTRIC = 0, 1
 MODULATION_NONE, MODULATION_SINE, MODULATION_SQUARE, MODULATION_HAMILTONIAN, MODULATION_MSEQ, MODULATION_DEPTHSELECTIVE = 0, 1, 2, 3, 4, 5
 
@@ -99,7 +99,7 @@ class SceneParams:
         self.env_radiance = [1.0, 1.0, 1.0]
         self.emission = [0.0, 0.0, 0.0]
         self.point_position = [0.0, 0.0, 0.0]; self.point_intensity = [0.0, 0.0, 0.0]     # emitter `point`
-        # film decomposition (src/librender/film.cpp:56-84): 0 none | 1 transient; frames = ceil((max-min)/binWidth)
+        # film decomposition (src/librender/film.cpp:56-84): 0 none | 1 transient | 2 bounce (bins by edge count); frames = ceil((max-min)/binWidth)
         self.decomposition = DECOMPOSITION_NONE; self.min_bound = 0.0; self.max_bound = 0.0; self.bin_width = 1.0
         self.calibrated_transient = False
         # path-length modulation (src/librender/pathlengthsampler.cpp:12-40): lambda, phase [deg], P, neighbors

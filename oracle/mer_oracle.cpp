@@ -710,9 +710,9 @@ struct Scene {
         if (s.modulation < 0 || s.modulation > 5) { g_err = "The \"modulation\" parameter must be equal toeither \"none\", \"square\", or \"hamiltonian\", or \"mseq\", or \"depthselective\"!"; return false; }
         if (s.modulation != 0 && s.decomposition != 1) { g_err = "film: a path-length modulation needs decomposition = transient"; return false; }
         if (s.decomposition == 1 && s.modulation != 0) frames = 1;                    /* film.cpp:76-78 */
-        else if (s.decomposition == 1) {
+        else if (s.decomposition == 1 || s.decomposition == 2) {
             frames = (int) std::ceil((s.max_bound - s.min_bound) / s.bin_width);      /* film.cpp:71-74 */
-            if (!(frames >= 1) || frames > 4096) { g_err = "film: transient decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames"; return false; }
+            if (!(frames >= 1) || frames > 4096) { g_err = "film: a decomposition needs 1 <= ceil((maxBound-minBound)/binWidth) <= 4096 frames"; return false; }
         } else if (s.decomposition != 0) { g_err = "The \"decomposition\" parameter must be equal toeither \"none\", \"transient\", or \"bounce\"!"; return false; }
         if (s.rif_double) rifD.configure(s); else rifF.configure(s);
         if (!s.rif_double && s.rif_mode == ORC_RIF_CONST) rifF.cst = s.rif_const;
@@ -1352,6 +1352,8 @@ struct Walker {
        decomposition values (frames x RGB) the contributions are binned into (bdpt_proc.cpp:449-470 restated for volpath) */
     Float lastTrOpt = 0;
     Float *decomp = nullptr;
+    /* what one path edge adds to the binned quantity: its optical length (transient) or 1 (bounce, bdpt_proc.cpp:179-187) */
+    inline Float el(Float opticalLength) const { return S.s.decomposition == 2 ? (Float) 1.0f : opticalLength; }
     Spec modL = Spec(0.0f);                      /* sum of contributions x correlationFunction(pathLength) (bdpt_proc.cpp:446-447) */
     inline void contribute(const Spec &value, Float pathLength) {
         if (S.s.modulation != 0) { if (!value.isZero()) modL += value * S.correlationFunction(pathLength); return; }
@@ -1656,7 +1658,7 @@ struct Walker {
 
         while (depth <= maxDepth || maxDepth < 0) {
             if (medium && sampleDistance(ro, rd, itsT, mRec)) {
-                plen += S.curved ? mRec.opticalLength : mRec.t * P.rif_const;           /* bdpt_proc.cpp:158-176 */
+                plen += el(S.curved ? mRec.opticalLength : mRec.t * P.rif_const);           /* bdpt_proc.cpp:158-176 */
                 if (depth >= maxDepth && maxDepth != -1) break;
                 if (hasEmission && P.sigma_mode == ORC_SIGMA_GRID) {
                     /* collision estimator for volumetric emission (new, config 5): eps(p)/sigma_t(p),
@@ -1693,7 +1695,7 @@ struct Walker {
                             Float phasePdf = phaseVal;       /* env emitter isOnSurface: constant.cpp:47 */
                             Float weight = miWeight(dpdf, phasePdf);
                             Li += throughput * value * phaseVal * weight;
-                            contribute(throughput * value * phaseVal * weight, plen + lastTrOpt);
+                            contribute(throughput * value * phaseVal * weight, plen + el(lastTrOpt));
                         }
                     }
                 }
@@ -1714,7 +1716,7 @@ struct Walker {
                         value *= tr;
                         if (!value.isZero()) {
                             Li += throughput * value * phaseEval(P.phase, P.g, wi, dvec);
-                            contribute(throughput * value * phaseEval(P.phase, P.g, wi, dvec), plen + dist * P.rif_const);
+                            contribute(throughput * value * phaseEval(P.phase, P.g, wi, dvec), plen + el(dist * P.rif_const));
                         }
                     } else {
                         /* connection through the RIF: Medium::eval (heterogeneousrefractive.cpp:571-640) */
@@ -1737,7 +1739,7 @@ struct Walker {
                             const Float invDist = 1.0f / std::sqrt(dot(dv, dv));
                             Spec value = pointI * (invDist * invDist) * tr * w;
                             Li += throughput * value * phaseEval(P.phase, P.g, wi, normalize(dir));
-                            contribute(throughput * value * phaseEval(P.phase, P.g, wi, normalize(dir)), plen + optD);
+                            contribute(throughput * value * phaseEval(P.phase, P.g, wi, normalize(dir)), plen + el(optD));
                         }
                     }
                 }
@@ -1767,13 +1769,13 @@ struct Walker {
                         Spec value = tr * env;
                         Float emitterPdf = INV_FOURPI_F;
                         Li += throughput * value * miWeight(phasePdf, emitterPdf);
-                        contribute(throughput * value * miWeight(phasePdf, emitterPdf), plen + lastTrOpt);
+                        contribute(throughput * value * miWeight(phasePdf, emitterPdf), plen + el(lastTrOpt));
                     }
                 }
                 emitted = false;                              /* ERadianceNoEmission */
             } else {
                 if (medium) {
-                    plen += S.curved ? mRec.opticalLength : itsT * P.rif_const;
+                    plen += el(S.curved ? mRec.opticalLength : itsT * P.rif_const);
                     throughput *= mRec.transmittance / mRec.pdfFailure;                  /* volpath.cpp:188-189 */
                     if (S.curved) {
                         throughput *= mRec.refRatioSq;
@@ -1794,7 +1796,7 @@ struct Walker {
                         const Float tHit = S.intersectShape(ro, rd, 0.0f, std::numeric_limits<Float>::infinity());
                         itsT = tHit >= 0 ? tHit : 0;
                     }
-                    if (!medium && !P.calibrated_transient) plen += itsT;
+                    if (!medium && !P.calibrated_transient) plen += el(itsT);
                     const Vec x = ro + rd * itsT;
                     const Vec n = S.shapeNormal(x);
                     const Float cosI = dot(-rd, n);            /* Frame::cosTheta(bRec.wi), wi = -ray.d */
@@ -1828,7 +1830,7 @@ struct Walker {
                 } else {
                 /* null BSDF (shape.cpp:48-70): no NEE (not smooth), pass-through sample */
                 (void) rng.next1D(); (void) rng.next1D();     /* bsdf->sample(bRec, pdf, rRec.nextSample2D()) */
-                if (!medium && !P.calibrated_transient) plen += itsT;      /* the camera edge (bdpt_proc.cpp:163-176: startIndex 2 | 3) */
+                if (!medium && !P.calibrated_transient) plen += el(itsT);  /* the camera edge (bdpt_proc.cpp:163-176: startIndex 2 | 3) */
                 ro = ro + rd * itsT;
                 medium = !medium;
                 emitted = !scattered;                         /* volpath.cpp:293-301 */
@@ -2089,12 +2091,12 @@ static void renderRows(const Scene &S, int spp_begin, int spp_count, uint64_t se
                 Vec o, d; Float mint, maxt;
                 S.sampleRay(px, py, o, d, mint, maxt);
                 std::fill(temp.begin(), temp.end(), 0.0f);
-                if (S.s.decomposition == 1 && S.s.modulation == 0) Wk.decomp = temp.data();
+                if (S.s.decomposition != 0 && S.s.modulation == 0) Wk.decomp = temp.data();
                 Spec L = Wk.Li(o, d, mint, maxt);
                 C.c[ORC_C_PATHS]++;
                 if (pathOut) { float *q = pathOut + ((size_t) y * W + x) * 3; q[0] = L[0]; q[1] = L[1]; q[2] = L[2]; }
                 else {
-                    if (S.s.decomposition != 1 || S.s.modulation != 0) { temp[0] = L[0]; temp[1] = L[1]; temp[2] = L[2]; }
+                    if (S.s.decomposition == 0 || S.s.modulation != 0) { temp[0] = L[0]; temp[1] = L[1]; temp[2] = L[2]; }
                     temp[ch - 2] = 1.0f; temp[ch - 1] = 1.0f;
                     filmPut(S, film, px, py, temp.data());
                 }

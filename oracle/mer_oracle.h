@@ -75,7 +75,7 @@ typedef struct {
     float   env_radiance[3];
     float   emission[3];            /* medium emission coefficient per unit density (0 => none) */
     float   point_position[3], point_intensity[3];   /* emitter `point` (src/emitters/point.cpp); intensity 0 => none */
-    /* film decomposition (src/librender/film.cpp:56-84): 0 = none (steady state), 1 = transient: every radiance contribution is
+    /* film decomposition (src/librender/film.cpp:56-84): 0 = none (steady state), 2 = bounce (as transient with every edge counting 1), 1 = transient: every radiance contribution is
        binned by its optical path length into frames = ceil((max_bound - min_bound) / bin_width) RGB slices; the film is
        float[H][W][frames*3 + 2] (RGB per frame, then alpha, weight), the reference's channel order (bdpt_proc.cpp:230-245) */
     int32_t decomposition; float min_bound, max_bound, bin_width; int32_t calibrated_transient;

@@ -55,6 +55,43 @@ def test_transient_film_matches_oracle(ctx, orc, name):
         v.destroy()
 
 
+BOUNCE = dict(decomposition=P.DECOMPOSITION_BOUNCE, min_bound=0.0, max_bound=16.0, bin_width=1.0, rfilter=P.FILTER_BOX, rfilter_param=0.5, max_depth=12)
+BOUNCE_CASES = {
+    "straight_env_ratio": lambda: scenes.straight_scene(N=24, w=24, h=20, **BOUNCE),
+    "homogeneous_point": lambda: scenes.homogeneous_scene(w=24, h=20, **POINT, **BOUNCE),
+    "curved_env_rk4": lambda: scenes.curved_scene(N=24, w=24, h=20, **BOUNCE),
+    "curved_dielectric_boundary": lambda: scenes.curved_scene(N=24, w=24, h=20, boundary_bsdf=P.BSDF_HDIELECTRIC, **BOUNCE),
+    "curved_point_emissive": lambda: scenes.curved_scene(N=24, w=24, h=20, emission=[0.2, 0.12, 0.06], **POINT, **BOUNCE),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BOUNCE_CASES))
+def test_bounce_film_matches_oracle(ctx, orc, name):
+    """decomposition = bounce (film.cpp:66-68): the transient film with every path edge counting 1 (bdpt_proc.cpp:179-187) -- the frames are
+    bounce orders.  Same tolerances as the transient film; the frames add up to the steady-state film."""
+    p = BOUNCE_CASES[name]()
+    sc, vols = ctx.upload_scene(p)
+    spp = 8
+    a = ctx.render_to_host(sc, 0, spp, seed=4)
+    b, _ = orc.render(p, 0, spp, 4)
+    assert a.shape == b.shape == (p.height, p.width, 16 * 3 + 2)
+    np.testing.assert_allclose(a[..., -2:], b[..., -2:], rtol=1e-5, atol=1e-5)
+    assert (b[..., :-2].reshape(-1, 16, 3).sum((0, 2)) > 0).sum() >= 4                # several bounce orders are populated
+    if name.startswith("curved_point"):
+        nz = (a[..., :-2] != 0) | (b[..., :-2] != 0)
+        agree = np.isclose(a[..., :-2][nz], b[..., :-2][nz], rtol=1e-3, atol=1e-7).mean()
+        assert agree > 0.8, agree
+    else:
+        assert _rel_l2(a[..., :-2], b[..., :-2]) < 2e-2
+        pa = a[..., :-2].reshape(-1, 16, 3).sum(0); pb = b[..., :-2].reshape(-1, 16, 3).sum(0)
+        assert _rel_l2(pa, pb) < 5e-3
+    steady_sc, vols2 = ctx.upload_scene(p.copy(decomposition=P.DECOMPOSITION_NONE))
+    steady = ctx.render_to_host(steady_sc, 0, spp, seed=4)
+    np.testing.assert_allclose(a[..., :-2].reshape(p.height, p.width, 16, 3).sum(2), steady[..., :3], rtol=1e-4, atol=1e-5)
+    for v in vols + vols2:
+        v.destroy()
+
+
 def test_frames_sum_to_steady_state_on_the_gpu(ctx):
     p = scenes.curved_scene(N=24, w=24, h=20, rfilter=P.FILTER_BOX, rfilter_param=0.5, max_depth=10)
     pt = p.copy(decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=0.0, max_bound=64.0, bin_width=0.5)

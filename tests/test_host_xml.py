@@ -138,9 +138,18 @@ def test_transient_film_and_point_emitter_flatten():
     assert list(d.env_radiance) == [0, 0, 0]
 
 
+def test_bounce_decomposition_flattens(tmp_path):
+    """film `decomposition` = bounce (src/librender/film.cpp:66-68) with minBound / maxBound / binWidth = the bounce orders kept"""
+    cam = ('<sensor type="perspective"><film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/><string name="decomposition" value="bounce"/>'
+           '<float name="maxBound" value="10"/></film></sensor>')
+    f = _scene(tmp_path, '<integrator type="volpath"/>' + cam + '<medium type="homogeneous" id="m"><spectrum name="sigmaS" value="1"/><spectrum name="sigmaA" value="0.1"/></medium><shape type="cube"><ref name="interior" id="m"/></shape>')
+    d, _ = host.flatten_xml(f)
+    assert d.decomposition == P.DECOMPOSITION_BOUNCE and (d.min_bound, d.max_bound, d.bin_width) == (0.0, 10.0, 1.0)
+
+
 @pytest.mark.parametrize("film,msg", [
     ('<string name="decomposition" value="temporal"/>', "decomposition"),
-    ('<string name="decomposition" value="bounce"/>', "bounce"),
+    ('<string name="decomposition" value="bounce"/><float name="minBound" value="3"/><float name="maxBound" value="1"/>', "frames"),
     ('<string name="decomposition" value="transient"/><float name="minBound" value="3"/><float name="maxBound" value="1"/>', "frames"),
     ('<string name="decomposition" value="transient"/><float name="maxBound" value="4"/><string name="modulation" value="triangle"/>', "modulation"),
     ('<string name="modulation" value="sine"/>', "needs decomposition = transient"),

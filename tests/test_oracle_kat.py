@@ -359,6 +359,30 @@ def test_transient_frames_sum_to_the_steady_state_film(orc, kind):
     np.testing.assert_allclose(tot, fs[..., :3], rtol=2e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("kind", ["straight", "curved", "homogeneous"])
+def test_bounce_frames_are_bounce_orders(orc, kind):
+    """decomposition = bounce bins by the number of path edges (film.cpp:66-68, bdpt_proc.cpp:179-187,335-381).  Known answers: the frames add
+    up to the steady-state film; raising maxDepth by one populates exactly one more frame and leaves the others bit for bit (the sampler
+    streams of the shorter paths are unchanged), so frame k holds the light of one bounce order."""
+    mk = {"straight": lambda: scenes.straight_scene(N=16, w=8, h=8), "curved": lambda: scenes.curved_scene(N=16, w=8, h=8),
+          "homogeneous": lambda: scenes.homogeneous_scene(w=8, h=8)}[kind]
+    base = mk().copy(rfilter=P.FILTER_BOX, rfilter_param=0.5, rr_depth=100)
+    films, tops = [], []
+    for d in (3, 4, 5, 6):                                     # maxDepth 2 stops at the (null) boundary of the medium shape: nothing scatters yet
+        pb = base.copy(max_depth=d, decomposition=P.DECOMPOSITION_BOUNCE, min_bound=0.0, max_bound=12.0, bin_width=1.0)
+        fb, _ = orc.render(pb, 0, 32, 5)
+        fs, _ = orc.render(base.copy(max_depth=d), 0, 32, 5)
+        assert fb.shape == (8, 8, 12 * 3 + 2)
+        np.testing.assert_array_equal(fb[..., -2:], fs[..., 3:])
+        fr = fb[..., :-2].reshape(8, 8, 12, 3)
+        np.testing.assert_allclose(fr.sum(2), fs[..., :3], rtol=2e-5, atol=1e-5)
+        films.append(fr); tops.append(int(np.nonzero(fr.sum((0, 1, 3)))[0].max()))
+    assert tops == [tops[0] + i for i in range(4)], tops
+    for lo, hi, t in zip(films, films[1:], tops):
+        np.testing.assert_array_equal(hi[:, :, :t + 1], lo[:, :, :t + 1])
+        assert hi[:, :, t + 1].sum() > 0 and hi[:, :, t + 2:].sum() == 0
+
+
 def test_transient_single_scatter_profile_matches_quadrature(orc):
     """Time-resolved known answer: homogeneous isotropic medium, point emitter, exactly one scattering event.  A path that
     scatters at depth t along the central camera ray has optical length 2 + t + d(t) (camera edge 2, n = 1), so frame k holds
