@@ -15,9 +15,18 @@ limiter = sys.argv[3] if len(sys.argv) > 3 else None
 
 
 def sums(kind):
+    """counter sums of K_march from the pass's summary.txt (written on the GPU box by pmc_sum.py; the raw CSVs above 1 MiB are not kept)"""
+    import re
     d = os.path.join(ROOT, "gpurun_out", "pmc_%s_%s" % (tag, kind))
-    out = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "scratch", "pmc_sum.py"), d, "--json"]))
-    return out.get("march_kernel", {}), d
+    out, cur = {}, None
+    for line in open(os.path.join(d, "summary.txt")):
+        if not line.startswith(" "):
+            cur = line.strip()
+            continue
+        m = re.match(r"\s+(\S+)\s+(\S+)\s+\(dispatches (\d+)\)", line)
+        if m and cur == "march_kernel":
+            out[m.group(1)] = {"sum": float(m.group(2)), "dispatches": int(m.group(3))}
+    return out, d
 
 
 rd, d_rd = sums("rd"); fe, _ = sums("fetch"); wr, _ = sums("write"); l2, _ = sums("l2"); sq, _ = sums("sq"); sq2, _ = sums("sq2")
