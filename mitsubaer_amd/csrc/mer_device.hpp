@@ -104,6 +104,13 @@ struct DGrid {
     uint64_t n_dense, n_record;       // element counts of data (all channels) and of cell8 (floats): the extents the checks use
 };
 
+// Record index of cell (x, y, z) in the CELL8 layout: cells in x-major order (four x-neighbours per 128-byte line).  Storing the eight cells of a
+// 2x2x2 tile together instead measured +1 ... 4 % (profiles/round2/ab_cell8_tile_order.txt): not adopted.
+__device__ __forceinline__ uint32_t cell8_record(const DGrid &g, int x, int y, int z) {
+    return __umul24(__umul24(z, g.res[1] - 1) + y, g.res[0] - 1) + x;
+}
+
+
 // include/mitsuba/core/aabb.h:308-339 (dRcp = 1/d as Ray::setDirection)
 __device__ __forceinline__ bool aabb_intersect(const float mn[3], const float mx[3], f3 o, f3 d, float &nearT, float &farT) {
     nearT = -MER_INF; farT = MER_INF;
@@ -148,7 +155,7 @@ __device__ __forceinline__ float lookup_float(const DGrid &g, f3 p, int *idx4 = 
     if (idx4) { idx4[0] = x1; idx4[1] = y1; idx4[2] = z1; idx4[3] = inside ? base : -1; }
     float d000, d001, d010, d011, d100, d101, d110, d111;
     if (g.layout == MER_LAYOUT_CELL8) {
-        const int cell = (zc * (g.res[1] - 1) + yc) * (g.res[0] - 1) + xc;
+        const int cell = (int) cell8_record(g, xc, yc, zc);
         const float4 *c = (const float4 *) (g.cell8 + (size_t) MER_CHK(g.chk, CHK_GRID_RECORD, (size_t) cell * 8, g.n_record - 7));
         const float4 a = c[0], b = c[1];
         d000 = a.x; d001 = a.y; d010 = a.z; d011 = a.w; d100 = b.x; d101 = b.y; d110 = b.z; d111 = b.w;
@@ -299,7 +306,7 @@ __device__ __forceinline__ void cell_fill(const DGrid &g, CellCache &cc, float p
         cc.cell = base;
         const int dbase = (int) MER_CHK(g.chk, CHK_GRID_DENSE, (uint32_t) base, g.n_dense - (uint32_t) (g.res[0] * g.res[1] + g.res[0]) - 1u); (void) dbase;
         if (RIFK == RIFK_CELL8 || RIFK == RIFK_CELL8_BUF) {
-            const int cell = (int) MER_CHK(g.chk, CHK_GRID_RECORD, (uint32_t) (__umul24(__umul24(z1, g.res[1] - 1) + y1, g.res[0] - 1) + x1), g.n_record >> 3);
+            const int cell = (int) MER_CHK(g.chk, CHK_GRID_RECORD, cell8_record(g, x1, y1, z1), g.n_record >> 3);
             float4 a, b;
             if (RIFK == RIFK_CELL8_BUF) {
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
@@ -703,7 +710,7 @@ __device__ __forceinline__ float lookup_float_branching(const DGrid &g, f3 p, in
     if (idx4) idx4[3] = base;
     float d000, d001, d010, d011, d100, d101, d110, d111;
     if (g.layout == MER_LAYOUT_CELL8) {
-        const int cell = (z1 * (g.res[1] - 1) + y1) * (g.res[0] - 1) + x1;
+        const int cell = (int) cell8_record(g, x1, y1, z1);
         const float4 *c = (const float4 *) (g.cell8 + (size_t) MER_CHK(g.chk, CHK_GRID_RECORD, (size_t) cell * 8, g.n_record - 7));
         const float4 a = c[0], b = c[1];
         d000 = a.x; d001 = a.y; d010 = a.z; d011 = a.w; d100 = b.x; d101 = b.y; d110 = b.z; d111 = b.w;
