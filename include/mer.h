@@ -120,7 +120,13 @@ typedef struct {
        k_r = 2 pi freq / speed; gradient and Hessian as written there (r clamped at 1e-8).  No `rif` volume. */
     float   ac_n_o, ac_n_max, ac_k_r;
     int32_t ac_mode;
+    /* `method` of the heterogeneous medium (src/medium/heterogeneous.cpp:195-202): MER_METHOD_WOODCOCK (default) or MER_METHOD_SIMPSON --
+       composite Simpson quadrature of the density along straight rays for the transmittance (integrateDensity, :301-376) and its
+       inversion for the free flight (invertDensityIntegral, :419-544); sigma_mode = GRID, rif_mode = CONST only.  het_stepsize = the
+       plugin's `stepSize`; 0 = inferred as the reference does (:245-257): 0.5 x the smallest voxel extent of the density / albedo grids. */
+    int32_t method; float het_stepsize;
 } mer_scene_desc;
+enum { MER_METHOD_WOODCOCK = 0, MER_METHOD_SIMPSON = 1 };
 enum { MER_BSDF_NULL = 0, MER_BSDF_HDIELECTRIC = 1 };
 enum { MER_MODULATION_NONE = 0, MER_MODULATION_SINE, MER_MODULATION_SQUARE, MER_MODULATION_HAMILTONIAN, MER_MODULATION_MSEQ,
        MER_MODULATION_DEPTHSELECTIVE };

@@ -60,6 +60,7 @@ class SceneDesc(C.Structure):
         ("aggressive_tracing", C.c_int32),
         ("sdf_max_error", C.c_float),
         ("ac_n_o", C.c_float), ("ac_n_max", C.c_float), ("ac_k_r", C.c_float), ("ac_mode", C.c_int32),
+        ("method", C.c_int32), ("het_stepsize", C.c_float),
     ]
 
 
@@ -244,6 +245,7 @@ class Context:
         s.rif_mode, s.rif_const = p.rif_mode, p.rif_const
         s.rif = rif.handle if rif is not None else 0
         s.ac_n_o, s.ac_n_max, s.ac_k_r, s.ac_mode = float(p.ac_n_o), float(p.ac_n_max), float(p.ac_k_r), int(p.ac_mode)
+        s.method = int(p.method); s.het_stepsize = float(p.het_stepsize)
         s.stepper, s.stepsize = p.stepper, p.stepsize
         s.phase, s.g = p.phase, p.g
         s.tr_estimator = p.tr_estimator

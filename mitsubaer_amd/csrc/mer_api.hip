@@ -131,6 +131,24 @@ int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bool allo
         if (!(sc->density_scale > 0)) return fail(ctx, "heterogeneous medium: 'scale' must be positive");
         // m_maxDensity = m_scale * getMaximumFloatValue() (= 1.0 for gridvolume): heterogeneous.cpp:239-242
         P.inv_max_density = 1.0f / (sc->density_scale * 1.0f);
+        if (sc->method != MER_METHOD_WOODCOCK && sc->method != MER_METHOD_SIMPSON) return fail(ctx, "Unsupported integration method!");    // heterogeneous.cpp:195-202
+        if (sc->method == MER_METHOD_SIMPSON) {
+            if (sc->rif_mode != MER_RIF_CONST) return fail(ctx, "method = simpson belongs to the heterogeneous medium (straight rays)");
+            auto step_of = [](const mer_grid_desc &g) {                      // gridvolume.cpp:196-198
+                float s = std::numeric_limits<float>::infinity();
+                for (int i = 0; i < 3; i++) s = std::min(s, 0.5f * (g.aabb_max[i] - g.aabb_min[i]) / (float) (g.res[i] - 1));
+                return s;
+            };
+            float h = sc->het_stepsize;                                      // heterogeneous.cpp:245-257
+            if (h == 0) {
+                h = step_of(ctx->volumes.find(sc->density)->second.desc);
+                if (sc->albedo_mode == MER_ALBEDO_GRID) { auto ia = ctx->volumes.find(sc->albedo_grid); if (ia != ctx->volumes.end()) h = std::min(h, step_of(ia->second.desc)); }
+            }
+            if (!(h > 0) || !std::isfinite(h))
+                return fail(ctx, "Unable to infer a suitable step size for deterministic integration, please specify one manually using the 'stepSize' parameter.");
+            P.het_step = h;
+            P.sc.tr_estimator = MER_TR_RATIO;        // one walk per transmittance query (the estimator choice is the Woodcock method's)
+        }
     }
     if (sc->albedo_mode == MER_ALBEDO_GRID) {
         auto it = ctx->volumes.find(sc->albedo_grid);

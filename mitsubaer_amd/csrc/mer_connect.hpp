@@ -503,6 +503,7 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
         f3 tr(1, 1, 1);
         if (crosses && interactions == 0) tr = f3(0, 0, 0);
         else if (SIGMA == MER_SIGMA_HOMOGENEOUS) tr = homogeneous_transmittance(P, 0.0f - L);
+        else if (S.method == MER_METHOD_SIMPSON) { const float tv = expf(-simpson_integrate(P, C, ps, dvec, L)); tr = f3(tv, tv, tv); }    // heterogeneous.cpp:547-548
         else {
             float mint, maxt;                                            // heterogeneous.cpp:546-587
             if (aabb_intersect(P.density.wmin, P.density.wmax, ps, dvec, mint, maxt)) {

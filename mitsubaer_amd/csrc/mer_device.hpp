@@ -588,6 +588,7 @@ struct Params {
     float medium_sampling_weight, sampling_density;
     MaxExp maxexp;                      // strategy = maximum
     float inv_max_density;
+    float het_step;               // method = simpson: the heterogeneous medium's stepSize (given, or inferred from the grids)
     float cam[12], aspect, cot_half_fov, inv_res_x, inv_res_y;
     float fvalues[33], fradius, fscale;
     // work

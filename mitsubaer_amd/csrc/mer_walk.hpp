@@ -21,6 +21,87 @@ struct LaneCounters {
     __device__ __forceinline__ void clear() { steps = rif_evals = tentative = real = segments = nee = paths = marched = 0; }
 };
 
+// ---------------------------------------------------------------------------------------------------
+// method = simpson of the heterogeneous medium (src/medium/heterogeneous.cpp:301-544): deterministic composite Simpson quadrature of
+// the density along a straight ray, and its inversion for the free flight.  Not a wavefront walk: the whole march runs where the
+// walk would have begun (Walk::begin), one lane per ray -- the north star's estimators are Woodcock / ratio tracking, this is the
+// reference's other `method`, kept for completeness and as the deterministic cross-check of the trackers.  ray.mint = 0 as
+// everywhere on this path; HETVOL_EARLY_EXIT as the reference defines it (:31).
+__device__ __forceinline__ float simpson_lookup(const Params &P, LaneCounters &C, f3 p) { C.tentative++; return lookup_float(P.density, p); }
+__device__ inline float simpson_integrate(const Params &P, LaneCounters &C, f3 o, f3 d, float rayMaxt) {       // integrateDensity, :301-376
+    float mint, maxt;
+    if (!aabb_intersect(P.density.wmin, P.density.wmax, o, d, mint, maxt)) return 0.0f;
+    mint = fmaxf(mint, 0.0f); maxt = fminf(maxt, rayMaxt);
+    const float length = maxt - mint;
+    f3 p = o + d * mint; const f3 pLast = o + d * maxt;
+    const float maxComp = fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(0.0f, fabsf(p.x)), fabsf(pLast.x)), fabsf(p.y)), fabsf(pLast.y)), fabsf(p.z)), fabsf(pLast.z));
+    if (length < 1e-6f * maxComp) return 0.0f;
+    uint32_t nSteps = (uint32_t) ceilf(length / P.het_step);
+    nSteps += nSteps % 2;
+    const float stepSize = length / nSteps;
+    const f3 increment = d * stepSize;
+    float integratedDensity = simpson_lookup(P, C, p) + simpson_lookup(P, C, pLast);
+    const float stopAfterDensity = -logf(1e-4f);
+    const float stopValue = stopAfterDensity * 3.0f / (stepSize * P.sc.density_scale);
+    p = p + increment;
+    float m = 4;
+    for (uint32_t i = 1; i < nSteps; ++i) {
+        integratedDensity += m * simpson_lookup(P, C, p);
+        m = 6 - m;
+        if (integratedDensity > stopValue) return MER_INF;
+        const f3 next = p + increment;
+        if (p.x == next.x && p.y == next.y && p.z == next.z) break;
+        p = next;
+    }
+    return integratedDensity * P.sc.density_scale * stepSize * (1.0f / 3.0f);
+}
+__device__ inline bool simpson_invert(const Params &P, LaneCounters &C, f3 o, f3 d, float rayMaxt, float desiredDensity,
+                                      float &integratedDensity, float &t, float &densityAtT) {                      // invertDensityIntegral, :419-544
+    integratedDensity = densityAtT = 0.0f; t = 0.0f;
+    float mint, maxt;
+    if (!aabb_intersect(P.density.wmin, P.density.wmax, o, d, mint, maxt)) return false;
+    mint = fmaxf(mint, 0.0f); maxt = fminf(maxt, rayMaxt);
+    const float length = maxt - mint;
+    f3 p = o + d * mint; const f3 pLast = o + d * maxt;
+    const float maxComp = fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(fmaxf(0.0f, fabsf(p.x)), fabsf(pLast.x)), fabsf(p.y)), fabsf(pLast.y)), fabsf(p.z)), fabsf(pLast.z));
+    if (length < 1e-6f * maxComp) return false;
+    const uint32_t nSteps = (uint32_t) ceilf(length / (2 * P.het_step));
+    const float stepSize = length / nSteps, multiplier = (1.0f / 6.0f) * stepSize * P.sc.density_scale;
+    const f3 fullStep = d * stepSize, halfStep = fullStep * .5f;
+    float node1 = simpson_lookup(P, C, p);
+    for (uint32_t i = 0; i < nSteps; ++i) {
+        const float node2 = simpson_lookup(P, C, p + halfStep), node3 = simpson_lookup(P, C, p + fullStep),
+                    newDensity = integratedDensity + multiplier * (node1 + node2 * 4 + node3);
+        if (newDensity >= desiredDensity) {
+            // Newton-bisection on the quadratic fitted to the last three look-ups (:476-528): no further density queries
+            float a = 0, b = stepSize, x = a, fx = integratedDensity - desiredDensity;
+            const float stepSizeSqr = stepSize * stepSize, temp = P.sc.density_scale / stepSizeSqr;
+            int it = 1;
+            for (;;) {
+                const float dfx = temp * (node1 * stepSizeSqr - (3 * node1 - 4 * node2 + node3) * stepSize * x + 2 * (node1 - 2 * node2 + node3) * x * x);
+                x -= fx / dfx;
+                if (x <= a || x >= b || dfx == 0) x = 0.5f * (b + a);
+                const float intval = integratedDensity + temp * (1.0f / 6.0f) * (x * (6 * node1 * stepSizeSqr - 3 * (3 * node1 - 4 * node2 + node3) * stepSize * x
+                                     + 4 * (node1 - 2 * node2 + node3) * x * x));
+                fx = intval - desiredDensity;
+                if (fabsf(fx) < 1e-6f) {
+                    t = mint + stepSize * i + x;
+                    integratedDensity = intval;
+                    densityAtT = temp * (node1 * stepSizeSqr - (3 * node1 - 4 * node2 + node3) * stepSize * x + 2 * (node1 - 2 * node2 + node3) * x * x);
+                    return true;
+                } else if (++it > 30) return false;
+                if (fx > 0) b = x; else a = x;
+            }
+        }
+        const f3 next = p + fullStep;
+        if (p.x == next.x && p.y == next.y && p.z == next.z) break;
+        integratedDensity = newDensity;
+        node1 = node3;
+        p = next;
+    }
+    return false;
+}
+
 // State of the ray a lane is currently marching.
 template <bool CURVED, int RIF, int STEPPER, int SIGMA, int BND = 0>
 struct Walk {
@@ -114,6 +195,17 @@ struct Walk {
             return EV_NONE;
         } else {
             p = o; v = d;
+            if (SIGMA == MER_SIGMA_GRID && P.sc.method == MER_METHOD_SIMPSON) {          // heterogeneous.cpp:547-548, 594-612: the march runs here
+                if (k == K_FREE) {
+                    const float desired = -logf(1 - rng.next1D());
+                    float integrated, dens;
+                    const bool ok = simpson_invert(P, C, o, d, rayMaxt, desired, integrated, t, dens);
+                    Tr = expf(-integrated); sdens = dens;                                 // expVal and densityAtT ride to finish_free_flight
+                    return (ok && Tr * dens > 0) ? EV_REAL : EV_FAIL;
+                }
+                Tr = expf(-simpson_integrate(P, C, o, d, rayMaxt));
+                return EV_WALK_END;
+            }
             if (SIGMA == MER_SIGMA_GRID) {
                 float mint, maxt;                                             // heterogeneous.cpp:626-630
                 if (!aabb_intersect(P.density.wmin, P.density.wmax, o, d, mint, maxt)) {
@@ -251,6 +343,10 @@ __device__ __forceinline__ void finish_free_flight(const Params &P, LaneCounters
     }
     if (SIGMA == MER_SIGMA_GRID) {
         m.pdfSuccess = 1.0f; m.pdfFailure = 1.0f; m.transmittance = f3(1, 1, 1);         // heterogeneous.cpp:616-619
+        if (!CURVED && P.sc.method == MER_METHOD_SIMPSON) {                              // :604-611: expVal in W.Tr, densityAtT in W.sdens
+            m.transmittance = f3(W.Tr, W.Tr, W.Tr); m.pdfFailure = W.Tr; m.pdfSuccess = W.Tr * W.sdens;
+            m.sigmaS = success ? albedo_at(P, m.p) * W.sdens : f3(0, 0, 0);
+        } else
         if (success) {
             const f3 albedo = albedo_at(P, m.p);
             m.sigmaS = albedo * sigma;                                                   // :645-649

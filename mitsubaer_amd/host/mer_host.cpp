@@ -317,9 +317,9 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
                 Log_EError("The 'sigmaS' and 'sigmaA' properties are only supported by homogeneous media. Please use nested volume instances to supply these parameters");
             if (props.hasProperty("densityMultiplier")) Log_EError("The 'densityMultiplier' parameter has been deprecated and is now called 'scale'.");
             o->scale = props.getFloat("scale", 1);
-            (void) props.getFloat("stepSize", 0);
+            o->hetStepSize = props.getFloat("stepSize", 0);
             const std::string method = lower(props.getString("method", "woodcock"));
-            if (method == "simpson") Log_EError("heterogeneous: method 'simpson' is not supported on the GPU path (woodcock)");
+            if (method == "simpson") o->method = MER_METHOD_SIMPSON;
             else if (method != "woodcock") Log_EError("Unsupported integration method \"" + method + "\"!");
         } else Log_EError("medium \"" + type + "\" is not supported on the GPU path");
         // extensions (documented in INTEGRATION.md): stepper, transmittance estimator, emission
@@ -690,7 +690,7 @@ void Integrator::flatten(const Scene &scene, mer_scene_desc &d) const {
         d.sdf_max_error = (float) std::sqrt(e2);
     }
     d.phase = m.phase->kind; d.g = m.phase->g;
-    d.tr_estimator = m.trEstimator;
+    d.tr_estimator = m.trEstimator; d.method = m.method; d.het_stepsize = m.hetStepSize;
     int nconst = 0, npoint = 0;
     for (int i = 0; i < 3; i++) { d.env_radiance[i] = 0; d.point_intensity[i] = 0; d.point_position[i] = 0; d.emission[i] = m.emission.c[i]; }
     for (auto &e : scene.emitters) {

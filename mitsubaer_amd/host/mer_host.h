@@ -120,6 +120,7 @@ public:
     float stepsize = 1e-3f;                    // heterogeneousrefractive `stepsize`
     bool aggressiveTracing = false;            // heterogeneousrefractive `aggressivetracing` (needs the `sdf` child)
     int stepper = MER_STEP_VERLET, trEstimator = MER_TR_WOODCOCK2;
+    int method = MER_METHOD_WOODCOCK; float hetStepSize = 0;       ///< heterogeneous `method`, `stepSize` (heterogeneous.cpp:183-202)
     Spectrum emission{};
     std::shared_ptr<VolumeDataSource> density, albedo, rif, sdf;
     std::shared_ptr<PhaseFunction> phase;

@@ -20,6 +20,7 @@ STRATEGY_BALANCE, STRATEGY_SINGLE, STRATEGY_MANUAL, STRATEGY_MAXIMUM = 0, 1, 2, 
 FILTER_BOX, FILTER_GAUSSIAN = 0, 1
 ALBEDO_CONST, ALBEDO_GRID = 0, 1
 DECOMPOSITION_NONE, DECOMPOSITION_TRANSIENT, DECOMPOSITION_BOUNCE = 0, 1, 2
+METHOD_WOODCOCK, METHOD_SIMPSON = 0, 1
 BSDF_NULL, BSDF_HDIELECTRIC = 0, 1
 MODULATION_NONE, MODULATION_SINE, MODULATION_SQUARE, MODULATION_HAMILTONIAN, MODULATION_MSEQ, MODULATION_DEPTHSELECTIVE = 0, 1, 2, 3, 4, 5
 
@@ -96,6 +97,8 @@ class SceneParams:
         self.rif_double = 0
         self.phase = PHASE_HG; self.g = 0.8
         self.tr_estimator = TR_RATIO
+        # heterogeneous `method` (woodcock | simpson) and its `stepSize` (0 = inferred from the grids): src/medium/heterogeneous.cpp:183-202,245-257
+        self.method = METHOD_WOODCOCK; self.het_stepsize = 0.0
         self.env_radiance = [1.0, 1.0, 1.0]
         self.emission = [0.0, 0.0, 0.0]
         self.point_position = [0.0, 0.0, 0.0]; self.point_intensity = [0.0, 0.0, 0.0]     # emitter `point`

@@ -651,6 +651,7 @@ struct Scene {
     Float mediumSamplingWeight, samplingDensity;
     MaxExpDist maxExp;
     Float maxDensity, invMaxDensity;
+    Float hetStepSize = 0;          /* heterogeneous `stepSize` (method = simpson), heterogeneous.cpp:183,245-257 */
     bool curved;
     Grid sdfGrid; Float sdfEps = 0;
     int frames = 1;                /* film.cpp:71-78 */
@@ -696,6 +697,16 @@ struct Scene {
             /* heterogeneous.cpp:239-242 with gridvolume.cpp:583-585 (maximum hard-coded to 1) */
             maxDensity = s.density_scale * 1.0f;
             invMaxDensity = 1.0f / maxDensity;
+            if (s.method != 0 && s.method != 1) { g_err = "Unsupported integration method!"; return false; }           /* :195-202 */
+            if (s.method == 1) {
+                if (s.rif_mode != ORC_RIF_CONST) { g_err = "method = simpson belongs to the heterogeneous medium (straight rays)"; return false; }
+                hetStepSize = s.het_stepsize;                                      /* :245-257: 0 => min over the volumes' getStepSize() */
+                if (hetStepSize == 0) {
+                    hetStepSize = density.stepSize;
+                    if (s.albedo_mode == ORC_ALBEDO_GRID) { Grid a; a.configure(s.albedo_grid); hetStepSize = std::min(hetStepSize, a.stepSize); }
+                }
+                if (!(hetStepSize > 0) || !std::isfinite(hetStepSize)) { g_err = "Unable to infer a suitable step size for deterministic integration, please specify one manually using the 'stepSize' parameter."; return false; }
+            }
         }
         if (s.albedo_mode == ORC_ALBEDO_GRID) albedoGrid.configure(s.albedo_grid);
         curved = s.rif_mode != ORC_RIF_CONST;
@@ -1369,8 +1380,109 @@ struct Walker {
         return S.density.lookupFloat(p) * S.s.density_scale;
     }
 
+    /* heterogeneous.cpp:301-376: composite Simpson quadrature of the density over the ray segment [0, rayMaxt] clipped to the
+       density box; HETVOL_EARLY_EXIT is defined in the reference (:31).  ray.mint = 0 as everywhere on this path. */
+    Float integrateDensity(const Vec &o, const Vec &d, Float rayMaxt) {
+        Float mint, maxt;
+        if (!S.density.rayIntersect(o, d, mint, maxt)) return 0.0f;
+        mint = std::max(mint, (Float) 0.0f);
+        maxt = std::min(maxt, rayMaxt);
+        Float length = maxt - mint, maxComp = 0;
+        Vec p = o + d * mint, pLast = o + d * maxt;
+        { const Float pc[3] = {p.x, p.y, p.z}, lc[3] = {pLast.x, pLast.y, pLast.z};
+          for (int i = 0; i < 3; ++i) maxComp = std::max(std::max(maxComp, std::abs(pc[i])), std::abs(lc[i])); }
+        if (length < 1e-6f * maxComp) return 0.0f;
+        uint32_t nSteps = (uint32_t) std::ceil(length / S.hetStepSize);
+        nSteps += nSteps % 2;
+        const Float stepSize = length / nSteps;
+        const Vec increment = d * stepSize;
+        Float integratedDensity = lookupDensity(p) + lookupDensity(pLast);
+        const Float stopAfterDensity = -std::log((Float) 1e-4f);                        /* Epsilon, single precision */
+        const Float stopValue = stopAfterDensity * 3.0f / (stepSize * S.s.density_scale);
+        p = p + increment;
+        Float m = 4;
+        for (uint32_t i = 1; i < nSteps; ++i) {
+            integratedDensity += m * lookupDensity(p);
+            m = 6 - m;
+            if (integratedDensity > stopValue) return std::numeric_limits<Float>::infinity();
+            Vec next = p + increment;
+            if (p.x == next.x && p.y == next.y && p.z == next.z) break;
+            p = next;
+        }
+        return integratedDensity * S.s.density_scale * stepSize * (1.0f / 3.0f);
+    }
+    inline Float lookupDensity(const Vec &p) { C.c[ORC_C_TENTATIVE]++; return S.density.lookupFloat(p); }   /* :707-717, isotropic */
+    /* heterogeneous.cpp:419-544 */
+    bool invertDensityIntegral(const Vec &o, const Vec &d, Float rayMaxt, Float desiredDensity, Float &integratedDensity, Float &t, Float &densityAtT) {
+        integratedDensity = densityAtT = 0.0f; t = 0.0f;
+        Float mint, maxt;
+        if (!S.density.rayIntersect(o, d, mint, maxt)) return false;
+        mint = std::max(mint, (Float) 0.0f);
+        maxt = std::min(maxt, rayMaxt);
+        Float length = maxt - mint, maxComp = 0;
+        Vec p = o + d * mint, pLast = o + d * maxt;
+        { const Float pc[3] = {p.x, p.y, p.z}, lc[3] = {pLast.x, pLast.y, pLast.z};
+          for (int i = 0; i < 3; ++i) maxComp = std::max(std::max(maxComp, std::abs(pc[i])), std::abs(lc[i])); }
+        if (length < 1e-6f * maxComp) return false;
+        uint32_t nSteps = (uint32_t) std::ceil(length / (2 * S.hetStepSize));
+        Float stepSize = length / nSteps, multiplier = (1.0f / 6.0f) * stepSize * S.s.density_scale;
+        Vec fullStep = d * stepSize, halfStep = fullStep * .5f;
+        Float node1 = lookupDensity(p);
+        for (uint32_t i = 0; i < nSteps; ++i) {
+            Float node2 = lookupDensity(p + halfStep), node3 = lookupDensity(p + fullStep),
+                  newDensity = integratedDensity + multiplier * (node1 + node2 * 4 + node3);
+            if (newDensity >= desiredDensity) {
+                Float a = 0, b = stepSize, x = a, fx = integratedDensity - desiredDensity, stepSizeSqr = stepSize * stepSize,
+                      temp = S.s.density_scale / stepSizeSqr;
+                int it = 1;
+                while (true) {
+                    Float dfx = temp * (node1 * stepSizeSqr - (3 * node1 - 4 * node2 + node3) * stepSize * x + 2 * (node1 - 2 * node2 + node3) * x * x);
+                    x -= fx / dfx;
+                    if (x <= a || x >= b || dfx == 0) x = 0.5f * (b + a);
+                    Float intval = integratedDensity + temp * (1.0f / 6.0f) * (x * (6 * node1 * stepSizeSqr - 3 * (3 * node1 - 4 * node2 + node3) * stepSize * x
+                                   + 4 * (node1 - 2 * node2 + node3) * x * x));
+                    fx = intval - desiredDensity;
+                    if (std::abs(fx) < 1e-6f) {
+                        t = mint + stepSize * i + x;
+                        integratedDensity = intval;
+                        densityAtT = temp * (node1 * stepSizeSqr - (3 * node1 - 4 * node2 + node3) * stepSize * x + 2 * (node1 - 2 * node2 + node3) * x * x);
+                        return true;
+                    } else if (++it > 30) return false;
+                    if (fx > 0) b = x; else a = x;
+                }
+            }
+            Vec next = p + fullStep;
+            if (p.x == next.x && p.y == next.y && p.z == next.z) break;
+            integratedDensity = newDensity;
+            node1 = node3;
+            p = next;
+        }
+        return false;
+    }
+    /* heterogeneous.cpp:589-612: sampleDistance, Simpson branch */
+    bool sampleDistanceSimpson(const Vec &o, const Vec &d, Float rayMaxt, MediumRec &mRec) {
+        mRec.refRatioSq = 1.0f;
+        Float integratedDensity, densityAtT;
+        bool success = false;
+        Float desiredDensity = -std::log(1 - rng.next1D());
+        if (invertDensityIntegral(o, d, rayMaxt, desiredDensity, integratedDensity, mRec.t, densityAtT)) {
+            mRec.p = o + d * mRec.t;
+            success = true;
+            Spec albedo = S.albedoAt(mRec.p);
+            mRec.sigmaS = albedo * densityAtT;
+            mRec.sigmaA = Spec(densityAtT) - mRec.sigmaS;
+        }
+        Float expVal = std::exp(-integratedDensity);
+        mRec.pdfFailure = expVal;
+        mRec.pdfSuccess = expVal * densityAtT;
+        mRec.transmittance = Spec(expVal);
+        success = success && mRec.pdfSuccess > 0;
+        if (success) C.c[ORC_C_REAL]++;
+        return success;
+    }
     /* (a) heterogeneous.cpp:589-663, Woodcock branch */
     bool sampleDistanceWoodcock(const Vec &o, const Vec &d, Float rayMaxt, MediumRec &mRec) {
+        if (S.s.method == 1) return sampleDistanceSimpson(o, d, rayMaxt, mRec);
         mRec.pdfFailure = 1.0f; mRec.pdfSuccess = 1.0f; mRec.transmittance = Spec(1.0f); mRec.refRatioSq = 1.0f;
         Float mint, maxt;
         if (!S.density.rayIntersect(o, d, mint, maxt)) return false;
@@ -1399,6 +1511,7 @@ struct Walker {
     }
     /* heterogeneous.cpp:546-587 (nSamples = 2 binary estimator) + ratio tracking (departure) */
     Spec evalTransmittanceHet(const Vec &o, const Vec &d, Float rayMaxt) {
+        if (S.s.method == 1) return Spec(std::exp(-integrateDensity(o, d, rayMaxt)));       /* :547-548 */
         Float mint, maxt;
         if (!S.density.rayIntersect(o, d, mint, maxt)) return Spec(1.0f);
         mint = std::max(mint, (Float) 0.0f);

@@ -95,6 +95,10 @@ typedef struct {
     /* rif_mode = ORC_RIF_ACOUSTIC (src/volume/acousticrifvolume.cpp:101-106,224-342): n = n_o + n_max J_m(k_r r) cos(m phi) */
     float   ac_n_o, ac_n_max, ac_k_r;
     int32_t ac_mode;
+    /* `method` of the heterogeneous medium (heterogeneous.cpp:195-202): 0 = woodcock, 1 = simpson (composite Simpson quadrature of the
+       density along straight rays: integrateDensity / invertDensityIntegral, :301-544); het_stepsize = its `stepSize`, 0 = inferred from
+       the density grid (0.5 x the smallest voxel extent, gridvolume.cpp:196-198) */
+    int32_t method; float het_stepsize;
 } orc_scene;
 enum { ORC_BSDF_NULL = 0, ORC_BSDF_HDIELECTRIC = 1 };
 

@@ -58,6 +58,7 @@ class Scene(C.Structure):
         ("aggressive_tracing", C.c_int32),
         ("sdf_max_error", C.c_float),
         ("ac_n_o", C.c_float), ("ac_n_max", C.c_float), ("ac_k_r", C.c_float), ("ac_mode", C.c_int32),
+        ("method", C.c_int32), ("het_stepsize", C.c_float),
     ]
 
 
@@ -146,6 +147,7 @@ def make_scene(p):
     s.rif = make_grid(p.rif, p.rif_aabb[0], p.rif_aabb[1], keep, getattr(p, "rif_to_world", None)) if (p.rif is not None and p.rif_mode != 8) else Grid()
     s.ac_n_o, s.ac_n_max, s.ac_k_r, s.ac_mode = (float(getattr(p, "ac_n_o", 1.0)), float(getattr(p, "ac_n_max", 0.0)),
                                                  float(getattr(p, "ac_k_r", 1.0)), int(getattr(p, "ac_mode", 0)))
+    s.method = int(getattr(p, "method", 0)); s.het_stepsize = float(getattr(p, "het_stepsize", 0.0))
     s.sdf = make_grid(p.sdf, p.sdf_aabb[0], p.sdf_aabb[1], keep, getattr(p, "sdf_to_world", None)) if p.sdf is not None else Grid()
     s.stepper, s.stepsize, s.rif_double = p.stepper, p.stepsize, int(getattr(p, "rif_double", 0))
     s.phase, s.g = p.phase, p.g

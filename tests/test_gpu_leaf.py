@@ -151,10 +151,14 @@ def test_er_trace(ctx, orc, stepper, rifkind):
     assert np.abs(np.linalg.norm(ov, axis=1) - nv).max() < 5e-3
 
 
-@pytest.mark.parametrize("mode", ["woodcock", "homogeneous", "homogeneous_maximum", "refractive_maximum", "refractive_homog", "composed_rk4", "composed_verlet"])
+@pytest.mark.parametrize("mode", ["woodcock", "simpson", "simpson_stepsize", "homogeneous", "homogeneous_maximum", "refractive_maximum", "refractive_homog", "composed_rk4", "composed_verlet"])
 def test_sample_distance(ctx, orc, mode):
     if mode == "woodcock":
         p = scenes.straight_scene(N=24)
+    elif mode == "simpson":                              # method = simpson: invertDensityIntegral (heterogeneous.cpp:419-544)
+        p = scenes.straight_scene(N=24, method=P.METHOD_SIMPSON)
+    elif mode == "simpson_stepsize":
+        p = scenes.straight_scene(N=24, method=P.METHOD_SIMPSON, het_stepsize=0.013, albedo_mode=P.ALBEDO_GRID, albedo_grid=scenes.rgb_albedo(24))
     elif mode == "homogeneous":
         p = scenes.homogeneous_scene()
     elif mode == "homogeneous_maximum":                  # strategy = maximum: MaxExpDist (src/medium/maxexp.h)
@@ -180,6 +184,9 @@ def test_sample_distance(ctx, orc, mode):
     assert np.abs(a - b)[ok].max() < 2e-3                        # full record on a medium interaction
     assert np.median(np.abs(a - b)[ok].max(1)) < 1e-5
     fl = same & (a[:, 0] == 0)                                    # failure: only transmittance / pdfs / refRatioSq are defined
+    if mode == "simpson":                                         # pdfSuccess = expVal * densityAtT, sigmaS = albedo * densityAtT (heterogeneous.cpp:600-608)
+        assert 0.2 < a[:, 0].mean() < 0.95
+        np.testing.assert_allclose(a[ok][:, 11], a[ok][:, 12] * a[ok][:, 5] / 0.9, rtol=1e-5)
     assert np.abs(a - b)[fl][:, 8:14].max() < 2e-3
     if p.rif_mode != P.RIF_CONST:                                 # refractive media also report the exit point and momentum
         assert np.abs(a - b)[fl][:, 1:5].max() < 2e-3 and np.abs(a - b)[fl][:, 14:17].max() < 2e-3
@@ -188,6 +195,26 @@ def test_sample_distance(ctx, orc, mode):
 @pytest.mark.parametrize("est", [P.TR_WOODCOCK2, P.TR_RATIO])
 @pytest.mark.parametrize("curved", [False, True])
 def test_eval_transmittance(ctx, orc, est, curved):
+    _eval_transmittance(ctx, orc, dict(tr_estimator=est), curved)
+
+
+def test_eval_transmittance_simpson(ctx, orc):
+    """method = simpson: integrateDensity (heterogeneous.cpp:301-376) -- deterministic, so every ray agrees (libm exp / ulp-level sums)"""
+    p = scenes.straight_scene(N=24, method=P.METHOD_SIMPSON)
+    sc, vols = ctx.upload_scene(p)
+    n = 8192
+    o = scenes.rand_points(n, -1.4, 1.4); d = scenes.rand_dirs(n)
+    maxt = np.random.RandomState(3).uniform(0.0, 3.0, n).astype(np.float32)
+    a = ctx.eval_transmittance(sc, o, d, maxt, 5); b = orc.eval_transmittance(p, o, d, maxt, 5)
+    assert np.abs(a - b).max() < 2e-6 and 0.05 < a.mean() < 0.95
+    dense = p.copy(density_scale=300.0)                              # the early exit (HETVOL_EARLY_EXIT): +inf => exactly 0
+    sc2, vols2 = ctx.upload_scene(dense)
+    a2 = ctx.eval_transmittance(sc2, o, d, maxt, 5); b2 = orc.eval_transmittance(dense, o, d, maxt, 5)
+    assert np.array_equal(a2 == 0, b2 == 0) and (a2 == 0).mean() > 0.2 and np.abs(a2 - b2).max() < 2e-6
+
+
+def _eval_transmittance(ctx, orc, kw, curved):
+    est = kw["tr_estimator"]
     p = scenes.curved_scene(N=24, tr_estimator=est) if curved else scenes.straight_scene(N=24, tr_estimator=est)
     sc, vols = ctx.upload_scene(p)
     n = 8192

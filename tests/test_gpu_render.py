@@ -19,6 +19,10 @@ def _rel_l2(a, b):
 CASES = {
     "cfg2_straight_ratio": lambda: scenes.straight_scene(N=32),
     "cfg2_straight_woodcock2": lambda: scenes.straight_scene(N=32, tr_estimator=P.TR_WOODCOCK2),
+    # method = simpson of the heterogeneous medium: deterministic quadrature for free flights, NEE and look-up transmittance
+    "straight_simpson": lambda: scenes.straight_scene(N=32, method=P.METHOD_SIMPSON),
+    "straight_simpson_point_rgb_albedo": lambda: scenes.straight_scene(N=24, method=P.METHOD_SIMPSON, het_stepsize=0.02, albedo_mode=P.ALBEDO_GRID, albedo_grid=scenes.rgb_albedo(24),
+                                                                      point_position=[0.2, 0.3, -0.1], point_intensity=[1.0, 0.8, 0.5]),
     "cfg1_homogeneous_isotropic": lambda: scenes.homogeneous_scene(),
     "cfg1_homogeneous_single": lambda: scenes.homogeneous_scene(strategy=P.STRATEGY_SINGLE, phase=P.PHASE_HG, g=0.7),
     "cfg1_homogeneous_maximum": lambda: scenes.homogeneous_scene(strategy=P.STRATEGY_MAXIMUM),

@@ -138,6 +138,22 @@ def test_transient_film_and_point_emitter_flatten():
     assert list(d.env_radiance) == [0, 0, 0]
 
 
+def test_heterogeneous_simpson_method_flattens(tmp_path):
+    """`method` / `stepSize` of the heterogeneous medium (src/medium/heterogeneous.cpp:183-202)"""
+    import struct
+    vol = tmp_path / "d.vol"
+    vol.write_bytes(b"VOL\x03" + struct.pack("<5i6f", 1, 4, 4, 4, 1, -1, -1, -1, 1, 1, 1) + np.full(64, 0.5, np.float32).tobytes())
+    body = ('<integrator type="volpath"/>' + CAM + '<medium type="heterogeneous" id="m"><string name="method" value="%s"/><float name="stepSize" value="0.05"/>'
+            '<volume name="density" type="gridvolume"><string name="filename" value="' + str(vol) + '"/></volume>'
+            '<volume name="albedo" type="constvolume"><spectrum name="value" value="0.9"/></volume></medium><shape type="cube"><ref name="interior" id="m"/></shape>')
+    d, _ = host.flatten_xml(_scene(tmp_path, body % "simpson"))
+    assert d.method == P.METHOD_SIMPSON and abs(d.het_stepsize - 0.05) < 1e-7
+    d, _ = host.flatten_xml(_scene(tmp_path, body % "woodcock"))
+    assert d.method == P.METHOD_WOODCOCK
+    with pytest.raises(host.HostError, match="Unsupported integration method"):
+        host.flatten_xml(_scene(tmp_path, body % "trapezoid"))
+
+
 def test_bounce_decomposition_flattens(tmp_path):
     """film `decomposition` = bounce (src/librender/film.cpp:66-68) with minBound / maxBound / binWidth = the bounce orders kept"""
     cam = ('<sensor type="perspective"><film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/><string name="decomposition" value="bounce"/>'

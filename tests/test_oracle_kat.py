@@ -210,6 +210,85 @@ def test_delta_tracking_transmittance_is_unbiased(orc, est):
         assert set(np.unique(tr)).issubset({0.0, 0.5, 1.0})       # binary estimator, nSamples = 2
 
 
+def _ramp_scene(**kw):
+    N = 33
+    ramp = np.broadcast_to((0.5 + 0.25 * np.linspace(-1, 1, N, dtype=np.float32))[None, None, :], (N, N, N)).copy()
+    p = scenes.straight_scene(N=8, **kw)
+    p.density = ramp
+    return p
+
+
+def test_simpson_quadrature_known_answers(orc):
+    """method = simpson (heterogeneous.cpp:301-376): composite Simpson along the ray is exact for a density that is linear along it.
+    sigma_t(x) = 4 (0.5 + 0.25 x): int_{-0.5}^{0.5} = 2, int_{-0.9}^{0.6} over a diagonal-free ray likewise closed form; the early exit
+    (HETVOL_EARLY_EXIT, :336-362) returns +inf => transmittance 0 once the running sum passes -log(Epsilon) * 3 / (stepSize * scale)."""
+    p = _ramp_scene(method=P.METHOD_SIMPSON)
+    o = np.array([[-0.5, 0.1, -0.2], [-0.9, 0.3, 0.4], [-2.0, 0.0, 0.0], [0.0, 0.0, 5.0]], np.float32)
+    d = np.array([[1, 0, 0], [1, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    maxt = np.array([1.0, 1.5, 2.95, 3.0], np.float32)             # (a segment that ends ON the far face would read 0 there: lookupFloat's x2 >= res rule)
+    tr = orc.eval_transmittance(p, o, d, maxt, 3)[:, 0]
+    F = lambda x: 4 * (0.5 * x + 0.125 * x * x)                     # antiderivative of sigma_t
+    exact = [np.exp(-(F(0.5) - F(-0.5))), np.exp(-(F(0.6) - F(-0.9))), np.exp(-(F(0.95) - F(-1.0))), 1.0]
+    np.testing.assert_allclose(tr, exact, rtol=2e-6)
+    # a stepSize of its own changes nothing on a linear density; a dense medium trips the early exit
+    tr2 = orc.eval_transmittance(p.copy(het_stepsize=0.11), o, d, maxt, 3)[:, 0]
+    np.testing.assert_allclose(tr2, exact, rtol=2e-6)
+    assert orc.eval_transmittance(p.copy(density_scale=400.0), o[:1], d[:1], maxt[:1], 3)[0, 0] == 0.0
+
+
+def test_simpson_agrees_with_delta_tracking(orc):
+    """the cross-check SURVEY 7.3 asks for: on a smooth non-linear density the deterministic quadrature and the mean of the ratio-tracking
+    estimator agree within the estimator's Monte-Carlo error (plus the quadrature's own error, < 1e-4 at half-voxel steps)."""
+    p = scenes.straight_scene(N=32)
+    n = 200000
+    o = np.tile(np.array([[-0.8, -0.35, 0.2]], np.float32), (n, 1)); dv = np.array([0.8, 0.5, -0.33]); dv /= np.linalg.norm(dv)
+    d = np.tile(dv.astype(np.float32)[None], (n, 1))
+    mc = orc.eval_transmittance(p.copy(tr_estimator=P.TR_RATIO), o, d, np.full(n, 1.4, np.float32), 7)[:, 0]
+    q = orc.eval_transmittance(p.copy(method=P.METHOD_SIMPSON), o[:1], d[:1], np.full(1, 1.4, np.float32), 7)[0, 0]
+    assert 0.02 < q < 0.98
+    assert abs(mc.mean() - q) < 4 * mc.std() / np.sqrt(n) + 2e-4, (mc.mean(), q)
+
+
+def test_simpson_free_flight_inverts_the_density_integral(orc):
+    """invertDensityIntegral (heterogeneous.cpp:419-544): on constant sigma_t = 2 the sampled distance is -log(1-u)/2 from the box entry for the
+    stream's first float u; pdfSuccess = sigma_t e^{-2t}, pdfFailure = transmittance = e^{-2t}; on the ramp the sampled t solves
+    F(t) - F(t0) = -log(1-u) (the quadratic fit of a linear density is exact) and the success fraction is 1 - exp(-int)."""
+    n = 4096
+    p = scenes.straight_scene(N=8, method=P.METHOD_SIMPSON); p.density = np.full((8, 8, 8), 0.5, np.float32)
+    o = np.tile(np.array([[-1.5, 0.2, 0.1]], np.float32), (n, 1)); d = np.tile(np.array([[1, 0, 0]], np.float32), (n, 1))
+    rec = orc.sample_distance(p, o, d, np.full(n, 2.0, np.float32), 4)
+    u = np.array([orc.rng_floats(4, i, 0, 1)[0] for i in range(n)], np.float64)
+    want = -np.log1p(-u) / 2.0
+    succ = rec[:, 0] == 1
+    assert np.array_equal(succ, want < 1.5 - 1e-6) or abs(succ.mean() - (want < 1.5).mean()) < 2e-3
+    np.testing.assert_allclose(rec[succ, 1], 0.5 + want[succ], rtol=2e-5, atol=2e-6)          # t measured from the ray origin: entry at 0.5
+    np.testing.assert_allclose(rec[succ, 11], 2.0 * np.exp(-2.0 * want[succ]), rtol=1e-4)     # pdfSuccess
+    np.testing.assert_allclose(rec[succ, 12], np.exp(-2.0 * want[succ]), rtol=1e-4)           # pdfFailure
+    np.testing.assert_allclose(rec[succ, 8], np.exp(-2.0 * want[succ]), rtol=1e-4)            # transmittance
+    np.testing.assert_allclose(rec[succ, 5:8], 0.9 * 2.0, rtol=1e-5)                          # sigmaS = albedo * sigma_t
+    np.testing.assert_allclose(rec[~succ, 12], np.exp(-3.0), rtol=1e-5)                       # failure: exp(-whole integral)
+    # ramp: F(t) - F(-0.9) = desired
+    pr = _ramp_scene(method=P.METHOD_SIMPSON)
+    o2 = np.tile(np.array([[-0.9, 0.0, 0.0]], np.float32), (n, 1))
+    rec = orc.sample_distance(pr, o2, d, np.full(n, 1.5, np.float32), 4)
+    succ = rec[:, 0] == 1
+    x = -0.9 + rec[succ, 1].astype(np.float64)
+    F = lambda x: 4 * (0.5 * x + 0.125 * x * x)
+    np.testing.assert_allclose(F(x) - F(-0.9), -np.log1p(-u[succ]), rtol=1e-4, atol=1e-5)
+    assert abs(succ.mean() - (1 - np.exp(-(F(0.6) - F(-0.9))))) < 3e-2
+
+
+def test_simpson_render_agrees_with_woodcock_render(orc):
+    """same scene rendered with method = simpson and with delta tracking: two estimators of one image (means within Monte-Carlo error)"""
+    base = scenes.straight_scene(N=16, w=12, h=10).copy(rfilter=P.FILTER_BOX, rfilter_param=0.5, max_depth=8)
+    a, _ = orc.render(base, 0, 256, 3)
+    b, _ = orc.render(base.copy(method=P.METHOD_SIMPSON), 0, 256, 3)
+    ma, mb = a[..., :3].mean(), b[..., :3].mean()
+    assert abs(ma - mb) < 0.01 * ma, (ma, mb)
+    with pytest.raises(RuntimeError, match="simpson"):
+        orc.render(scenes.curved_scene(N=16, w=4, h=4).copy(method=P.METHOD_SIMPSON), 0, 1, 1)
+
+
 def test_woodcock_collision_density(orc):
     """collisions land with density sigma_t(x) T(x); on constant rho = 0.5, scale 4: exponential, rate 2."""
     p = scenes.straight_scene(N=8)
