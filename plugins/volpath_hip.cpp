@@ -29,6 +29,7 @@
  *     <string name="rif" value="rif.vol"/> <string name="rifType" value="gridvolume|splinevolume"/>
  *     <string name="sdf" value="sdf.vol"/> <float name="stepsize" value="1e-3"/>     <!-- heterogeneousrefractive -->
  *     <string name="stepper" value="verlet|rk4"/> <string name="transmittance" value="woodcock|ratio"/>
+     <string name="method" value="woodcock|simpson"/> <float name="stepSize" value="0"/>   <!-- heterogeneous -->
  *     <transform name="toWorld"> ... </transform>                                    <!-- the volumes' toWorld (gridvolume) -->
      <integer name="device" value="0"/> <string name="rifLayout" value="auto|dense|cell8|brick27"/>
  *   </integrator>
@@ -67,6 +68,8 @@ public:
         m_stepsize = props.getFloat("stepsize", 1e-3f);                                 /* heterogeneousrefractive.cpp:208 */
         m_rk4 = props.getString("stepper", "verlet") == "rk4";
         m_ratio = props.getString("transmittance", "woodcock") == "ratio";
+        m_simpson = props.getString("method", "woodcock") == "simpson";                 /* heterogeneous.cpp:195-202 */
+        m_hetStepSize = props.getFloat("stepSize", 0);
         const std::string l = props.getString("rifLayout", "auto");
         m_layout = l == "auto" ? MER_LAYOUT_AUTO : l == "brick27" ? MER_LAYOUT_BRICK27 : l == "cell8" ? MER_LAYOUT_CELL8 : MER_LAYOUT_DENSE;
         m_seed = (uint64_t) props.getSize("seed", 0);
@@ -79,7 +82,7 @@ public:
         m_densityFile = stream->readString(); m_rifFile = stream->readString(); m_sdfFile = stream->readString();
         m_rifSpline = stream->readBool(); m_scale = stream->readFloat(); m_albedo = Spectrum(stream);
         m_stepsize = stream->readFloat(); m_rk4 = stream->readBool(); m_ratio = stream->readBool(); m_seed = stream->readSize();
-        m_volumeToWorld = Transform(stream);
+        m_volumeToWorld = Transform(stream); m_simpson = stream->readBool(); m_hetStepSize = stream->readFloat();
     }
     void serialize(Stream *stream, InstanceManager *manager) const {
         MonteCarloIntegrator::serialize(stream, manager);
@@ -87,7 +90,7 @@ public:
         stream->writeString(m_densityFile); stream->writeString(m_rifFile); stream->writeString(m_sdfFile);
         stream->writeBool(m_rifSpline); stream->writeFloat(m_scale); m_albedo.serialize(stream);
         stream->writeFloat(m_stepsize); stream->writeBool(m_rk4); stream->writeBool(m_ratio); stream->writeSize((size_t) m_seed);
-        m_volumeToWorld.serialize(stream);
+        m_volumeToWorld.serialize(stream); stream->writeBool(m_simpson); stream->writeFloat(m_hetStepSize);
     }
 
     bool render(Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID, int samplerResID) {
@@ -247,6 +250,7 @@ private:
         d.tr_estimator = m_ratio ? MER_TR_RATIO : MER_TR_WOODCOCK2;
         d.stepper = m_rk4 ? MER_STEP_RK4 : MER_STEP_VERLET;
         d.stepsize = m_stepsize;
+        d.method = m_simpson ? MER_METHOD_SIMPSON : MER_METHOD_WOODCOCK; d.het_stepsize = m_hetStepSize;
         d.rif_const = 1.0f;
         if (cls == "HomogeneousMedium") {
             d.sigma_mode = MER_SIGMA_HOMOGENEOUS; d.rif_mode = MER_RIF_CONST;
@@ -276,8 +280,8 @@ private:
 
     int m_device, m_layout;
     std::string m_densityFile, m_rifFile, m_sdfFile;
-    bool m_rifSpline, m_rk4, m_ratio;
-    Float m_scale, m_stepsize;
+    bool m_rifSpline, m_rk4, m_ratio, m_simpson;
+    Float m_scale, m_stepsize, m_hetStepSize;
     Spectrum m_albedo;
     Transform m_volumeToWorld;
     uint64_t m_seed;

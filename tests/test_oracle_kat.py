@@ -210,6 +210,23 @@ def test_delta_tracking_transmittance_is_unbiased(orc, est):
         assert set(np.unique(tr)).issubset({0.0, 0.5, 1.0})       # binary estimator, nSamples = 2
 
 
+@pytest.mark.parametrize("stepper", [P.STEP_VERLET, P.STEP_RK4])
+@pytest.mark.parametrize("rifkind", ["trilinear", "bspline"])
+def test_fp32_trace_stays_within_the_stated_tolerance_of_fp64(orc, stepper, rifkind):
+    """D6: `FLOAT` is double in one reference configuration and float in the other.  The oracle's fp32 trace against its fp64 trace at the
+    reference's default step h = 1e-3 (up to 1000 steps): position 6e-5, momentum 2e-4, optical length 5e-5 -- the tolerance the GPU (fp32)
+    is held to against the fp64 oracle in tests/test_gpu_leaf.py."""
+    mk = scenes.curved_scene if rifkind == "trilinear" else scenes.bspline_scene
+    p = mk(N=24, stepper=stepper, stepsize=1e-3)
+    n = 1024
+    p0 = scenes.rand_points(n, -0.45, 0.45); d0 = scenes.rand_dirs(n)
+    dist = np.random.RandomState(2).uniform(0.2, 1.0, n).astype(np.float32)
+    a = orc.er_trace(p, p0, d0, dist); b = orc.er_trace(p.copy(rif_double=1), p0, d0, dist)
+    same = (a[4] == b[4]) & (a[4] == 1)
+    assert (a[4] == b[4]).mean() > 0.999 and same.mean() > 0.6
+    assert np.abs(a[0] - b[0])[same].max() < 6e-5 and np.abs(a[1] - b[1])[same].max() < 2e-4 and np.abs(a[3] - b[3])[same].max() < 5e-5
+
+
 def _ramp_scene(**kw):
     N = 33
     ramp = np.broadcast_to((0.5 + 0.25 * np.linspace(-1, 1, N, dtype=np.float32))[None, None, :], (N, N, N)).copy()
