@@ -288,7 +288,7 @@ def main():
     counters = ctx.counters().astype(np.float64)
     # one more step OUTSIDE the timed region as a single pipeline: per-launch figures of the dominant kernel
     solo = None
-    if not args.no_solo_step and world == 1:
+    if not args.no_solo_step:             # every rank (N > 1: rank 0's block is printed; the others keep the GPUs in step until the next collective)
         with ctx.options(pipes=1):
             ctx.counters_reset()
             mer_sh = mdist.shard_args("samples", 0, 1, args.spp)
