@@ -175,6 +175,7 @@ int  mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu
      buffer_loads   0 = read fields with global loads even below 4 GiB, i.e. run the kernels a >= 4 GiB field selects (default 1)
      gen_all        K_gen hands every camera sample to K_event (A/B, default 0)
      prefilter      K_prefilter form: 0 register windows (default), 1 one thread per line, 2 two kernels per axis, 3 strided x, 4 LDS x
+     march_lds_kb   KiB of unused dynamic LDS requested per K_march block: an occupancy cap for A/B runs (33 -> 4 blocks per CU, 41 -> 3; default 0)
      verbose, debug_pixel */
 int  mer_context_set_option(mer_context *ctx, const char *name, int64_t value);
 int  mer_context_get_option(mer_context *ctx, const char *name, int64_t *value);

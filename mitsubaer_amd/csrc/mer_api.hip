@@ -389,7 +389,7 @@ static int64_t *option_slot(mer_context *ctx, const char *name) {
     const struct { const char *n; int64_t *p; } table[] = {
         {"pipes", &o.pipes}, {"nslots", &o.nslots}, {"ksteps", &o.ksteps}, {"mq_sort", &o.mq_sort}, {"connect_launches", &o.connect_launches},
         {"adaptive_k", &o.adaptive_k}, {"pass_events", &o.pass_events}, {"buffer_loads", &o.buffer_loads}, {"gen_all", &o.gen_all},
-        {"prefilter", &o.prefilter}, {"verbose", &o.verbose}, {"debug_pixel", &o.debug_pixel}, {"lds_bricks", &o.lds_bricks}};
+        {"prefilter", &o.prefilter}, {"verbose", &o.verbose}, {"debug_pixel", &o.debug_pixel}, {"lds_bricks", &o.lds_bricks}, {"march_lds_kb", &o.march_lds_kb}};
     for (const auto &t : table) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }

@@ -49,6 +49,7 @@ struct Options {
     int64_t prefilter = 0;        // K_prefilter form: 0 register windows, 1 one thread per line, 2 two kernels per axis, 3 strided x pass, 4 LDS x pass
     int64_t verbose = 0;
     int64_t debug_pixel = -1;
+    int64_t march_lds_kb = 0;     // KiB of (unused) dynamic LDS per K_march block: caps its occupancy (160 KiB per CU; 33 -> 4 blocks, 41 -> 3) for A/B runs
     int64_t lds_bricks = 0;       // K_march keeps every lane's current BRICK27 record in LDS (BRICK27 below 4 GiB only; measured slower)
 };
 

@@ -176,7 +176,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
                 R.P.cq_row++;
             }
             if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 1], pp.stream));
-            hipLaunchKernelGGL(ks.march, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+            hipLaunchKernelGGL(ks.march, dim3(R.blocks), dim3(MER_BLOCK), (size_t) opt.march_lds_kb * 1024, pp.stream, R.P, pass);   // dynamic LDS: an occupancy cap for A/B runs
             if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 2], pp.stream));
             R.pass++;
         }
