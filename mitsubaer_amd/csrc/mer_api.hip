@@ -238,7 +238,16 @@ int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bool allo
     P.inv_res_x = 1.0f / sc->width; P.inv_res_y = 1.0f / sc->height;
     if (sc->rfilter != MER_FILTER_BOX && sc->rfilter != MER_FILTER_GAUSSIAN) return fail(ctx, "unknown reconstruction filter");
     if (!(sc->rfilter_param > 0)) return fail(ctx, "reconstruction filter radius/stddev must be positive");
-    filter_table(sc->rfilter, sc->rfilter_param, P.fvalues, P.fradius, P.fscale);
+    {   // the table goes to device memory once per (kind, parameter); no kernel of this context is in flight here (renders and leaf calls return synchronised)
+        float fv[33];
+        filter_table(sc->rfilter, sc->rfilter_param, fv, P.fradius, P.fscale);
+        if (!ctx->ftable) HIP_CHECK(ctx, hipMalloc((void **) &ctx->ftable, sizeof(fv)));
+        if (ctx->ftable_kind != sc->rfilter || ctx->ftable_param != sc->rfilter_param) {
+            HIP_CHECK(ctx, hipMemcpy(ctx->ftable, fv, sizeof(fv), hipMemcpyHostToDevice));
+            ctx->ftable_kind = sc->rfilter; ctx->ftable_param = sc->rfilter_param;
+        }
+        P.ftable = ctx->ftable;
+    }
     if (P.fradius > 7.0f) return fail(ctx, "reconstruction filter radius too large");
     if (sc->boundary_bsdf != MER_BSDF_NULL && sc->boundary_bsdf != MER_BSDF_HDIELECTRIC) return fail(ctx, "boundary BSDF must be null or hdielectric");
     if (film_frames(ctx, sc, P.frames)) return 1;
@@ -433,6 +442,7 @@ void mer_context_destroy(mer_context *ctx) {
         if (kv.second.coeff) (void) hipFree(kv.second.coeff);
     }
     if (ctx->counters) (void) hipFree(ctx->counters);
+    if (ctx->ftable) (void) hipFree(ctx->ftable);
     if (ctx->chk) (void) hipFree(ctx->chk);
     for (Pipe &pp : ctx->pipes) {
         if (pp.slots) (void) hipFree(pp.slots);

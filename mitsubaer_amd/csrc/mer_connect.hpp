@@ -373,7 +373,7 @@ template <int RIF, int BND = 0, bool XC = true> struct Connector {
         S.phase = CP_EVAL0;
     }
     // one traced ray of the connection p1 -> p2, and the algebra up to the next one.  S.phase = CP_NEW and S.weight set by the caller.
-    __device__ void unit(ConnState &S, f3 p1, f3 p2, Rng &rng, f3 &revDir) const {
+    __device__ __forceinline__ void unit(ConnState &S, f3 p1, f3 p2, Rng &rng, f3 &revDir) const {
         if (S.phase == CP_NEW) {
             S.iterations = 1; S.tempSol = f3(0, 0, 0); S.dir = f3(0, 0, 1); S.optDist = 0; S.dist = 0; S.it = 0; S.tries = 0; S.ok = 0;
             S.cost = 0; S.lambda = 0; S.radius = 0; S.e = f3(0, 0, 0); S.xn = f3(0, 0, 0); S.J = m33(0.0f);
@@ -482,7 +482,7 @@ template <int RIF, int BND = 0, bool XC = true> struct Connector {
 // Medium::eval through the RIF (curved rays, heterogeneousrefractive.cpp:571-640).  Returns value * phase (to be
 // multiplied by the path throughput).  Synchronous: it runs inside K_event.
 template <bool CURVED, int RIF, int STEPPER, int SIGMA, int BND = 0>
-__device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi, int depth, float &optLen) {
+__device__ __forceinline__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi, int depth, float &optLen) {   // inlined: an out-of-line callee taking Params by reference forces a scratch copy of the kernel arguments
     optLen = 0.0f;
     const mer_scene_desc &S = P.sc;
     const f3 I(S.point_intensity[0], S.point_intensity[1], S.point_intensity[2]);
@@ -534,7 +534,7 @@ __device__ f3 point_nee(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi
 // path throughput): I / |pp - ps|^2 (the straight-line distance of PointEmitter::sampleDirect, which the reference keeps for curved
 // connections) x transmittance along the connecting ray (arc length dist, launched along dir) x solver weight x phase function.
 template <int RIF, int STEPPER, int SIGMA, int BND = 0>
-__device__ f3 connection_value(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi, f3 dir, float dist, float w) {
+__device__ __forceinline__ f3 connection_value(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 wi, f3 dir, float dist, float w) {
     const mer_scene_desc &S = P.sc;
     const f3 I(S.point_intensity[0], S.point_intensity[1], S.point_intensity[2]);
     const f3 pp(S.point_position[0], S.point_position[1], S.point_position[2]);

@@ -560,6 +560,15 @@ struct SegQueue {
     unsigned long long *chk;  // MER_BOUNDS_CHECK: violation record (NULL in the product build)
 };
 
+// One of a pair of ping-pong queues, by value.  Written with constant indices and a select: `P.cq[row & 1]` makes the compiler copy the
+// whole 2.3 KB kernel-argument struct into per-lane scratch at kernel entry (the address of a kernarg member indexed by a run-time
+// value), and every later read of a Params field in that kernel then becomes a scratch load.
+__device__ __forceinline__ SegQueue pick_queue(const SegQueue (&q)[2], uint32_t row) {
+    SegQueue r = q[0]; const SegQueue b = q[1];
+    if (row & 1u) r = b;
+    return r;
+}
+
 // MaxExpDist (src/medium/maxexp.h:28-98): the distance distribution proportional to max_i sigma_i exp(-sigma_i t) over the three
 // channels (`strategy = maximum` of homogeneous / heterogeneousrefractive).  Tables built on the host (mer_api.hip) as :30-58.
 struct MaxExp {
@@ -590,7 +599,9 @@ struct Params {
     float inv_max_density;
     float het_step;               // method = simpson: the heterogeneous medium's stepSize (given, or inferred from the grids)
     float cam[12], aspect, cot_half_fov, inv_res_x, inv_res_y;
-    float fvalues[33], fradius, fscale;
+    const float *ftable;                // reconstruction-filter table, 33 floats in device memory: a table INSIDE this struct, indexed per lane, makes the
+                                        // compiler copy the whole 2.3 KB kernel-argument struct into scratch (K_connect, the EXTRA K_event)
+    float fradius, fscale;
     // work
     uint64_t seed;
     int32_t spp_begin, spp_count, spp_stride, tile_rank, tile_count;
@@ -835,9 +846,9 @@ __device__ __forceinline__ void film_splat(const Params &P, float px, float py, 
     const int minx = max((int) ceilf(posx - r), 0), miny = max((int) ceilf(posy - r), 0),
               maxx = min((int) floorf(posx + r), W - 1), maxy = min((int) floorf(posy + r), H - 1);
     for (int y = miny; y <= maxy; ++y) {
-        const float wy = P.fvalues[min((int) fabsf(((float) y - posy) * P.fscale), 31)];   // rfilter.h:76-77
+        const float wy = P.ftable[min((int) fabsf(((float) y - posy) * P.fscale), 31)];   // rfilter.h:76-77
         for (int x = minx; x <= maxx; ++x) {
-            const float wx = P.fvalues[min((int) fabsf(((float) x - posx) * P.fscale), 31)];
+            const float wx = P.ftable[min((int) fabsf(((float) x - posx) * P.fscale), 31)];
             const float weight = wx * wy;
             float *dest = P.film + MER_CHK(P.chk, CHK_FILM, ((size_t) y * W + x) * P.film_ch, P.n_film - (uint32_t) P.film_ch + 1u);
             if (what & 1) {
@@ -853,8 +864,12 @@ __device__ __forceinline__ void film_put(const Params &P, float px, float py, f3
 }
 // PathLengthSampler::mSeq / correlationFunction (include/mitsuba/render/pathlengthsampler.h:32-42,
 // src/librender/pathlengthsampler.cpp:68-114), float / double mix as written there
-__device__ __forceinline__ float mseq(const Params &P, float t, float phase) {
-    const float lambda = P.sc.mod_lambda; const int mP = P.sc.mod_P;
+// The function is out of line (inlined at every contribution site it bloats K_event), so it takes what it needs BY VALUE: a reference to
+// the kernel-argument struct handed to an out-of-line function forces the compiler to copy the whole 2.3 KB struct into per-lane scratch at
+// kernel entry and to read every Params field from scratch afterwards (K_connect and the EXTRA K_event carried 2.3 KB of scratch for it).
+struct ModDesc { int modulation, mP, neighbors; float lambda, phase; };
+__device__ __forceinline__ ModDesc mod_desc(const Params &P) { return ModDesc{P.sc.modulation, P.sc.mod_P, P.sc.mod_neighbors, P.sc.mod_lambda, P.mod_phase}; }
+__device__ __forceinline__ float mseq(float lambda, int mP, float t, float phase) {
     float pathLength = t;
     pathLength = pathLength + phase * lambda * MER_INV_PI / 2;
     pathLength = fmodf(pathLength, lambda);
@@ -862,10 +877,10 @@ __device__ __forceinline__ float mseq(const Params &P, float t, float phase) {
     else if (pathLength > (1 - 1.0 / mP) * lambda) return 1 - (lambda - pathLength) * (mP - 1) / lambda;
     else return (float) (1.0 / mP);
 }
-static __device__ __noinline__ float correlation_function(const Params &P, float t) {
-    const float lambda = P.sc.mod_lambda, modPhase = P.mod_phase;
+static __device__ __noinline__ float correlation_function(const ModDesc m, float t) {
+    const float lambda = m.lambda, modPhase = m.phase;
     float pathLength = t;
-    switch (P.sc.modulation) {
+    switch (m.modulation) {
     case MER_MODULATION_SINE: pathLength = pathLength + modPhase * lambda * MER_INV_PI / 2; return (float) cos(pathLength * 2 * M_PI / lambda);
     case MER_MODULATION_SQUARE: pathLength = pathLength + modPhase * lambda * MER_INV_PI / 2;
         return 4 / lambda * (fabsf(fmodf(pathLength, lambda) - lambda / 2) - lambda / 4);
@@ -875,10 +890,10 @@ static __device__ __noinline__ float correlation_function(const Params &P, float
         else if (pathLength < lambda / 2 && pathLength >= lambda / 6) return 1.0f;
         else if (pathLength < 2 * lambda / 3 && pathLength >= lambda / 2) return 1 - (pathLength - lambda / 2) * 6 / lambda;
         else return 0;
-    case MER_MODULATION_MSEQ: return mseq(P, pathLength, modPhase);
+    case MER_MODULATION_MSEQ: return mseq(lambda, m.mP, pathLength, modPhase);
     case MER_MODULATION_DEPTHSELECTIVE: { float value = 0;
-        for (int i = 0; i < P.sc.mod_neighbors; i++) value += mseq(P, pathLength, (float) (modPhase - i * (2 * M_PI) / P.sc.mod_P));
-        value -= (float) (P.sc.mod_neighbors - 1) / P.sc.mod_P;
+        for (int i = 0; i < m.neighbors; i++) value += mseq(lambda, m.mP, pathLength, (float) (modPhase - i * (2 * M_PI) / m.mP));
+        value -= (float) (m.neighbors - 1) / m.mP;
         return value; }
     }
     return 1.0f;
@@ -889,7 +904,7 @@ static __device__ __noinline__ float correlation_function(const Params &P, float
 template <bool MOD>
 __device__ __forceinline__ f3 mod_weight(const Params &P, f3 value, float pathLength) {
     if (!MOD) return value;
-    return P.sc.modulation ? value * correlation_function(P, pathLength) : value;
+    return P.sc.modulation ? value * correlation_function(mod_desc(P), pathLength) : value;
 }
 // Transient film: one radiance contribution binned by its optical path length (bdpt_proc.cpp:449-470)
 __device__ __forceinline__ void film_contribute(const Params &P, float px, float py, f3 value, float pathLength) {

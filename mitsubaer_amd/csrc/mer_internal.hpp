@@ -62,6 +62,7 @@ struct mer_context {
     std::map<int, mer::Volume> volumes;
     int next_handle = 1;
     unsigned long long *counters = nullptr;      // MER_C_COUNT x replicas + work counter
+    float *ftable = nullptr; int ftable_kind = -1; float ftable_param = 0;   // reconstruction-filter table on the device (33 floats) and what it holds
     unsigned long long *chk = nullptr;           // MER_BOUNDS_CHECK build: violation record (count, kind, index, limit)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;

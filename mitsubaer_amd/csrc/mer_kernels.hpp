@@ -149,7 +149,7 @@ __global__ void camera_rays_kernel(const Params P, const float *pos2, int64_t n,
 __global__ void correlation_kernel(const Params P, const float *t, int64_t n, float *out) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = correlation_function(P, t[i]);
+    out[i] = correlation_function(mod_desc(P), t[i]);
 }
 __global__ void rng_kernel(uint64_t seed, uint32_t pixel, uint32_t sample, int n, float *out) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;

@@ -1,0 +1,8 @@
+#!/bin/bash
+for lib in libmer.so libmer_e2.so; do
+echo "== $lib"
+MER_LIB=$PWD/mitsubaer_amd/$lib python bench.py --workload cfg5 --spp 128 --steps 2 --warmup 1 --no-cpu-baseline --no-target-512 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('cfg5 value %.1f Mpaths/s  ms %.1f' % (d['value'], d['ms_per_step']))"
+done
