@@ -560,7 +560,7 @@ struct SegQueue {
     unsigned long long *chk;  // MER_BOUNDS_CHECK: violation record (NULL in the product build)
 };
 
-// One of a pair of ping-pong queues, by value.  Written with constant indices and a select: `P.cq[row & 1]` makes the compiler copy the
+// One of a pair of ping-pong queues, by value (K_connect / the EXTRA K_event, whose kernel arguments must stay out of scratch).  Written with constant indices and a select: an address-taken `P.cq[row & 1]` can make the compiler copy the
 // whole 2.3 KB kernel-argument struct into per-lane scratch at kernel entry (the address of a kernarg member indexed by a run-time
 // value), and every later read of a Params field in that kernel then becomes a scratch load.
 __device__ __forceinline__ SegQueue pick_queue(const SegQueue (&q)[2], uint32_t row) {

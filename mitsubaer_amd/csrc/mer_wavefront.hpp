@@ -277,12 +277,12 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
     // while K_march runs, so this is the race-free place to clamp the head before K_gen produces again
     if (j == 0) { const unsigned long long t = P.hitq_ctr[0], h = P.hitq_ctr[MER_HITQ_HEAD]; if (h > t) P.hitq_ctr[MER_HITQ_HEAD] = t; }
     // sweep the compacted list of marching slots: dense waves in the steady state and in the tail alike
-    const uint32_t count = queue_total(pick_queue(P.mq, pass), pass);
+    const uint32_t count = queue_total(P.mq[pass & 1u], pass);
     LaneCounters C; C.clear();
     uint32_t iters = 0, i = 0;
     bool has_event = false, still_marching = false; int ev_class = 0, mq_class = 0;
     if (j < count) {
-        i = queue_item(pick_queue(P.mq, pass), pass, j);
+        i = queue_item(P.mq[pass & 1u], pass, j);
         uint32_t fl;
         Walk<CURVED, RIF, STEPPER, SIGMA, BND> W;
         Rng rng; uint32_t pixel, sample; float sigma;
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
     }
     // compaction: lanes parked on an event go to K_event's queue (by class), the others straight to the next march list
     queue_push_class<MER_EV_CLASSES>(P.eq, pass + 1, has_event, i, ev_class);
-    queue_push_class<MER_MQ_CLASSES>(pick_queue(P.mq, pass + 1), pass + 1, still_marching, i, mq_class);
+    queue_push_class<MER_MQ_CLASSES>(P.mq[(pass + 1) & 1u], pass + 1, still_marching, i, mq_class);
     // lane-slot accounting: every lane of the wave is held for as many trips as its slowest lane
     uint32_t wave_iters = iters;
 #pragma unroll
@@ -347,14 +347,14 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
     if (j >= P.nslots) return;
     // pass 0: every slot is new; later passes: the compacted list of slots K_march parked on an event
     const uint32_t nq = pass == 0 ? P.nslots : queue_total(P.eq, pass);
-    const uint32_t ns = pass == 0 ? 0u : queue_total(pick_queue(P.sq, pass), pass);      // slots left without work last pass
+    const uint32_t ns = pass == 0 ? 0u : queue_total(P.sq[pass & 1u], pass);      // slots left without work last pass
     const uint32_t count = nq + ns;
     // ring hygiene: the rows K_march / K_event of pass+1 will add to
-    queue_clear_row(P.eq, pass + 2, j); queue_clear_row(pick_queue(P.mq, pass), pass + 2, j); queue_clear_row(pick_queue(P.sq, pass), pass + 2, j);
+    queue_clear_row(P.eq, pass + 2, j); queue_clear_row(P.mq[pass & 1u], pass + 2, j); queue_clear_row(P.sq[pass & 1u], pass + 2, j);
     LaneCounters C; C.clear();
     bool marching = false, starved_out = false, connecting = false; uint32_t i = 0; int mq_class = 0, cq_class = 0;
     if (j < count) {
-    i = pass == 0 ? j : (j < nq ? queue_item(P.eq, pass, j) : queue_item(pick_queue(P.sq, pass), pass, j - nq));
+    i = pass == 0 ? j : (j < nq ? queue_item(P.eq, pass, j) : queue_item(P.sq[pass & 1u], pass, j - nq));
     const uint32_t fl = SLOT(H_FLAGS);
     int st = fl & 3u, ev = (fl >> 2) & 15u;
 
@@ -662,8 +662,8 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
     }   // j < count
     // a new connection joins the pending ones of the next K_connect launch, grouped by the length of the rays its solver will trace
     if (EXTRA && CURVED) queue_push_class<MER_CQ_CLASSES>(pick_queue(P.cq, P.cq_row), P.cq_row, connecting, i, cq_class);
-    queue_push_class<MER_MQ_CLASSES>(pick_queue(P.mq, pass), pass, marching, i, mq_class);
-    queue_push(pick_queue(P.sq, pass + 1), pass + 1, starved_out, i);
+    queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class);
+    queue_push(P.sq[(pass + 1) & 1u], pass + 1, starved_out, i);
     flush_counters(P, C, 0);
 }
 
