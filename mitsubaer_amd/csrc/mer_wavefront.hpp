@@ -180,7 +180,9 @@ __device__ __forceinline__ void queue_push(const SegQueue &q, uint32_t row, bool
 //    the lanes of a wave park at about the same trip of K_march's loop instead of idling until the slowest one has.
 #define MER_EV_CLASSES 4
 #define MER_MQ_CLASSES 8
-#define MER_CQ_CLASSES 8
+#ifndef MER_CQ_CLASSES
+#define MER_CQ_CLASSES 16        // 8 / 16 / 32 classes: configs[4] 27.7 / 28.5 / 28.4 Mpaths/s (profiles/round2/ab_connect_waves.txt)
+#endif
 // class of a pending connection: the length of the rays its solver traces (the chord to the emitter over the size of the shape), longest first
 __device__ __forceinline__ int connect_class(const Params &P, f3 ps) {
     const mer_scene_desc &S = P.sc;
