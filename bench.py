@@ -306,6 +306,8 @@ def main():
     if rank == 0:
         name, cus, hbm = ctx.device_info()
         pipes = ctx.get_option("pipes")
+        slots = ctx.get_option("nslots") or cus * 2048 * 4              # the library's default: 4 x the resident lanes of the chip
+        tile_share = sh["tile_count"]
         tag = workload_tag(args.workload, args.res, args.size)
         out = {
             "metric": "Mpaths/sec (curved-ray heterogeneous volume); roofline = measured HBM GB/s of the dominant kernel vs peak",
@@ -317,7 +319,10 @@ def main():
                        "spp_job": spp_job, "spp_per_gpu": args.spp if args.scaling == "weak" else None,
                        "pipelines_per_gpu": pipes, "stepper": "rk4", "rif_interp": "trilinear", "layout": args.layout, "shard": shard_mode,
                        "stepsize": p.stepsize, "estimator": "volpath + delta tracking on eikonal rays, ratio-tracking NEE",
-                       "device": name, "cus": cus, "backend": (args.backend or "nccl") if world > 1 else None},
+                       "device": name, "cus": cus, "backend": (args.backend or "nccl") if world > 1 else None,
+                       # paths of one rank's step per path-state slot: below ~4 the render is one generation of paths and its time is the tail of the
+                       # longest paths, not the steady rate (configs[3] at 8 spp: 4; at 128 spp: 64)
+                       "paths_per_slot": round(p.width * p.height * sh["spp_count"] / max(tile_share, 1) / max(slots, 1), 2)},
             "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": per_rank_ms,
             # device counters of rank 0, per step of the timed region (inputs of SURVEY section 8d's byte formula)
             "counters_per_step": {"paths": counters[capi.C_PATHS] / max(args.steps, 1), "eikonal_steps": counters[capi.C_STEPS] / max(args.steps, 1),
