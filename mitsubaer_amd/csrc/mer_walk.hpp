@@ -111,7 +111,7 @@ struct Walk {
     float n0;                    // refStart (heterogeneousrefractive.cpp:468)
     float rem;                   // remainder step of the current trace()
     int   steps_left;            // full steps left; -1 => remainder taken; INT_MAX/1e5 for traceTillBoundary
-    int   seg_inf;               // traceTillBoundary (int: see render_kernel flags note)
+    int   seg_inf;               // traceTillBoundary (int, not bool: bool flags living across big loops were corrupted under SGPR pressure, DESIGN.md section 4 compiler note 1)
     float dist;                  // distSurf accumulated (curved) / sampled distance (homogeneous)
     float opt;                   // optical length
     float sdens;                 // sampling density chosen by the strategy (homogeneous)
