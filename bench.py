@@ -278,13 +278,15 @@ def main():
     elapsed = time.perf_counter() - t0
     tl = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     per_rank_ms = [elapsed / max(args.steps, 1) * 1e3]
-    rccl_ranks = 1
+    # ranks that joined the RCCL communicator (backend "nccl" is RCCL on ROCm); null under any other backend -- a gloo rehearsal says so
+    backend_used = torch.distributed.get_backend() if world > 1 else None
+    rccl_ranks = None
     if world > 1:
         gathered = [torch.zeros_like(tl) for _ in range(world)]
         torch.distributed.all_gather(gathered, tl)
         per_rank_ms = [float(g.item()) / max(args.steps, 1) * 1e3 for g in gathered]
         elapsed = max(float(g.item()) for g in gathered)                  # MAX over ranks
-        rccl_ranks = torch.distributed.get_world_size()
+        rccl_ranks = torch.distributed.get_world_size() if backend_used == "nccl" else None
     counters = ctx.counters().astype(np.float64)
     # one more step OUTSIDE the timed region as a single pipeline: per-launch figures of the dominant kernel
     solo = None
@@ -314,12 +316,12 @@ def main():
             "value": total_paths / elapsed / 1e6, "unit": "Mpaths/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "backend": backend_used,
             "config": {"workload": desc, "grid": args.res, "film": [p.width, p.height],
                        "spp_job": spp_job, "spp_per_gpu": args.spp if args.scaling == "weak" else None,
                        "pipelines_per_gpu": pipes, "stepper": "rk4", "rif_interp": "trilinear", "layout": args.layout, "shard": shard_mode,
                        "stepsize": p.stepsize, "estimator": "volpath + delta tracking on eikonal rays, ratio-tracking NEE",
-                       "device": name, "cus": cus, "backend": (args.backend or "nccl") if world > 1 else None,
+                       "device": name, "cus": cus, "backend": backend_used,
                        # paths of one rank's step per path-state slot: below ~4 the render is one generation of paths and its time is the tail of the
                        # longest paths, not the steady rate (configs[3] at 8 spp: 4; at 128 spp: 64)
                        "paths_per_slot": round(p.width * p.height * sh["spp_count"] / max(tile_share, 1) / max(slots, 1), 2)},

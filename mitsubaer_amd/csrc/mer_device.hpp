@@ -606,6 +606,7 @@ struct Params {
     uint64_t seed;
     int32_t spp_begin, spp_count, spp_stride, tile_rank, tile_count;
     int32_t tiles_x, tiles_y, ntiles_mine;
+    int32_t tile_skew;                  // tile dealing: row ty of the tile grid is rotated by tile_skew * ty columns before the round-robin deal (0 = plain)
     uint64_t total_work;
     float *film;                        // float[H][W][film_ch]: RGB per frame, alpha, weight
     int32_t frames, film_ch;            // frames = 1 and film_ch = 5 in steady state
@@ -918,6 +919,12 @@ __device__ __forceinline__ void film_contribute(const Params &P, float px, float
 // Work decode: w -> (pixel, sample).  Sample-major; inside a pass pixels go by 32x32 image tiles (the
 // reference's block size, src/mitsuba/mitsuba.cpp:80-81) and by 8x8 sub-tiles so that the 64 lanes of a
 // fresh wavefront start on one 8x8 pixel patch (coherent camera rays, distinct film pixels per lane).
+// Tile dealing (mer_shard.tile_rank / tile_count): the tiles are dealt round-robin in row-major order AFTER row ty has been
+// rotated by tile_skew * ty columns.  A plain deal hands rank r whole tile COLUMNS whenever tile_count divides tiles_x (16 or 32
+// columns, 8 ranks): the columns through the medium carry all the work, the outer ones none (measured: profiles/round3/
+// shard_balance_*.txt).  With the rotation (a skew coprime to tiles_x) a rank's tiles lie on diagonals and visit every column
+// and every row equally often -- the role of the reference's spiral block order (src/librender/renderproc.cpp:79).  A
+// permutation inside each row: the shards still partition the tiles exactly.
 #define MER_TILE 32
 __device__ __forceinline__ bool decode_work(const Params &P, uint64_t w, int &x, int &y, uint32_t &sample) {
     const uint32_t npix = (uint32_t) P.ntiles_mine * (MER_TILE * MER_TILE);
@@ -925,7 +932,7 @@ __device__ __forceinline__ bool decode_work(const Params &P, uint64_t w, int &x,
     const uint32_t r = (uint32_t) (w - (uint64_t) s_local * npix);
     const uint32_t tile_local = r >> 10, q = r & 1023u, sub = q >> 6, lane = q & 63u;
     const uint32_t tile = (uint32_t) P.tile_rank + tile_local * (uint32_t) P.tile_count;
-    const uint32_t tx = tile % (uint32_t) P.tiles_x, ty = tile / (uint32_t) P.tiles_x;
+    const uint32_t ty = tile / (uint32_t) P.tiles_x, tx = (tile - ty * (uint32_t) P.tiles_x + (uint32_t) P.tile_skew * ty) % (uint32_t) P.tiles_x;
     x = (int) (tx * MER_TILE + (sub & 3u) * 8u + (lane & 7u));
     y = (int) (ty * MER_TILE + (sub >> 2) * 8u + (lane >> 3));
     sample = (uint32_t) P.spp_begin + s_local * (uint32_t) P.spp_stride;

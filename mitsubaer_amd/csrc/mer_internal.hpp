@@ -50,6 +50,8 @@ struct Options {
     int64_t verbose = 0;
     int64_t debug_pixel = -1;
     int64_t march_lds_kb = 0;     // KiB of (unused) dynamic LDS per K_march block: caps its occupancy (160 KiB per CU; 33 -> 4 blocks, 41 -> 3) for A/B runs
+    int64_t tile_deal = 1;        // tile shards dealt on diagonals (1, default) or in plain row-major round robin (0): decode_work
+    int64_t small_render_slots = 1;   // a render with few paths per slot uses fewer slots / pipelines, so that the wavefront stays full while it drains
     int64_t lds_bricks = 0;       // K_march keeps every lane's current BRICK27 record in LDS (BRICK27 below 4 GiB only; measured slower)
 };
 
@@ -112,6 +114,7 @@ bool kernels_cell8(int rifk, int stepper, int sigma, bool extra, KernelSet &k);
 bool kernels_brick(int rifk, int stepper, int sigma, bool extra, KernelSet &k);
 bool kernels_bspline(int stepper, int sigma, bool extra, KernelSet &k);
 bool kernels_sdf_curved(int rifk, int stepper, int sigma, KernelSet &k);
+int tile_skew_for(int tiles_x, int tile_count, int tile_deal);
 int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed, float *film_dev, float *path_out_dev,
                   uint64_t n_film, uint64_t n_path_out);
 

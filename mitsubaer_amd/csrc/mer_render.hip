@@ -29,6 +29,18 @@ static bool pick_kernels(mer_context *ctx, const mer_scene_desc *sc, bool extra,
     return false;
 }
 
+// column rotation per tile row of the tile deal (decode_work): 0 for an unsharded film (the single-GPU work order is unchanged) and
+// for option tile_deal = 0; otherwise the smallest of 3, 5, 7, 11, 13 that is coprime to the number of tile columns
+int tile_skew_for(int tiles_x, int tile_count, int tile_deal) {
+    if (tile_count <= 1 || tiles_x <= 1 || !tile_deal) return 0;
+    for (int s : {3, 5, 7, 11, 13}) {
+        int a = s % tiles_x, b = tiles_x;
+        while (a) { const int t = b % a; b = a; a = t; }
+        if (b == 1) return s % tiles_x;
+    }
+    return 1 % tiles_x;
+}
+
 int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed, float *film_dev, float *path_out_dev,
                   uint64_t n_film, uint64_t n_path_out) {
     Params P;
@@ -41,6 +53,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
     P.spp_begin = shard->spp_begin; P.spp_count = shard->spp_count; P.spp_stride = shard->spp_stride;
     P.tile_rank = shard->tile_rank; P.tile_count = shard->tile_count;
     P.tiles_x = (scene->width + MER_TILE - 1) / MER_TILE; P.tiles_y = (scene->height + MER_TILE - 1) / MER_TILE;
+    P.tile_skew = tile_skew_for(P.tiles_x, shard->tile_count, (int) ctx->opt.tile_deal);
     const int ntiles = P.tiles_x * P.tiles_y;
     P.ntiles_mine = (ntiles - shard->tile_rank + shard->tile_count - 1) / shard->tile_count;
     P.total_work = (uint64_t) P.ntiles_mine * MER_TILE * MER_TILE * (uint64_t) shard->spp_count;
@@ -96,7 +109,10 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         // in the worst case, every id of ONE launch (all its waves read the tail before any of them pushes, and every camera sample
         // may hit the medium): capacity >= 2 x max(slots, ids per launch), or unread ids would be overwritten.
         unsigned long long ring = 1; while (ring < 2ull * std::max<unsigned long long>(want, ids_per_launch)) ring <<= 1;
-        if (pp.nslots < want || pp.hitq_cap < ring) {                 // capacity: grows, never shrinks
+        // event-queue segments: a segment of class c receives the lanes of the waves w = s (mod segments per class) of EVERY producer launch of
+        // the row -- K_march plus connect_launches K_connect launches, each of which re-packs its pending lanes into its first waves
+        auto eq_segcap = [&](uint32_t cap) { return std::min<uint64_t>((uint64_t) cap, (uint64_t) ((connect_stage ? connect_launches : 0) + 2) * (cap / (MER_NSEG / MER_EV_CLASSES))) + 256u; };
+        if (pp.nslots < want || pp.hitq_cap < ring || (pp.nslots && pp.eq.segcap < eq_segcap(pp.nslots))) {                 // capacity: grows, never shrinks
             const uint32_t cap = std::max(want, pp.nslots);
             if (pp.slots) (void) hipFree(pp.slots);
             if (pp.hitq) (void) hipFree(pp.hitq);
@@ -106,7 +122,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
                 if (sq->items) (void) hipFree(sq->items);
                 sq->items = nullptr;
                 sq->segcap = 2u * (cap / MER_NSEG) + 256u;          // two producer kernels may feed one segment
-                if (sq == &pp.eq) sq->segcap = 2u * (cap / (MER_NSEG / MER_EV_CLASSES)) + 256u;   // every lane may be of one event class
+                if (sq == &pp.eq) sq->segcap = (uint32_t) eq_segcap(cap);                        // every lane may be of one event class
                 if (sq == &pp.mq[0] || sq == &pp.mq[1]) sq->segcap = 2u * (cap / (MER_NSEG / MER_MQ_CLASSES)) + 256u;   // ... or of one march class
                 if (sq == &pp.cq[0] || sq == &pp.cq[1]) sq->segcap = cap + 256u;   // every slot may be pending, in one class
                 HIP_CHECK(ctx, hipMalloc((void **) &sq->items, (size_t) sq->segcap * MER_NSEG * sizeof(uint32_t)));
@@ -186,8 +202,15 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         HIP_CHECK(ctx, hipEventRecord(pp.readback[rb], pp.stream));
         return 0;
     };
-    for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q, 0)) return 1;
-    for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q, 1)) return 1;
+    // an error while other pipelines are running: wait for what was launched before handing control (and the film) back to the caller
+    auto abort_render = [&]() -> int {
+        const std::string msg = ctx->error;
+        for (int q = 0; q < npipes; q++) if (ctx->pipes[q].stream || q == 0) (void) hipStreamSynchronize(q == 0 ? ctx->stream : ctx->pipes[q].stream);
+        ctx->error = msg;
+        return 1;
+    };
+    for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q, 0)) return abort_render();
+    for (int q = 0; q < npipes; q++) if (!runs[q].done && enqueue_batch(q, 1)) return abort_render();
     for (;;) {
         bool any = false;
         for (int q = 0; q < npipes; q++) {
@@ -195,7 +218,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
             if (R.done) continue;
             any = true;
             const int rb = R.cur; R.cur ^= 1;
-            HIP_CHECK(ctx, hipEventSynchronize(pp.readback[rb]));
+            if (hipEventSynchronize(pp.readback[rb]) != hipSuccess) { ctx->error = "hipEventSynchronize(readback) failed"; return abort_render(); }
             const uint32_t finished_slots = pp.host_live[4 * rb];
             if (finished_slots >= R.nslots) { R.done = true; continue; }
             R.work_left = *(unsigned long long *) (pp.host_live + 4 * rb + 2) < R.P.total_work;
@@ -203,8 +226,8 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
                 const uint32_t alive = R.nslots - finished_slots;
                 R.P.ksteps = alive < R.nslots / 64 ? ksteps0 * 32 : (alive < R.nslots / 16 ? ksteps0 * 8 : (alive < R.nslots / 4 ? ksteps0 * 2 : ksteps0));
             }
-            if (R.pass > (1u << 24)) return fail(ctx, "mer_render: pass limit exceeded");
-            if (enqueue_batch(q, rb)) return 1;
+            if (R.pass > (1u << 24)) { ctx->error = "mer_render: pass limit exceeded"; return abort_render(); }
+            if (enqueue_batch(q, rb)) return abort_render();
         }
         if (!any) break;
     }

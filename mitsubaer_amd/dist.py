@@ -8,7 +8,8 @@ torch.distributed is plumbing only (backend "nccl" = RCCL over xGMI; "gloo" in t
 import os
 
 SHARD_SAMPLES = "samples"     # rank r renders sample indices s = r (mod world): perfect balance, result independent of world
-SHARD_TILES = "tiles"         # rank r renders 32x32 image tiles t = r (mod world) (the reference's block size)
+SHARD_TILES = "tiles"         # rank r renders the 32x32 image tiles (the reference's block size) that tile_owner() deals to it
+TILE = 32
 
 
 def env_rank_world():
@@ -42,6 +43,30 @@ def shard_args(mode, rank, world, spp_total):
     if mode == SHARD_TILES:
         return dict(spp_begin=0, spp_count=spp_total, spp_stride=1, tile_rank=rank, tile_count=world)
     raise ValueError("unknown shard mode %r" % mode)
+
+
+def tile_skew(tiles_x, world):
+    """Column rotation per tile row of libmer's tile deal (csrc/mer_render.hip: tile_skew_for): 0 for an unsharded film, else the smallest of
+    3, 5, 7, 11, 13 coprime to the number of tile columns."""
+    import math
+    if world <= 1 or tiles_x <= 1:
+        return 0
+    for s in (3, 5, 7, 11, 13):
+        if math.gcd(s % tiles_x, tiles_x) == 1:
+            return s % tiles_x
+    return 1 % tiles_x
+
+
+def tile_owner(width, height, world):
+    """-> int array [tiles_y][tiles_x]: the rank that renders each 32x32 tile in SHARD_TILES mode.  Tiles are dealt round-robin in row-major
+    order after row ty has been rotated by tile_skew * ty columns, so that a rank's tiles lie on diagonals of the tile grid instead of in whole
+    columns (the columns through the medium carry the work): the host-side mirror of decode_work (csrc/mer_device.hpp)."""
+    import numpy as np
+    tiles_x, tiles_y = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+    sk = tile_skew(tiles_x, world)
+    ty, tx = np.meshgrid(np.arange(tiles_y), np.arange(tiles_x), indexing="ij")
+    tx0 = (tx - sk * ty) % tiles_x
+    return (ty * tiles_x + tx0) % world
 
 
 def reduce_film(film_tensor):

@@ -35,9 +35,8 @@ def _worker(rank, world, port, mode, out_dir):
     else:   # tiles: the oracle shards by rows; emulate 32x32 tile ownership by masking the per-pixel box-filtered film
         p = p.copy(rfilter=1 - 1, rfilter_param=0.5)       # box filter: splats stay inside their pixel
         f, _ = orc.render(p, 0, 4, 7, nthreads=2)
-        tx = (np.arange(p.width) // 32)[None, :]; ty = (np.arange(p.height) // 32)[:, None]
-        tile = ty * ((p.width + 31) // 32) + tx
-        film = f * (tile % world == rank)[..., None]
+        owner = np.kron(mdist.tile_owner(p.width, p.height, world), np.ones((32, 32), int))[:p.height, :p.width]   # per pixel
+        film = f * (owner == rank)[..., None]
     t = torch.from_numpy(film)
     mdist.reduce_film(t)
     c = torch.tensor([float(rank + 1)] * 4, dtype=torch.float64)

@@ -114,6 +114,20 @@ def test_hg_sample_eval(ctx, orc, g):
         ctx.phase_sample(kind, 1.0, wi[:4], u2[:4])       # hg.cpp:52-53
 
 
+@pytest.mark.parametrize("kind,g", [(P.PHASE_ISOTROPIC, 0.0), (P.PHASE_HG, 0.9), (P.PHASE_HG, -0.3)])
+def test_phase_chisquare_reference_fixture_on_the_hip_path(ctx, kind, g):
+    """The one fixture the reference holds for a hot-path row (A9), applied to the HIP kernels themselves: src/tests/test_chisquare.cpp:508-573
+    on the isotropic / hg g=0.9 / hg g=-0.3 plugins of data/tests/test_phase.xml -- wiSamples = 20 incident directions, 10 x 20 (theta, phi)
+    bins, 200 000 samples each drawn by mer_phase_sample, expected frequencies integrated from mer_phase_eval, significance 0.0025 with
+    Sidak correction over the 20 tests, cells pooled below 5.  No oracle involved: this is the reference's own acceptance test."""
+    from tests.test_oracle_kat import _chi2_phase
+    rng = np.random.RandomState(42)
+    wis = scenes.rand_dirs(20, seed=7)
+    for wi in wis:
+        pval, alpha = _chi2_phase(lambda a, b: ctx.phase_sample(kind, g, a, b), lambda a, b: ctx.phase_eval(kind, g, a, b), wi, rng)
+        assert pval >= alpha, (kind, g, wi, pval, alpha)
+
+
 def test_camera_rays(ctx, orc):
     p = scenes.straight_scene()
     sc, vols = ctx.upload_scene(p)

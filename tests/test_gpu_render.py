@@ -85,7 +85,7 @@ def test_per_path_radiance_matches_oracle(ctx, orc, name):
         v.destroy()
 
 
-@pytest.mark.parametrize("name", ["point_curved_trilinear", "point_curved_bspline"])
+@pytest.mark.parametrize("name", ["point_curved_trilinear", "point_curved_bspline", "point_curved_outside_sphere", "point_curved_outside_dielectric"])
 def test_paths_that_disagree_with_the_oracle_are_unbiased(ctx, orc, name):
     """Curved-ray connections run an iterative solver per scattering event; a last-bit difference in the field evaluation can flip
     one of its accept / reject decisions, and 1 - 8 % of the paths then differ from the oracle's.  Such a path is still a valid
@@ -201,6 +201,33 @@ def test_sharding_is_exact_partition(ctx):
     assert np.allclose(full, parts, rtol=1e-4, atol=1e-5)
     tiles = sum(ctx.render_to_host(sc, 0, 6, seed=2, tile_rank=r, tile_count=3) for r in range(3))
     assert np.allclose(full, tiles, rtol=1e-4, atol=1e-5)
+
+
+def test_tile_shards_are_dealt_on_diagonals(ctx):
+    """SHARD_TILES: the tiles rank r renders are exactly those mitsubaer_amd.dist.tile_owner deals to it (box filter: a sample stays in its
+    pixel, so the weight channel shows who rendered what); with 8 ranks and 16 tile columns no rank owns a whole column (option
+    tile_deal = 0, the plain row-major deal, does), and every rank has tiles in every tile row and column."""
+    from mitsubaer_amd import dist as mdist
+    p = scenes.straight_scene(N=16, w=512, h=480, rfilter=P.FILTER_BOX, rfilter_param=0.5, max_depth=2)
+    sc, vols = ctx.upload_scene(p)
+    for world in (2, 3, 8):
+        owner = mdist.tile_owner(p.width, p.height, world)
+        total = np.zeros((p.height, p.width), np.float32)
+        for r in range(world):
+            w = ctx.render_to_host(sc, 0, 1, seed=4, tile_rank=r, tile_count=world)[..., 4]
+            tiles = w.reshape(p.height // 32, 32, p.width // 32, 32).sum((1, 3)) > 0
+            assert np.array_equal(tiles, owner == r), (world, r)
+            total += w
+        assert np.allclose(total, 1.0, atol=1e-5)
+    owner = mdist.tile_owner(p.width, p.height, 8)
+    for r in range(8):
+        assert (owner == r).any(0).all() and (owner == r).any(1).all()
+    with ctx.options(tile_deal=0):
+        w = ctx.render_to_host(sc, 0, 1, seed=4, tile_rank=3, tile_count=8)[..., 4]
+        cols = (w.reshape(p.height // 32, 32, p.width // 32, 32).sum((1, 3)) > 0).all(0)
+        assert cols.sum() == 2                                   # the plain deal: two whole tile columns
+    for v in vols:
+        v.destroy()
 
 
 def test_determinism(ctx):

@@ -92,7 +92,7 @@ def _chi2_phase(sample_fn, pdf_fn, wi, rng):
 def test_phase_chisquare_reference_fixture(orc, kind, g):
     rng = np.random.RandomState(42)
     wis = scenes.rand_dirs(20, seed=7)
-    for wi in wis[:6]:                                  # 6 of the reference's 20 directions keep the CPU suite fast
+    for wi in wis:                                      # wiSamples = 20 incident directions, as the reference (test_chisquare.cpp:515)
         pval, alpha = _chi2_phase(lambda a, b: orc.phase_sample(kind, g, a, b), lambda a, b: orc.phase_eval(kind, g, a, b), wi, rng)
         assert pval >= alpha, (pval, alpha)
 
