@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MER_ABI_VERSION 2
+#define MER_ABI_VERSION 3
 
 typedef struct mer_context mer_context;
 typedef int32_t mer_volume;            /* handle, > 0; 0 = none */
@@ -263,6 +263,39 @@ int  mer_rng_floats(mer_context *ctx, uint64_t seed, uint32_t pixel, uint32_t sa
    with mer_device_free */
 int  mer_synth_field_dev(mer_context *ctx, int32_t kind, int32_t N, float **data_dev);
 int  mer_device_free(mer_context *ctx, void *ptr_dev);
+
+/* ---- several GPUs in one process: replaces the reference's N local workers whose image blocks are merged by
+        film->put under a mutex (src/librender/renderproc.cpp:142-149; worker count: src/mitsuba/mitsuba.cpp:281).
+        A mer_multi owns one context per entry of device_ids and one host thread per context for the duration of a render.  Volumes are
+        replicated (every device holds every grid); the sample space of a render is cut into one mer_shard per context
+        (MER_SHARD_SAMPLES: sample s goes to context s mod n -- perfect balance, result independent of n up to summation order;
+        MER_SHARD_TILES: the 32x32 image tiles, dealt on diagonals of the tile grid -- the reference's block partition); the films are then
+        sum-reduced onto the first device: with RCCL (ncclReduce inside ncclGroupStart/End over a communicator made by ncclCommInitAll,
+        librccl.so loaded at run time) when all devices are distinct, by peer copy + an add kernel otherwise (a device listed twice,
+        e.g. {0, 0}, runs the whole code path on a one-GPU machine; RCCL refuses duplicate devices).  No other exchange: paths are
+        independent. ---- */
+typedef struct mer_multi mer_multi;
+enum { MER_SHARD_SAMPLES = 0, MER_SHARD_TILES = 1 };
+enum { MER_REDUCE_NONE = 0 /* one context */, MER_REDUCE_RCCL = 1, MER_REDUCE_PEER_COPY = 2 };
+int  mer_multi_create(const int32_t *device_ids, int32_t n, mer_multi **out);
+void mer_multi_destroy(mer_multi *m);
+const char *mer_multi_last_error(mer_multi *m);          /* m may be NULL: error of a failed create */
+int32_t mer_multi_size(mer_multi *m);
+mer_context *mer_multi_context(mer_multi *m, int32_t i); /* context i (options, leaf calls); owned by m */
+/* mer_context_set_option on every context */
+int  mer_multi_set_option(mer_multi *m, const char *name, int64_t value);
+/* mer_volume_upload / mer_volume_build_spline / mer_volume_destroy on every context; ONE handle, valid in all of them */
+int  mer_multi_volume_upload(mer_multi *m, const mer_grid_desc *desc, const void *host_data, int32_t layout, mer_volume *out);
+int  mer_multi_volume_build_spline(mer_multi *m, mer_volume v);
+int  mer_multi_volume_destroy(mer_multi *m, mer_volume v);
+/* renders sample indices spp_begin .. spp_begin + spp_count - 1 of every pixel, sharded over the contexts, and returns the reduced film
+   float[height][width][mer_film_channels] in film_host.  rccl: 1 = use RCCL when the devices allow it (default choice), 0 = always
+   peer copy + add, 2 = RCCL even for a single context (a one-rank communicator: exercises the library binding on one GPU). */
+int  mer_multi_render(mer_multi *m, const mer_scene_desc *scene, int32_t shard_mode, int32_t spp_begin, int32_t spp_count, uint64_t seed,
+                      int32_t rccl, float *film_host);
+/* of the last mer_multi_render: how the films were reduced (MER_REDUCE_*), wall milliseconds of every context's render (n floats, may be
+   NULL), of the reduction, and the counters summed over the contexts (may be NULL) */
+int  mer_multi_last_stats(mer_multi *m, int32_t *reduce_path, float *render_ms, float *reduce_ms, uint64_t counters[MER_C_COUNT]);
 
 #ifdef __cplusplus
 }

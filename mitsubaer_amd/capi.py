@@ -24,7 +24,11 @@ SYMBOLS = [
     "mer_counters_reset", "mer_lookup_trilinear", "mer_lookup_trilinear_rgb", "mer_rif_value_grad", "mer_er_trace",
     "mer_sample_distance", "mer_connect", "mer_eval_transmittance", "mer_phase_sample", "mer_phase_eval", "mer_camera_rays",
     "mer_correlation", "mer_render_paths", "mer_rng_floats", "mer_synth_field_dev", "mer_device_free",
+    "mer_multi_create", "mer_multi_destroy", "mer_multi_last_error", "mer_multi_size", "mer_multi_context", "mer_multi_set_option",
+    "mer_multi_volume_upload", "mer_multi_volume_build_spline", "mer_multi_volume_destroy", "mer_multi_render", "mer_multi_last_stats",
 ]
+SHARD_SAMPLES, SHARD_TILES = 0, 1
+REDUCE_NONE, REDUCE_RCCL, REDUCE_PEER_COPY = 0, 1, 2
 
 
 class GridDesc(C.Structure):
@@ -84,9 +88,15 @@ def lib(path=None):
         L.mer_last_error.restype = C.c_char_p
         L.mer_last_error.argtypes = [C.c_void_p]
         for s in SYMBOLS:
-            if s not in ("mer_last_error", "mer_context_destroy"):
+            if s not in ("mer_last_error", "mer_context_destroy", "mer_multi_destroy", "mer_multi_last_error", "mer_multi_context"):
                 getattr(L, s).restype = C.c_int
         L.mer_context_destroy.restype = None
+        L.mer_multi_destroy.restype = None
+        L.mer_multi_destroy.argtypes = [C.c_void_p]
+        L.mer_multi_last_error.restype = C.c_char_p
+        L.mer_multi_last_error.argtypes = [C.c_void_p]
+        L.mer_multi_context.restype = C.c_void_p
+        L.mer_multi_context.argtypes = [C.c_void_p, C.c_int32]
         _LIBS[path] = L
     return _LIBS[path]
 
@@ -116,20 +126,27 @@ class Volume:
 
     def destroy(self):
         if self.handle:
-            self.ctx.lib.mer_volume_destroy(self.ctx.h, C.c_int32(self.handle))
+            if isinstance(self.ctx, MultiContext):
+                self.ctx.destroy_volume(self)
+            else:
+                self.ctx.lib.mer_volume_destroy(self.ctx.h, C.c_int32(self.handle))
             self.handle = 0
 
 
 class Context:
     """One context per (process, GPU)."""
 
-    def __init__(self, device_id=0, check=False, **options):
+    def __init__(self, device_id=0, check=False, _borrowed=None, **options):
         """check=True: the bounds-checking build of the library (libmer_check.so); options: mer_context_set_option names."""
         self.lib = lib(CHECK_LIB_PATH if check else None)
-        self.h = C.c_void_p()
-        rc = self.lib.mer_context_create(C.c_int32(device_id), C.byref(self.h))
-        if rc != 0:
-            raise MerError(self.lib.mer_last_error(None).decode())
+        self.owned = _borrowed is None
+        if _borrowed is not None:                      # a context owned by a MultiContext
+            self.h = C.c_void_p(_borrowed)
+        else:
+            self.h = C.c_void_p()
+            rc = self.lib.mer_context_create(C.c_int32(device_id), C.byref(self.h))
+            if rc != 0:
+                raise MerError(self.lib.mer_last_error(None).decode())
         self.device_id = device_id
         for k, v in options.items():
             self.set_option(k, v)
@@ -139,9 +156,9 @@ class Context:
             raise MerError(self.lib.mer_last_error(self.h).decode())
 
     def close(self):
-        if self.h:
+        if self.h and self.owned:
             self.lib.mer_context_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def set_option(self, name, value):
         self._check(self.lib.mer_context_set_option(self.h, name.encode(), C.c_int64(int(value))))
@@ -420,3 +437,78 @@ class Context:
         out = np.empty(n, np.float32)
         self._check(self.lib.mer_rng_floats(self.h, C.c_uint64(seed), C.c_uint32(pixel), C.c_uint32(sample), C.c_int32(n), _fp(out)))
         return out
+
+
+class MultiContext:
+    """Several GPUs in one process (include/mer.h: mer_multi_*): one context and, during a render, one host thread per listed device;
+    volumes replicated; films sum-reduced onto the first device with RCCL (distinct devices) or peer copy + add (a device listed twice)."""
+
+    def __init__(self, device_ids, check=False, **options):
+        self.lib = lib(CHECK_LIB_PATH if check else None)
+        ids = (C.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
+        self.h = C.c_void_p()
+        if self.lib.mer_multi_create(ids, C.c_int32(len(device_ids)), C.byref(self.h)) != 0:
+            raise MerError(self.lib.mer_multi_last_error(None).decode())
+        self.device_ids = list(device_ids)
+        self.contexts = [Context(d, check=check, _borrowed=self.lib.mer_multi_context(self.h, C.c_int32(i))) for i, d in enumerate(device_ids)]
+        for k, v in options.items():
+            self.set_option(k, v)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise MerError(self.lib.mer_multi_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.mer_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def set_option(self, name, value):
+        self._check(self.lib.mer_multi_set_option(self.h, name.encode(), C.c_int64(int(value))))
+
+    def upload_volume(self, data, aabb_min, aabb_max, layout=LAYOUT_DENSE, to_world=None):
+        a = np.ascontiguousarray(data)
+        if a.dtype != np.uint8:
+            a = a.astype(np.float32, copy=False)
+        ch = 1 if a.ndim == 3 else a.shape[3]
+        d = Context._desc(a.shape, ch, P.VOL_U8 if a.dtype == np.uint8 else P.VOL_F32, aabb_min, aabb_max, to_world)
+        h = C.c_int32()
+        self._check(self.lib.mer_multi_volume_upload(self.h, C.byref(d), _fp(a), C.c_int32(layout), C.byref(h)))
+        return Volume(self, h.value, d, layout)
+
+    def upload_scene(self, p, layout=LAYOUT_DENSE):
+        """the replicated-volume form of Context.upload_scene: every device receives every grid, one handle each"""
+        vols = []
+        dens = alb = rif = sdf = None
+        if p.sigma_mode == P.SIGMA_GRID and p.density is not None:
+            dl = LAYOUT_CELL8 if layout in (LAYOUT_BRICK27, LAYOUT_BRICK125, LAYOUT_AUTO) else layout
+            dens = self.upload_volume(p.density, p.density_aabb[0], p.density_aabb[1], dl if np.asarray(p.density).dtype != np.uint8 else LAYOUT_DENSE, p.density_to_world)
+            vols.append(dens)
+        if p.albedo_mode == P.ALBEDO_GRID and p.albedo_grid is not None:
+            alb = self.upload_volume(p.albedo_grid, p.albedo_aabb[0], p.albedo_aabb[1], to_world=p.albedo_to_world); vols.append(alb)
+        if p.rif_mode not in (P.RIF_CONST, P.RIF_ACOUSTIC) and p.rif is not None:
+            rif = self.upload_volume(p.rif, p.rif_aabb[0], p.rif_aabb[1], layout if p.rif_mode == P.RIF_TRILINEAR else LAYOUT_DENSE, p.rif_to_world)
+            if p.rif_mode == P.RIF_BSPLINE3:
+                self._check(self.lib.mer_multi_volume_build_spline(self.h, C.c_int32(rif.handle)))
+            vols.append(rif)
+        if p.boundary == P.BOUNDARY_SDF and p.sdf is not None:
+            sdf = self.upload_volume(p.sdf, p.sdf_aabb[0], p.sdf_aabb[1], LAYOUT_DENSE, p.sdf_to_world); vols.append(sdf)
+        return self.contexts[0].scene_desc(p, dens, alb, rif, sdf), vols
+
+    def destroy_volume(self, vol):
+        if vol.handle:
+            self._check(self.lib.mer_multi_volume_destroy(self.h, C.c_int32(vol.handle)))
+            vol.handle = 0
+
+    def render_to_host(self, scene, spp_begin, spp_count, seed=0, shard=SHARD_SAMPLES, rccl=1):
+        ch = self.contexts[0].film_channels(scene)
+        out = np.empty((scene.height, scene.width, ch), np.float32)
+        self._check(self.lib.mer_multi_render(self.h, C.byref(scene), C.c_int32(shard), C.c_int32(spp_begin), C.c_int32(spp_count), C.c_uint64(seed),
+                                              C.c_int32(rccl), _fp(out)))
+        return out
+
+    def last_stats(self):
+        """-> (reduce path REDUCE_*, [render ms per context], reduce ms, counters summed over the contexts)"""
+        path = C.c_int32(); ms = (C.c_float * len(self.contexts))(); red = C.c_float(); cnt = np.zeros(C_COUNT, np.uint64)
+        self._check(self.lib.mer_multi_last_stats(self.h, C.byref(path), ms, C.byref(red), _fp(cnt)))
+        return path.value, list(ms), red.value, cnt

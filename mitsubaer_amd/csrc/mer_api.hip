@@ -2,6 +2,8 @@
 // Host side is plain HIP runtime: device memory, one stream, HIP events.  No CPU compute path exists:
 // every entry point that computes launches a kernel, and fails loudly when no device is present.
 #include "mer_internal.hpp"
+// every entry point runs on its context's device: a process may hold contexts of several GPUs (mer_multi.hip), and the current device is per-thread state
+#define MER_USE_DEVICE(ctx) do { if (ctx) (void) hipSetDevice((ctx)->device); } while (0)
 #include "mer_kernels.hpp"
 #include <algorithm>
 #include <functional>
@@ -404,6 +406,7 @@ static int64_t *option_slot(mer_context *ctx, const char *name) {
     return nullptr;
 }
 int mer_context_set_option(mer_context *ctx, const char *name, int64_t value) {
+    MER_USE_DEVICE(ctx);
     if (!ctx || !name) return 1;
     int64_t *p = option_slot(ctx, name);
     if (!p) return fail(ctx, std::string("unknown option '") + name + "'");
@@ -421,6 +424,7 @@ int mer_context_set_option(mer_context *ctx, const char *name, int64_t value) {
     return 0;
 }
 int mer_context_get_option(mer_context *ctx, const char *name, int64_t *value) {
+    MER_USE_DEVICE(ctx);
     if (!ctx || !name || !value) return 1;
     int64_t *p = option_slot(ctx, name);
     if (!p) return fail(ctx, std::string("unknown option '") + name + "'");
@@ -428,6 +432,7 @@ int mer_context_get_option(mer_context *ctx, const char *name, int64_t *value) {
     return 0;
 }
 int mer_debug_bounds(mer_context *ctx, int32_t *enabled, uint64_t out[4]) {
+    MER_USE_DEVICE(ctx);
     if (!ctx || !enabled || !out) return 1;
     out[0] = out[1] = out[2] = out[3] = 0;
     *enabled = ctx->chk != nullptr;
@@ -473,6 +478,7 @@ const char *mer_last_error(mer_context *ctx) { return ctx ? ctx->error.c_str() :
 int mer_context_set_stream(mer_context *ctx, void *hip_stream) { ctx->stream = (hipStream_t) hip_stream; return 0; }
 
 int mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu_count, int64_t *hbm_bytes) {
+    MER_USE_DEVICE(ctx);
     if (name && name_len > 0) { std::strncpy(name, ctx->prop.name, name_len - 1); name[name_len - 1] = 0; }
     if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (int64_t) ctx->prop.totalGlobalMem;
@@ -540,6 +546,7 @@ static int check_desc(mer_context *ctx, const mer_grid_desc *d) {
 }
 
 int mer_volume_upload(mer_context *ctx, const mer_grid_desc *desc, const void *host_data, int32_t layout, mer_volume *out) {
+    MER_USE_DEVICE(ctx);
     if (!ctx || !desc || !host_data || !out) return 1;
     if (check_desc(ctx, desc)) return 1;
     HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -552,6 +559,7 @@ int mer_volume_upload(mer_context *ctx, const mer_grid_desc *desc, const void *h
 }
 
 int mer_volume_upload_dev(mer_context *ctx, const mer_grid_desc *desc, const void *data_dev, int32_t layout, mer_volume *out) {
+    MER_USE_DEVICE(ctx);
     if (!ctx || !desc || !data_dev || !out) return 1;
     if (check_desc(ctx, desc)) return 1;
     HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -565,6 +573,7 @@ int mer_volume_upload_dev(mer_context *ctx, const mer_grid_desc *desc, const voi
 }
 
 int mer_volume_build_spline(mer_context *ctx, mer_volume h) {
+    MER_USE_DEVICE(ctx);
     auto it = ctx->volumes.find(h);
     if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
     Volume &v = it->second;
@@ -622,6 +631,7 @@ int mer_volume_build_spline(mer_context *ctx, mer_volume h) {
 }
 
 int mer_volume_download_spline(mer_context *ctx, mer_volume h, float *coeff_host) {
+    MER_USE_DEVICE(ctx);
     auto it = ctx->volumes.find(h);
     if (it == ctx->volumes.end() || !it->second.coeff) return fail(ctx, "volume has no spline coefficients");
     const size_t n = (size_t) it->second.desc.res[0] * it->second.desc.res[1] * it->second.desc.res[2];
@@ -630,6 +640,7 @@ int mer_volume_download_spline(mer_context *ctx, mer_volume h, float *coeff_host
 }
 
 int mer_volume_destroy(mer_context *ctx, mer_volume h) {
+    MER_USE_DEVICE(ctx);
     auto it = ctx->volumes.find(h);
     if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
     if (it->second.dense && it->second.owns_dense) (void) hipFree(it->second.dense);
@@ -640,6 +651,7 @@ int mer_volume_destroy(mer_context *ctx, mer_volume h) {
 }
 
 int mer_film_channels(mer_context *ctx, const mer_scene_desc *scene, int32_t *channels) {
+    MER_USE_DEVICE(ctx);
     int frames;
     if (!scene || !channels) return 1;
     if (film_frames(ctx, scene, frames)) return 1;
@@ -647,15 +659,18 @@ int mer_film_channels(mer_context *ctx, const mer_scene_desc *scene, int32_t *ch
     return 0;
 }
 int mer_film_alloc_n(mer_context *ctx, int32_t width, int32_t height, int32_t channels, float **film_dev) {
+    MER_USE_DEVICE(ctx);
     HIP_CHECK(ctx, hipMalloc((void **) film_dev, (size_t) width * height * channels * sizeof(float)));
     HIP_CHECK(ctx, hipMemsetAsync(*film_dev, 0, (size_t) width * height * channels * sizeof(float), ctx->stream));
     return 0;
 }
 int mer_film_zero_n(mer_context *ctx, float *film_dev, int32_t width, int32_t height, int32_t channels) {
+    MER_USE_DEVICE(ctx);
     HIP_CHECK(ctx, hipMemsetAsync(film_dev, 0, (size_t) width * height * channels * sizeof(float), ctx->stream));
     return 0;
 }
 int mer_film_download_n(mer_context *ctx, const float *film_dev, int32_t width, int32_t height, int32_t channels, float *film_host) {
+    MER_USE_DEVICE(ctx);
     HIP_CHECK(ctx, hipMemcpyAsync(film_host, film_dev, (size_t) width * height * channels * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -663,12 +678,14 @@ int mer_film_download_n(mer_context *ctx, const float *film_dev, int32_t width, 
 int mer_film_alloc(mer_context *ctx, int32_t width, int32_t height, float **film_dev) { return mer_film_alloc_n(ctx, width, height, 5, film_dev); }
 int mer_film_zero(mer_context *ctx, float *film_dev, int32_t width, int32_t height) { return mer_film_zero_n(ctx, film_dev, width, height, 5); }
 int mer_film_download(mer_context *ctx, const float *film_dev, int32_t width, int32_t height, float *film_host) {
+    MER_USE_DEVICE(ctx);
     return mer_film_download_n(ctx, film_dev, width, height, 5, film_host);
 }
 int mer_film_free(mer_context *ctx, float *film_dev) { HIP_CHECK(ctx, hipFree(film_dev)); return 0; }
 int mer_device_free(mer_context *ctx, void *p) { HIP_CHECK(ctx, hipFree(p)); return 0; }
 
 int mer_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed, float *film_dev) {
+    MER_USE_DEVICE(ctx);
     if (!ctx || !scene || !film_dev) return 1;
     int32_t ch = 5;
     if (mer_film_channels(ctx, scene, &ch)) return 1;
@@ -676,6 +693,7 @@ int mer_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *s
 }
 
 int mer_render_paths(mer_context *ctx, const mer_scene_desc *scene, int32_t sample_index, uint64_t seed, float *out_rgb) {
+    MER_USE_DEVICE(ctx);
     if (!ctx || !scene || !out_rgb) return 1;
     const size_t n = (size_t) scene->width * scene->height * 3;
     DevBuf buf(ctx);
@@ -689,6 +707,7 @@ int mer_render_paths(mer_context *ctx, const mer_scene_desc *scene, int32_t samp
 int mer_synchronize(mer_context *ctx) { HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); return 0; }
 
 int mer_last_kernel_ms(mer_context *ctx, float *ms) {
+    MER_USE_DEVICE(ctx);
     if (!ctx->timed) return fail(ctx, "no render has been launched");
     HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
     HIP_CHECK(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
@@ -696,6 +715,7 @@ int mer_last_kernel_ms(mer_context *ctx, float *ms) {
 }
 
 int mer_last_render_stats(mer_context *ctx, int32_t *passes, float *march_ms, float *event_ms) {
+    MER_USE_DEVICE(ctx);
     if (!ctx->timed) return fail(ctx, "no render has been launched");
     if (passes) *passes = ctx->last_passes;
     if (march_ms) *march_ms = ctx->last_march_ms;
@@ -704,6 +724,7 @@ int mer_last_render_stats(mer_context *ctx, int32_t *passes, float *march_ms, fl
 }
 
 int mer_counters_read(mer_context *ctx, uint64_t out[MER_C_COUNT]) {
+    MER_USE_DEVICE(ctx);
     HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<uint64_t> all((size_t) MER_C_COUNT * MER_COUNTER_REPLICAS);
     HIP_CHECK(ctx, hipMemcpy(all.data(), ctx->counters, sizeof(uint64_t) * all.size(), hipMemcpyDeviceToHost));
@@ -714,12 +735,14 @@ int mer_counters_read(mer_context *ctx, uint64_t out[MER_C_COUNT]) {
     return 0;
 }
 int mer_counters_reset(mer_context *ctx) {
+    MER_USE_DEVICE(ctx);
     HIP_CHECK(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(uint64_t) * MER_C_COUNT * MER_COUNTER_REPLICAS, ctx->stream));
     return 0;
 }
 
 // ---- leaf entry points ------------------------------------------------------------------------------
 int mer_lookup_trilinear(mer_context *ctx, mer_volume h, const float *pts, int64_t n, float *out_val, int32_t *out_idx) {
+    MER_USE_DEVICE(ctx);
     auto it = ctx->volumes.find(h);
     if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
     if (it->second.desc.channels != 1) return fail(ctx, "lookupFloat(): volume does not support float lookups");
@@ -734,6 +757,7 @@ int mer_lookup_trilinear(mer_context *ctx, mer_volume h, const float *pts, int64
     return 0;
 }
 int mer_lookup_trilinear_rgb(mer_context *ctx, mer_volume h, const float *pts, int64_t n, float *out_rgb) {
+    MER_USE_DEVICE(ctx);
     auto it = ctx->volumes.find(h);
     if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
     if (it->second.desc.channels != 3) return fail(ctx, "lookupSpectrum(): volume does not support spectrum lookups");
@@ -746,6 +770,7 @@ int mer_lookup_trilinear_rgb(mer_context *ctx, mer_volume h, const float *pts, i
     return dv.download(out_rgb, n * 12);
 }
 int mer_rif_value_grad(mer_context *ctx, mer_volume h, int32_t interp, const float *pts, int64_t n, float *out_val, float *out_grad) {
+    MER_USE_DEVICE(ctx);
     auto it = ctx->volumes.find(h);
     if (it == ctx->volumes.end()) return fail(ctx, "invalid volume handle");
     if (it->second.desc.channels != 1 || it->second.desc.dtype != MER_VOL_F32) return fail(ctx, "value(): not implemented for this volume type"); // volume.cpp:57-80
@@ -762,6 +787,7 @@ int mer_rif_value_grad(mer_context *ctx, mer_volume h, int32_t interp, const flo
 
 int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0, const float *d0, const float *dist, int64_t n,
                  float *out_p, float *out_v, float *out_dist_surf, float *out_opt, int32_t *out_success) {
+    MER_USE_DEVICE(ctx);
     Params P;
     if (make_params(ctx, scene, P)) return 1;
     if (scene->rif_mode == MER_RIF_CONST) return fail(ctx, "mer_er_trace needs a RIF volume");
@@ -788,6 +814,7 @@ int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0,
 }
 
 int mer_connect(mer_context *ctx, const mer_scene_desc *scene, const float *p1, const float *p2, int64_t n, uint64_t seed, float *out) {
+    MER_USE_DEVICE(ctx);
     Params P;
     if (make_params(ctx, scene, P, true)) return 1;
     if (scene->rif_mode == MER_RIF_CONST) return fail(ctx, "mer_connect needs a RIF volume");
@@ -816,6 +843,7 @@ int mer_connect(mer_context *ctx, const mer_scene_desc *scene, const float *p1, 
 
 int mer_sample_distance(mer_context *ctx, const mer_scene_desc *scene, const float *o, const float *d, const float *maxt, int64_t n,
                         uint64_t seed, float *rec) {
+    MER_USE_DEVICE(ctx);
     Params P;
     if (make_params(ctx, scene, P)) return 1;
     P.seed = seed;
@@ -833,6 +861,7 @@ int mer_sample_distance(mer_context *ctx, const mer_scene_desc *scene, const flo
 
 int mer_eval_transmittance(mer_context *ctx, const mer_scene_desc *scene, const float *o, const float *d, const float *maxt, int64_t n,
                            uint64_t seed, float *out_tr) {
+    MER_USE_DEVICE(ctx);
     Params P;
     if (make_params(ctx, scene, P)) return 1;
     P.seed = seed;
@@ -849,6 +878,7 @@ int mer_eval_transmittance(mer_context *ctx, const mer_scene_desc *scene, const 
 }
 
 int mer_phase_sample(mer_context *ctx, int32_t phase, float g, const float *wi, const float *u2, int64_t n, float *wo, float *pdf) {
+    MER_USE_DEVICE(ctx);
     if (phase == MER_PHASE_HG && (g >= 1 || g <= -1)) return fail(ctx, "The asymmetry parameter must lie in the interval (-1, 1)!");
     DevBuf a(ctx), b(ctx), c(ctx), e(ctx);
     if (a.upload(wi, n * 12) || b.upload(u2, n * 8) || c.alloc(n * 12) || e.alloc(n * 4)) return 1;
@@ -858,6 +888,7 @@ int mer_phase_sample(mer_context *ctx, int32_t phase, float g, const float *wi, 
     return e.download(pdf, n * 4);
 }
 int mer_phase_eval(mer_context *ctx, int32_t phase, float g, const float *wi, const float *wo, int64_t n, float *val) {
+    MER_USE_DEVICE(ctx);
     DevBuf a(ctx), b(ctx), c(ctx);
     if (a.upload(wi, n * 12) || b.upload(wo, n * 12) || c.alloc(n * 4)) return 1;
     hipLaunchKernelGGL(phase_eval_kernel, dim3(nblocks(n)), dim3(256), 0, ctx->stream, phase, g, a.as<float>(), b.as<float>(), n, c.as<float>());
@@ -865,6 +896,7 @@ int mer_phase_eval(mer_context *ctx, int32_t phase, float g, const float *wi, co
     return c.download(val, n * 4);
 }
 int mer_camera_rays(mer_context *ctx, const mer_scene_desc *scene, const float *pos2, int64_t n, float *o, float *d) {
+    MER_USE_DEVICE(ctx);
     Params P;
     mer_scene_desc sc = *scene; sc.sigma_mode = MER_SIGMA_HOMOGENEOUS; sc.rif_mode = MER_RIF_CONST; sc.albedo_mode = MER_ALBEDO_CONST;
     if (make_params(ctx, &sc, P)) return 1;
@@ -876,6 +908,7 @@ int mer_camera_rays(mer_context *ctx, const mer_scene_desc *scene, const float *
     return c.download(d, n * 12);
 }
 int mer_correlation(mer_context *ctx, const mer_scene_desc *scene, const float *path_length, int64_t n, float *out) {
+    MER_USE_DEVICE(ctx);
     Params P;
     mer_scene_desc sc = *scene; sc.sigma_mode = MER_SIGMA_HOMOGENEOUS; sc.rif_mode = MER_RIF_CONST; sc.albedo_mode = MER_ALBEDO_CONST;
     if (make_params(ctx, &sc, P)) return 1;
@@ -887,6 +920,7 @@ int mer_correlation(mer_context *ctx, const mer_scene_desc *scene, const float *
     return b.download(out, n * 4);
 }
 int mer_rng_floats(mer_context *ctx, uint64_t seed, uint32_t pixel, uint32_t sample, int32_t n, float *out) {
+    MER_USE_DEVICE(ctx);
     DevBuf a(ctx);
     if (a.alloc((size_t) n * 4)) return 1;
     hipLaunchKernelGGL(rng_kernel, dim3(1), dim3(64), 0, ctx->stream, seed, pixel, sample, n, a.as<float>());
@@ -894,6 +928,7 @@ int mer_rng_floats(mer_context *ctx, uint64_t seed, uint32_t pixel, uint32_t sam
     return a.download(out, (size_t) n * 4);
 }
 int mer_synth_field_dev(mer_context *ctx, int32_t kind, int32_t N, float **data_dev) {
+    MER_USE_DEVICE(ctx);
     if (kind < 0 || kind > 2 || N < 2) return fail(ctx, "mer_synth_field_dev: bad arguments");
     HIP_CHECK(ctx, hipMalloc((void **) data_dev, (size_t) N * N * N * 4));
     hipLaunchKernelGGL(synth_field_kernel, dim3(8192), dim3(256), 0, ctx->stream, kind, N, *data_dev);

@@ -9,6 +9,7 @@
 // not depend on the number of pipelines.
 #include "mer_internal.hpp"
 #include "mer_wavefront.hpp"
+#include <chrono>
 
 namespace mer {
 
@@ -99,6 +100,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
     const unsigned long long ids_per_launch = (unsigned long long) gen_blocks_max * (MER_BLOCK / 64) * 64ull * (unsigned long long) P.gen_iters;
 
     Run runs[MER_MAX_PIPES];
+    const auto t_start = std::chrono::steady_clock::now();
     HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int q = 0; q < npipes; q++) {
         Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
@@ -220,6 +222,9 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
             const int rb = R.cur; R.cur ^= 1;
             if (hipEventSynchronize(pp.readback[rb]) != hipSuccess) { ctx->error = "hipEventSynchronize(readback) failed"; return abort_render(); }
             const uint32_t finished_slots = pp.host_live[4 * rb];
+            if (opt.verbose >= 2)        // drain timeline: host time, pipeline, passes issued, slots finished, work ids handed out
+                fprintf(stderr, "[mer] t=%8.3f ms pipe %d passes %u finished %u / %u work %llu / %llu K=%d\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(),
+                        q, R.pass, finished_slots, R.nslots, *(unsigned long long *) (pp.host_live + 4 * rb + 2), (unsigned long long) R.P.total_work, R.P.ksteps);
             if (finished_slots >= R.nslots) { R.done = true; continue; }
             R.work_left = *(unsigned long long *) (pp.host_live + 4 * rb + 2) < R.P.total_work;
             if (adaptive) {          // tail: few lanes left => longer passes, fewer launches

@@ -37,12 +37,19 @@ def flatten_xml(path, defines=None):
     return d, spp.value
 
 
-def render_xml(path, defines=None, device=0, spp=0, seed=0, layout=capi.LAYOUT_AUTO):
+def render_xml(path, defines=None, device=0, spp=0, seed=0, layout=capi.LAYOUT_AUTO, devices=None, shard=capi.SHARD_SAMPLES):
+    """devices: a list of GPU indices renders on all of them (mer_multi_*: shard = capi.SHARD_SAMPLES | SHARD_TILES); None = `device` alone"""
     d, _ = flatten_xml(path, defines)
     frames = int(np.ceil((d.max_bound - d.min_bound) / d.bin_width)) if (d.decomposition and not d.modulation) else 1
     film = np.zeros((d.height, d.width, frames * 3 + 2), np.float32)
-    if lib().merhost_render_xml(path.encode(), _defs(defines), C.c_int32(device), C.c_int32(spp), C.c_uint64(seed),
-                                C.c_int32(layout), film.ctypes.data_as(C.c_void_p)) != 0:
+    if devices is None:
+        rc = lib().merhost_render_xml(path.encode(), _defs(defines), C.c_int32(device), C.c_int32(spp), C.c_uint64(seed),
+                                      C.c_int32(layout), film.ctypes.data_as(C.c_void_p))
+    else:
+        ids = (C.c_int32 * len(devices))(*devices)
+        rc = lib().merhost_render_xml_multi(path.encode(), _defs(defines), ids, C.c_int32(len(devices)), C.c_int32(shard), C.c_int32(spp), C.c_uint64(seed),
+                                            C.c_int32(layout), film.ctypes.data_as(C.c_void_p))
+    if rc != 0:
         raise HostError(lib().merhost_last_error().decode())
     return film
 

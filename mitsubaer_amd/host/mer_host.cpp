@@ -706,12 +706,21 @@ void Integrator::flatten(const Scene &scene, mer_scene_desc &d) const {
 }
 
 std::vector<float> Integrator::render(const Scene &scene, int device, int spp, unsigned long long seed, int layout) const {
+    return render(scene, std::vector<int>(1, device), MER_SHARD_SAMPLES, spp, seed, layout);
+}
+
+// One or several GPUs: mer_multi owns a context per device, replicates the volumes and reduces the films (RCCL between distinct devices).
+// The reference's counterpart: `mitsuba -p <workers>` local workers merged by film->put (src/mitsuba/mitsuba.cpp:281,
+// src/librender/renderproc.cpp:142-149).
+std::vector<float> Integrator::render(const Scene &scene, const std::vector<int> &devices, int shardMode, int spp, unsigned long long seed, int layout) const {
     mer_scene_desc d; flatten(scene, d);
     if (spp <= 0) spp = scene.sensor->sampler->sampleCount;
-    mer_context *ctx = NULL;
-    if (mer_context_create(device, &ctx)) Log_EError(mer_last_error(NULL));
+    if (devices.empty()) Log_EError("Integrator::render: no device given");
+    mer_multi *mm = NULL;
+    std::vector<int32_t> ids(devices.begin(), devices.end());
+    if (mer_multi_create(ids.data(), (int32_t) ids.size(), &mm)) Log_EError(mer_multi_last_error(NULL));
     int32_t channels = 5;
-    auto fail = [&](void) { std::string msg = mer_last_error(ctx); mer_context_destroy(ctx); Log_EError(msg); };
+    auto fail = [&](void) { std::string msg = mer_multi_last_error(mm); mer_multi_destroy(mm); Log_EError(msg); };
     const Medium &m = *([&]() -> const Shape * { for (auto &s : scene.shapes) if (s->interior) return s.get(); return (const Shape *) NULL; }())->interior;
     auto upload = [&](const VolumeDataSource &v, int lay) -> mer_volume {
         mer_grid_desc g; std::memset(&g, 0, sizeof(g));
@@ -719,25 +728,20 @@ std::vector<float> Integrator::render(const Scene &scene, int device, int spp, u
         for (int i = 0; i < 12; i++) g.world_to_volume[i] = v.worldToVolume[i];
         g.channels = v.channels; g.dtype = v.dtype;
         mer_volume h = 0;
-        if (mer_volume_upload(ctx, &g, v.data.data(), lay, &h)) fail();
+        if (mer_multi_volume_upload(mm, &g, v.data.data(), lay, &h)) fail();
         return h;
     };
     if (m.density) d.density = upload(*m.density, MER_LAYOUT_DENSE);
     if (m.albedo && !m.albedo->isConstant()) d.albedo_grid = upload(*m.albedo, MER_LAYOUT_DENSE);
     if (m.rif && !m.rif->isAcoustic()) {
         d.rif = upload(*m.rif, m.rif->isSpline() ? MER_LAYOUT_DENSE : layout);
-        if (m.rif->isSpline() && mer_volume_build_spline(ctx, d.rif)) fail();
+        if (m.rif->isSpline() && mer_multi_volume_build_spline(mm, d.rif)) fail();
     }
     if (m.sdf) d.sdf = upload(*m.sdf, MER_LAYOUT_DENSE);
-    float *film_dev = NULL;
-    if (mer_film_channels(ctx, &d, &channels)) fail();
+    if (mer_film_channels(mer_multi_context(mm, 0), &d, &channels)) { std::string msg = mer_last_error(mer_multi_context(mm, 0)); mer_multi_destroy(mm); Log_EError(msg); }
     std::vector<float> film((size_t) d.width * d.height * channels, 0.0f);
-    if (mer_film_alloc_n(ctx, d.width, d.height, channels, &film_dev)) fail();
-    mer_shard sh = {0, spp, 1, 0, 1};
-    if (mer_render(ctx, &d, &sh, seed, film_dev)) fail();
-    if (mer_film_download_n(ctx, film_dev, d.width, d.height, channels, film.data())) fail();
-    mer_film_free(ctx, film_dev);
-    mer_context_destroy(ctx);
+    if (mer_multi_render(mm, &d, shardMode, 0, spp, seed, 1, film.data())) fail();
+    mer_multi_destroy(mm);
     return film;
 }
 
@@ -829,6 +833,15 @@ int merhost_flatten_xml(const char *path, const char *defines, mer_scene_desc *o
         auto scene = merhost::loadScene(path, parseDefines(defines));
         scene->integrator->flatten(*scene, *out);
         if (spp) *spp = scene->sensor->sampler->sampleCount;
+        return 0;
+    } catch (const std::exception &e) { g_host_error = e.what(); return 1; }
+}
+int merhost_render_xml_multi(const char *path, const char *defines, const int32_t *devices, int32_t n, int32_t shard_mode, int32_t spp, uint64_t seed, int32_t layout,
+                             float *film_host) {
+    try {
+        auto scene = merhost::loadScene(path, parseDefines(defines));
+        std::vector<float> film = scene->integrator->render(*scene, std::vector<int>(devices, devices + (n > 0 ? n : 0)), shard_mode, spp, seed, layout);
+        std::memcpy(film_host, film.data(), film.size() * sizeof(float));
         return 0;
     } catch (const std::exception &e) { g_host_error = e.what(); return 1; }
 }

@@ -193,6 +193,8 @@ public:
     void flatten(const Scene &scene, mer_scene_desc &desc) const;
     /// upload volumes, render `spp` samples per pixel (0 = the sampler's sampleCount), return the film [h][w][5]
     std::vector<float> render(const Scene &scene, int device, int spp, unsigned long long seed, int layout) const;
+    /// the same on several GPUs of this machine (mer_multi_*: replicated volumes, shardMode = MER_SHARD_SAMPLES | MER_SHARD_TILES, films reduced with RCCL)
+    std::vector<float> render(const Scene &scene, const std::vector<int> &devices, int shardMode, int spp, unsigned long long seed, int layout) const;
 };
 
 class Scene : public ConfigurableObject {
@@ -229,4 +231,7 @@ const char *merhost_last_error(void);
 int merhost_flatten_xml(const char *path, const char *defines /* "k=v;k=v" */, mer_scene_desc *out, int32_t *spp);
 /* parse, upload, render on `device`; film_host = float[h][w][5] of the scene's film size (query with flatten first) */
 int merhost_render_xml(const char *path, const char *defines, int32_t device, int32_t spp, uint64_t seed, int32_t layout, float *film_host);
+/* the same on n devices (a device may be listed twice): shard_mode = MER_SHARD_SAMPLES | MER_SHARD_TILES */
+int merhost_render_xml_multi(const char *path, const char *defines, const int32_t *devices, int32_t n, int32_t shard_mode, int32_t spp, uint64_t seed, int32_t layout,
+                             float *film_host);
 }

@@ -31,11 +31,27 @@
  *     <string name="stepper" value="verlet|rk4"/> <string name="transmittance" value="woodcock|ratio"/>
      <string name="method" value="woodcock|simpson"/> <float name="stepSize" value="0"/>   <!-- heterogeneous -->
  *     <transform name="toWorld"> ... </transform>                                    <!-- the volumes' toWorld (gridvolume) -->
-     <integer name="device" value="0"/> <string name="rifLayout" value="auto|dense|cell8|brick27"/>
+ *     <string name="albedoFile" value="albedo.vol"/>                                 <!-- heterogeneous: gridded (RGB) albedo, heterogeneous.cpp:262-281 -->
+ *     <spectrum name="emission" value="0"/>                                          <!-- emission per unit density (configs[4]) -->
+ *     <string name="strategy" value="balance|single|manual|maximum"/> <float name="samplingDensity" value=".."/>
+ *     <float name="mediumSamplingWeight" value="-1"/>                                <!-- homogeneous.cpp:156-228 -->
+ *     <boolean name="aggressivetracing" value="false"/>                              <!-- heterogeneousrefractive.cpp:230 -->
+ *     <float name="lambda" .../> <float name="phase" .../> <integer name="P" .../> <integer name="neighbors" .../>   <!-- PathLengthSampler, pathlengthsampler.cpp:12-40 -->
+ *     <integer name="device" value="0"/> <string name="devices" value="0,1,2,3"/> <string name="shard" value="samples|tiles"/>
+ *     <string name="rifLayout" value="auto|dense|cell8|brick27"/>
  *   </integrator>
  *
- * sigmaA / sigmaS, the phase function, the shape, the sensor, the film, the reconstruction filter, the sampler's sample count and the
- * emitters are read from the objects themselves.
+ * sigmaA / sigmaS, the phase function, the shape, the sensor, the reconstruction filter, the sampler's sample count, the emitters and
+ * the film -- its size, its decomposition (Film::getDecompositionType / MinBound / MaxBound / BinWidth / getFrames / isCalibratedTransient,
+ * include/mitsuba/render/film.h:84-93) and the modulation TYPE of its PathLengthSampler (getModulationType; the sampler keeps lambda,
+ * phase, P and neighbors private, include/mitsuba/render/pathlengthsampler.h) -- are read from the objects themselves.
+ *
+ * Several GPUs: `devices` lists the GPUs of this machine to render on (mer_multi_*: one context and one host thread per GPU, volumes
+ * replicated, samples or image tiles sharded, films reduced with RCCL) -- what `mitsuba -p N` does with CPU workers
+ * (src/mitsuba/mitsuba.cpp:281, src/librender/renderproc.cpp:142-149).
+ *
+ * UNVERIFIED: this file has never been compiled (no Mitsuba tree in this image).  tests/test_plugin_shim.py keeps it from drifting
+ * against include/mer.h (every desc field it assigns and every mer_* function it calls must exist there), nothing more.
  */
 #include <mitsuba/render/scene.h>
 #include <mitsuba/render/integrator.h>
@@ -45,12 +61,16 @@
 #include <mitsuba/render/medium.h>
 #include <mitsuba/render/phase.h>
 #include <mitsuba/render/emitter.h>
+#include <mitsuba/render/film.h>
+#include <mitsuba/render/pathlengthsampler.h>
 #include <mitsuba/core/bitmap.h>
 #include <mitsuba/core/fresolver.h>
 #include <mitsuba/core/plugin.h>
 #include <fstream>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
+#include <cmath>
 #include "mer.h"
 
 MTS_NAMESPACE_BEGIN
@@ -74,6 +94,28 @@ public:
         m_layout = l == "auto" ? MER_LAYOUT_AUTO : l == "brick27" ? MER_LAYOUT_BRICK27 : l == "cell8" ? MER_LAYOUT_CELL8 : MER_LAYOUT_DENSE;
         m_seed = (uint64_t) props.getSize("seed", 0);
         m_volumeToWorld = props.getTransform("toWorld", Transform());                   /* gridvolume.cpp:110: the volumes' common toWorld */
+        m_albedoFile = props.getString("albedoFile", "");                               /* heterogeneous.cpp:262-281: `albedo` volume child */
+        m_emission = props.getSpectrum("emission", Spectrum(0.0f));
+        const std::string st = props.getString("strategy", "balance");                  /* homogeneous.cpp:183-228 */
+        if (st == "balance") m_strategy = MER_STRATEGY_BALANCE;
+        else if (st == "single") m_strategy = MER_STRATEGY_SINGLE;
+        else if (st == "maximum") m_strategy = MER_STRATEGY_MAXIMUM;
+        else if (st == "manual") m_strategy = MER_STRATEGY_MANUAL;
+        else Log(EError, "Specified an unknown sampling strategy");                     /* homogeneous.cpp:224-226 */
+        m_samplingDensity = m_strategy == MER_STRATEGY_MANUAL ? props.getFloat("samplingDensity") : 0.0f;
+        m_mediumSamplingWeight = props.getFloat("mediumSamplingWeight", -1);
+        m_aggressive = props.getBoolean("aggressivetracing", false);
+        m_lambda = props.getFloat("lambda", 1.0f); m_phase = props.getFloat("phase", 0.0f);   /* pathlengthsampler.cpp:12-40 */
+        m_P = props.getInteger("P", 32); m_neighbors = props.getInteger("neighbors", 3);
+        /* GPUs: `devices` = "0,1,..." (a GPU may be listed twice), else the single `device` */
+        const std::string dl = props.getString("devices", "");
+        for (size_t p = 0; p <= dl.size() && !dl.empty();) {
+            size_t e = dl.find(',', p); if (e == std::string::npos) e = dl.size();
+            if (e > p) m_devices.push_back(atoi(dl.substr(p, e - p).c_str()));
+            p = e + 1;
+        }
+        if (m_devices.empty()) m_devices.push_back(m_device);
+        m_shardTiles = props.getString("shard", "samples") == "tiles";
     }
 
     /* network rendering / serialisation of the plugin itself (src/librender/integrator.cpp:227-238) */
@@ -83,6 +125,11 @@ public:
         m_rifSpline = stream->readBool(); m_scale = stream->readFloat(); m_albedo = Spectrum(stream);
         m_stepsize = stream->readFloat(); m_rk4 = stream->readBool(); m_ratio = stream->readBool(); m_seed = stream->readSize();
         m_volumeToWorld = Transform(stream); m_simpson = stream->readBool(); m_hetStepSize = stream->readFloat();
+        m_albedoFile = stream->readString(); m_emission = Spectrum(stream); m_strategy = stream->readInt();
+        m_samplingDensity = stream->readFloat(); m_mediumSamplingWeight = stream->readFloat(); m_aggressive = stream->readBool();
+        m_lambda = stream->readFloat(); m_phase = stream->readFloat(); m_P = stream->readInt(); m_neighbors = stream->readInt();
+        m_devices.resize(stream->readSize()); for (size_t i = 0; i < m_devices.size(); ++i) m_devices[i] = stream->readInt();
+        m_shardTiles = stream->readBool();
     }
     void serialize(Stream *stream, InstanceManager *manager) const {
         MonteCarloIntegrator::serialize(stream, manager);
@@ -91,11 +138,18 @@ public:
         stream->writeBool(m_rifSpline); stream->writeFloat(m_scale); m_albedo.serialize(stream);
         stream->writeFloat(m_stepsize); stream->writeBool(m_rk4); stream->writeBool(m_ratio); stream->writeSize((size_t) m_seed);
         m_volumeToWorld.serialize(stream); stream->writeBool(m_simpson); stream->writeFloat(m_hetStepSize);
+        stream->writeString(m_albedoFile); m_emission.serialize(stream); stream->writeInt(m_strategy);
+        stream->writeFloat(m_samplingDensity); stream->writeFloat(m_mediumSamplingWeight); stream->writeBool(m_aggressive);
+        stream->writeFloat(m_lambda); stream->writeFloat(m_phase); stream->writeInt(m_P); stream->writeInt(m_neighbors);
+        stream->writeSize(m_devices.size()); for (size_t i = 0; i < m_devices.size(); ++i) stream->writeInt(m_devices[i]);
+        stream->writeBool(m_shardTiles);
     }
 
     bool render(Scene *scene, RenderQueue *queue, const RenderJob *job, int sceneResID, int sensorResID, int samplerResID) {
-        mer_context *ctx = NULL;
-        if (mer_context_create(m_device, &ctx)) Log(EError, "%s", mer_last_error(NULL));
+        /* one context per listed GPU (mer_multi_*); volumes are replicated, the films reduced (RCCL between distinct devices) */
+        mer_multi *ctx = NULL;
+        std::vector<int32_t> ids(m_devices.begin(), m_devices.end());
+        if (mer_multi_create(&ids[0], (int32_t) ids.size(), &ctx)) Log(EError, "%s", mer_multi_last_error(NULL));
         mer_scene_desc d; memset(&d, 0, sizeof(d));
         std::vector<mer_volume> volumes;
 
@@ -114,6 +168,21 @@ public:
         else if (rf->getClass()->getName() == "GaussianFilter") { d.rfilter = MER_FILTER_GAUSSIAN; d.rfilter_param = rf->getRadius() / 4; }   /* radius = 4 stddev, gaussian.cpp:42 */
         else Log(EError, "volpath_hip: reconstruction filter must be 'box' or 'gaussian'");
         d.max_depth = m_maxDepth; d.rr_depth = m_rrDepth; d.hide_emitters = m_hideEmitters ? 1 : 0;
+        /* film decomposition (src/librender/film.cpp:56-84; include/mitsuba/render/film.h:84-93): transient / bounce frames, or one frame
+           weighted by the PathLengthSampler's correlation function when a modulation is set (film.cpp:76-78) */
+        switch (film->getDecompositionType()) {
+            case Film::ESteadyState: d.decomposition = MER_DECOMPOSITION_NONE; break;
+            case Film::ETransient:   d.decomposition = MER_DECOMPOSITION_TRANSIENT; break;
+            case Film::EBounce:      d.decomposition = MER_DECOMPOSITION_BOUNCE; break;
+            default: Log(EError, "volpath_hip: film decomposition must be none, transient or bounce");
+        }
+        d.min_bound = film->getDecompositionMinBound(); d.max_bound = film->getDecompositionMaxBound(); d.bin_width = film->getDecompositionBinWidth();
+        d.calibrated_transient = film->isCalibratedTransient() ? 1 : 0;
+        if (d.decomposition != MER_DECOMPOSITION_NONE) {
+            ref<PathLengthSampler> pls = film->getPathLengthSampler();
+            d.modulation = pls ? (int32_t) pls->getModulationType() : MER_MODULATION_NONE;     /* ENone .. EDepthSelective = MER_MODULATION_* (same order) */
+            d.mod_lambda = m_lambda; d.mod_phase_deg = m_phase; d.mod_P = m_P; d.mod_neighbors = m_neighbors;
+        }
 
         /* ---- the one shape that carries an interior medium */
         const Shape *shape = findMediumShape(scene);
@@ -152,26 +221,27 @@ public:
             d.point_position[0] = pRec.p.x; d.point_position[1] = pRec.p.y; d.point_position[2] = pRec.p.z;
         }
 
-        /* ---- render, then hand the image to the film as one block */
+        /* ---- render on every listed GPU, then hand the reduced image to the film as one block */
         int32_t channels = 5;
-        if (mer_film_channels(ctx, &d, &channels)) fail(ctx);
-        float *filmDev = NULL;
-        if (mer_film_alloc_n(ctx, d.width, d.height, channels, &filmDev)) fail(ctx);
-        const mer_shard all = { 0, (int32_t) scene->getSampler()->getSampleCount(), 1, 0, 1 };
-        if (mer_render(ctx, &d, &all, m_seed, filmDev)) fail(ctx);
+        if (mer_film_channels(mer_multi_context(ctx, 0), &d, &channels)) { const std::string msg = mer_last_error(mer_multi_context(ctx, 0)); mer_multi_destroy(ctx); Log(EError, "%s", msg.c_str()); }
+        if (d.decomposition != MER_DECOMPOSITION_NONE && d.modulation == MER_MODULATION_NONE && (size_t) channels != film->getFrames() * 3 + 2)
+            Log(EError, "volpath_hip: the film holds %i frames, the scene description %i", (int) film->getFrames(), (channels - 2) / 3);
         std::vector<float> host((size_t) d.width * d.height * channels);
-        if (mer_film_download_n(ctx, filmDev, d.width, d.height, channels, &host[0])) fail(ctx);
+        if (mer_multi_render(ctx, &d, m_shardTiles ? MER_SHARD_TILES : MER_SHARD_SAMPLES, 0, (int32_t) scene->getSampler()->getSampleCount(), m_seed, 1, &host[0])) fail(ctx);
 
-        ref<ImageBlock> block = new ImageBlock(Bitmap::ESpectrumAlphaWeight, film->getCropSize(), film->getReconstructionFilter());
+        /* steady state: (R,G,B,alpha,weight); decomposed films: frames x RGB + alpha + weight, the reference's multichannel block
+           (src/integrators/bdpt/bdpt_wr.cpp:51-55, bdpt_proc.cpp:230-245,484-485) */
+        ref<ImageBlock> block = channels == 5
+            ? new ImageBlock(Bitmap::ESpectrumAlphaWeight, film->getCropSize(), film->getReconstructionFilter())
+            : new ImageBlock(Bitmap::EMultiSpectrumAlphaWeight, film->getCropSize(), film->getReconstructionFilter(), channels);
         block->setOffset(Point2i(0, 0));
         block->clear();
-        copyInto(block, host, d.width, d.height);
+        copyInto(block, host, d.width, d.height, channels);
         film->put(block);                                                              /* src/librender/renderproc.cpp:142-149 */
         queue->signalWorkEnd(job, block, false);
 
-        mer_film_free(ctx, filmDev);
-        for (size_t i = 0; i < volumes.size(); ++i) mer_volume_destroy(ctx, volumes[i]);
-        mer_context_destroy(ctx);
+        for (size_t i = 0; i < volumes.size(); ++i) mer_multi_volume_destroy(ctx, volumes[i]);
+        mer_multi_destroy(ctx);
         return true;
     }
 
@@ -186,9 +256,9 @@ public:
 
     MTS_DECLARE_CLASS()
 private:
-    void fail(mer_context *ctx) const {                              /* Log(EError) throws std::runtime_error (src/libcore/logger.cpp:100-147) */
-        const std::string msg = mer_last_error(ctx);
-        mer_context_destroy(ctx);
+    void fail(mer_multi *ctx) const {                                /* Log(EError) throws std::runtime_error (src/libcore/logger.cpp:100-147) */
+        const std::string msg = mer_multi_last_error(ctx);
+        mer_multi_destroy(ctx);
         Log(EError, "%s", msg.c_str());
     }
 
@@ -207,7 +277,7 @@ private:
     }
 
     /* a VOL v3 file (src/volume/gridvolume.cpp:54-89,217-287) -> mer_volume_upload */
-    mer_volume uploadVol(mer_context *ctx, const std::string &name, int layout, bool spline, std::vector<mer_volume> &keep) const {
+    mer_volume uploadVol(mer_multi *ctx, const std::string &name, int layout, bool spline, std::vector<mer_volume> &keep) const {
         const fs::path path = Thread::getThread()->getFileResolver()->resolve(name);
         std::ifstream f(path.string().c_str(), std::ios::binary);
         if (!f) Log(EError, "\"%s\": file does not exist!", path.string().c_str());
@@ -221,18 +291,22 @@ private:
         for (int i = 0; i < 3; ++i) { g.aabb_min[i] = bb[i]; g.aabb_max[i] = bb[3 + i]; }
         const Matrix4x4 &w2v = m_volumeToWorld.getInverseMatrix();                      /* m_worldToVolume, gridvolume.cpp:188-195 */
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) g.world_to_volume[4 * r + c] = (float) w2v(r, c);
+        {   /* one voxel diagonal of this grid: maxSDFError() of a signed-distance volume (src/volume/splinevolume.cpp:282) */
+            double e2 = 0; for (int i = 0; i < 3; ++i) { const double v = (bb[3 + i] - bb[i]) / (g.res[i] - 1); e2 += v * v; }
+            m_sdfMaxError = (float) std::sqrt(e2);
+        }
         const size_t n = (size_t) g.res[0] * g.res[1] * g.res[2] * g.channels * (g.dtype == MER_VOL_F32 ? 4 : 1);
         std::vector<char> data(n);
         f.read(&data[0], (std::streamsize) n);
         if ((size_t) f.gcount() != n) Log(EError, "Volume data file \"%s\" is truncated", path.string().c_str());
         mer_volume v = 0;
-        if (mer_volume_upload(ctx, &g, &data[0], layout, &v)) fail(ctx);
-        if (spline && mer_volume_build_spline(ctx, v)) fail(ctx);
+        if (mer_multi_volume_upload(ctx, &g, &data[0], layout, &v)) fail(ctx);             /* every listed GPU receives the grid; one handle */
+        if (spline && mer_multi_volume_build_spline(ctx, v)) fail(ctx);
         keep.push_back(v);
         return v;
     }
 
-    void fillMedium(mer_context *ctx, const Medium *med, mer_scene_desc &d, std::vector<mer_volume> &keep) const {
+    void fillMedium(mer_multi *ctx, const Medium *med, mer_scene_desc &d, std::vector<mer_volume> &keep) const {
         const std::string cls = med->getClass()->getName();
         /* phase function (src/phase/hg.cpp, src/phase/isotropic.cpp) */
         const PhaseFunction *phase = med->getPhaseFunction();
@@ -243,10 +317,12 @@ private:
         Float r, g, b;
         med->getSigmaA().toLinearRGB(r, g, b); d.sigma_a[0] = r; d.sigma_a[1] = g; d.sigma_a[2] = b;
         med->getSigmaS().toLinearRGB(r, g, b); d.sigma_s[0] = r; d.sigma_s[1] = g; d.sigma_s[2] = b;
-        d.strategy = MER_STRATEGY_BALANCE; d.channel = -1; d.medium_sampling_weight = -1;      /* plugin defaults (homogeneous.cpp:156-228) */
+        /* the media keep these private (homogeneous.cpp:426-427): the integrator's own `strategy` / `samplingDensity` / `mediumSamplingWeight` */
+        d.strategy = m_strategy; d.channel = -1; d.sampling_density = m_samplingDensity; d.medium_sampling_weight = m_mediumSamplingWeight;
         d.density_scale = m_scale;
         m_albedo.toLinearRGB(r, g, b); d.albedo[0] = r; d.albedo[1] = g; d.albedo[2] = b;
         d.albedo_mode = MER_ALBEDO_CONST;
+        m_emission.toLinearRGB(r, g, b); d.emission[0] = r; d.emission[1] = g; d.emission[2] = b;
         d.tr_estimator = m_ratio ? MER_TR_RATIO : MER_TR_WOODCOCK2;
         d.stepper = m_rk4 ? MER_STEP_RK4 : MER_STEP_VERLET;
         d.stepsize = m_stepsize;
@@ -258,31 +334,42 @@ private:
             if (m_densityFile.empty()) Log(EError, "No density specified!");                   /* heterogeneous.cpp:229-230 */
             d.sigma_mode = MER_SIGMA_GRID; d.rif_mode = MER_RIF_CONST;
             d.density = uploadVol(ctx, m_densityFile, MER_LAYOUT_DENSE, false, keep);
+            if (!m_albedoFile.empty()) { d.albedo_mode = MER_ALBEDO_GRID; d.albedo_grid = uploadVol(ctx, m_albedoFile, MER_LAYOUT_DENSE, false, keep); }   /* heterogeneous.cpp:262-281 */
         } else if (cls == "HeterogeneousRefractiveMedium") {
             if (m_rifFile.empty()) Log(EError, "No RIF specified!");                           /* heterogeneousrefractive.cpp:368-369 */
             d.rif_mode = m_rifSpline ? MER_RIF_BSPLINE3 : MER_RIF_TRILINEAR;
             d.rif = uploadVol(ctx, m_rifFile, m_rifSpline ? MER_LAYOUT_DENSE : m_layout, m_rifSpline, keep);
             if (!m_densityFile.empty()) { d.sigma_mode = MER_SIGMA_GRID; d.density = uploadVol(ctx, m_densityFile, MER_LAYOUT_CELL8, false, keep); }
             else d.sigma_mode = MER_SIGMA_HOMOGENEOUS;
-            if (!m_sdfFile.empty()) { d.boundary = MER_BOUNDARY_SDF; d.sdf = uploadVol(ctx, m_sdfFile, MER_LAYOUT_DENSE, false, keep); }
+            if (!m_albedoFile.empty() && d.sigma_mode == MER_SIGMA_GRID) { d.albedo_mode = MER_ALBEDO_GRID; d.albedo_grid = uploadVol(ctx, m_albedoFile, MER_LAYOUT_DENSE, false, keep); }
+            if (!m_sdfFile.empty()) {
+                d.boundary = MER_BOUNDARY_SDF; d.sdf = uploadVol(ctx, m_sdfFile, MER_LAYOUT_DENSE, false, keep);
+                if (m_aggressive) {                                                          /* heterogeneousrefractive.cpp:230,473-493 */
+                    d.aggressive_tracing = 1;
+                    d.sdf_max_error = m_sdfMaxError;                                         /* maxSDFError(): one voxel diagonal, set by uploadVol (splinevolume.cpp:282) */
+                }
+            } else if (m_aggressive) Log(EError, "aggressivetracing needs a signed-distance volume ('sdf')");
         } else Log(EError, "volpath_hip: medium \"%s\" is not on this path (homogeneous, heterogeneous, heterogeneousrefractive)", cls.c_str());
     }
 
-    /* film image float[h][w][5] -> the block's bitmap (which carries a border of getBorderSize() pixels on every side) */
-    static void copyInto(ImageBlock *block, const std::vector<float> &host, int w, int h) {
+    /* film image float[h][w][channels] -> the block's bitmap (which carries a border of getBorderSize() pixels on every side);
+       channels = 5 in steady state, frames x 3 + 2 for a decomposed film */
+    static void copyInto(ImageBlock *block, const std::vector<float> &host, int w, int h, int channels) {
         Bitmap *bmp = block->getBitmap();
         const int border = block->getBorderSize(), ch = bmp->getChannelCount(), bw = bmp->getWidth();
-        SAssert(ch == SPECTRUM_SAMPLES + 2 && SPECTRUM_SAMPLES == 3 && bmp->getComponentFormat() == Bitmap::EFloat32);
+        SAssert(ch == channels && SPECTRUM_SAMPLES == 3 && bmp->getComponentFormat() == Bitmap::EFloat32);
         float *dst = bmp->getFloat32Data();
         for (int y = 0; y < h; ++y)
-            memcpy(dst + ((size_t) (y + border) * bw + border) * ch, &host[(size_t) y * w * 5], (size_t) w * 5 * sizeof(float));
+            memcpy(dst + ((size_t) (y + border) * bw + border) * ch, &host[(size_t) y * w * channels], (size_t) w * channels * sizeof(float));
     }
 
-    int m_device, m_layout;
-    std::string m_densityFile, m_rifFile, m_sdfFile;
-    bool m_rifSpline, m_rk4, m_ratio, m_simpson;
-    Float m_scale, m_stepsize, m_hetStepSize;
-    Spectrum m_albedo;
+    int m_device, m_layout, m_strategy, m_P, m_neighbors;
+    std::vector<int> m_devices;
+    std::string m_densityFile, m_rifFile, m_sdfFile, m_albedoFile;
+    bool m_rifSpline, m_rk4, m_ratio, m_simpson, m_aggressive, m_shardTiles;
+    Float m_scale, m_stepsize, m_hetStepSize, m_samplingDensity, m_mediumSamplingWeight, m_lambda, m_phase;
+    mutable float m_sdfMaxError;
+    Spectrum m_albedo, m_emission;
     Transform m_volumeToWorld;
     uint64_t m_seed;
 };

@@ -106,6 +106,28 @@ def test_xml_render_equals_direct_c_abi_render(tmp_path, ctx):
 
 
 @pytest.mark.gpu
+def test_xml_render_on_several_devices_and_the_cli(tmp_path, ctx):
+    """the same scene XML on a device list (libmer_host -> mer_multi_*): samples and tiles sharding over {0, 0} equal the one-device film;
+    `mer_render --devices 0,0 --tiles --raw` writes that film too"""
+    import subprocess
+    N = 16
+    dens, rif = _vols(tmp_path, N)
+    defs = {"samples": 4, "size": 48, "density": dens, "rif": rif, "riftype": "gridvolume", "stepper": "rk4", "stepsize": 0.5 * 2.0 / (N - 1)}
+    xml = os.path.join(SC, "cfg3_refractive.xml")
+    one = host.render_xml(xml, defs, seed=3, layout=capi.LAYOUT_DENSE)
+    for shard in (capi.SHARD_SAMPLES, capi.SHARD_TILES):
+        two = host.render_xml(xml, defs, seed=3, layout=capi.LAYOUT_DENSE, devices=[0, 0], shard=shard)
+        assert np.allclose(two, one, rtol=1e-4, atol=1e-5)
+    with pytest.raises(host.HostError, match="device"):
+        host.render_xml(xml, defs, devices=[0, 4096])
+    exe = os.path.join(os.path.dirname(host.__file__), "mer_render")
+    out = str(tmp_path / "film.npy")
+    cmd = [exe, "--devices", "0,0", "--tiles", "--raw", "--dense", "--seed", "3", "-o", out] + sum((["-D", "%s=%s" % kv] for kv in defs.items()), []) + [xml]
+    subprocess.check_call(cmd)
+    assert np.allclose(np.load(out), one, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_xml_render_with_acousticrifvolume_equals_direct_render(tmp_path, ctx):
     """the cfg3 scene with its `rif` child replaced by an `acousticrifvolume`: host parse -> MER_RIF_ACOUSTIC -> same film as the direct C-ABI render"""
     N = 16
