@@ -170,7 +170,9 @@ int  mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu
      lds_bricks     1 = K_march keeps every lane's current BRICK27 record in LDS (BRICK27 fields below 4 GiB) instead of re-gathering cells
                     through L1 / L2 (default 0: measured slower)
      connect_launches  K_connect launches per pass: each runs one solver unit (one traced ray) per pending curved-ray connection (default 2)
-     adaptive_k     longer passes in the tail of a render (default 1)
+     adaptive_k     pass length in the tail of a render: 0 fixed (default), 1 longer, 2 shorter
+     tile_deal      1 = image-tile shards dealt on diagonals of the tile grid (default), 0 = plain row-major round robin (whole tile columns)
+     small_render_slots  1 = a render with fewer than ~8 paths per slot runs on a quarter of the slots (default)
      pass_events    per-pass HIP events feeding mer_last_render_stats (default 1)
      buffer_loads   0 = read fields with global loads even below 4 GiB, i.e. run the kernels a >= 4 GiB field selects (default 1)
      gen_all        K_gen hands every camera sample to K_event (A/B, default 0)

@@ -418,7 +418,7 @@ int mer_context_set_option(mer_context *ctx, const char *name, int64_t value) {
         (n == "prefilter" && (value < 0 || value > 4)) || (n == "mq_sort" && (value < -1 || value > 1)) ||
         (n == "march_lds_kb" && (value < 0 || value > 64)) ||          // dynamic LDS above 64 KiB would need hipFuncSetAttribute
         (n == "debug_pixel" && (value < -1 || value > ((int64_t) 1 << 31) - 1)) || (n == "tile_deal" && (value < 0 || value > 1)) ||
-        (n == "small_render_slots" && (value < 0 || value > 1)))
+        (n == "small_render_slots" && (value < 0 || value > 1)) || (n == "adaptive_k" && (value < 0 || value > 2)))
         return fail(ctx, std::string("option '") + name + "': value out of range");
     *p = value;
     return 0;

@@ -127,9 +127,10 @@ __device__ __forceinline__ void rif_value_grad_hess_vol(const DGrid &g, CellCach
         trilinear_value_grad<RIF>(g, cc, p, val, grad);
         const float fx = __builtin_fmaf(g.s[0], p.x, g.t[0]) - cc.cx, fy = __builtin_fmaf(g.s[1], p.y, g.t[1]) - cc.cy,
                     fz = __builtin_fmaf(g.s[2], p.z, g.t[2]) - cc.cz;
-        const float hxy = ((cc.d011 - cc.d010 - cc.d001 + cc.d000) * (1 - fz) + (cc.d111 - cc.d110 - cc.d101 + cc.d100) * fz) * g.s[0] * g.s[1];
-        const float hyz = ((cc.d110 - cc.d100 - cc.d010 + cc.d000) * (1 - fx) + (cc.d111 - cc.d101 - cc.d011 + cc.d001) * fx) * g.s[1] * g.s[2];
-        const float hzx = ((cc.d101 - cc.d100 - cc.d001 + cc.d000) * (1 - fy) + (cc.d111 - cc.d110 - cc.d011 + cc.d010) * fy) * g.s[2] * g.s[0];
+        // mixed second derivatives of the monomial form (the pure ones vanish): d2f/dxdy = axy + axyz z, ...
+        const float hxy = __builtin_fmaf(cc.axyz, fz, cc.axy) * g.s[0] * g.s[1];
+        const float hyz = __builtin_fmaf(cc.axyz, fx, cc.ayz) * g.s[1] * g.s[2];
+        const float hzx = __builtin_fmaf(cc.axyz, fy, cc.axz) * g.s[2] * g.s[0];
         H = m33(0.0f);
         H.m[0][1] = H.m[1][0] = hxy; H.m[1][2] = H.m[2][1] = hyz; H.m[0][2] = H.m[2][0] = hzx;
     }

@@ -198,15 +198,26 @@ __device__ __forceinline__ f3 lookup_spectrum(const DGrid &g, f3 p) {
 
 // Trilinear RIF: value + analytic gradient of the interpolant; cell clamped to the grid (new --
 // gridvolume has no value()/gradient(), src/librender/volume.cpp:57-80).  Being new functionality, its
-// arithmetic is DEFINED here (and restated identically in the oracle) in fused form: lerp(a,b,f)=fma(f,b-a,a).
+// arithmetic is DEFINED here (and restated identically in the oracle): monomial coefficients per cell (CellCache::set), fused Horner evaluation.
 // The 8 corner values of the last cell are kept in registers: the 4 RK4 stages of a half-voxel step land in
 // the same cell most of the time, so the gather is re-issued only when the cell index changes.
 struct CellCache {
     int cell;                 // linear index of the cached cell's base corner, -1 = empty
     float cx, cy, cz;         // the cached cell's base corner in grid coordinates (exact small integers)
-    float d000, d001, d010, d011, d100, d101, d110, d111;
+    // the cell's trilinear interpolant in monomial form about its base corner, f = a0 + ax x + ay y + az z + axy xy + axz xz + ayz yz + axyz xyz
+    // (x, y, z in [0,1)): computed ONCE per cell change from the 8 gathered corners (12 subtractions), so that each of the ~8 evaluations a
+    // ray makes inside a cell (4 RK4 stages per half-voxel step) costs 11 fused multiply-adds for value + gradient instead of the 22
+    // add / fma operations of nested lerps that re-derive the corner differences every time
+    float a0, ax, ay, az, axy, axz, ayz, axyz;
     int brick;                // RIFK_BRICK27_LDS: the brick whose record this lane holds in LDS, -1 = none
-    __device__ __forceinline__ void reset() { cell = -1; brick = -1; cx = cy = cz = -1.0e30f; d000 = d001 = d010 = d011 = d100 = d101 = d110 = d111 = 0.0f; }
+    __device__ __forceinline__ void reset() { cell = -1; brick = -1; cx = cy = cz = -1.0e30f; a0 = ax = ay = az = axy = axz = ayz = axyz = 0.0f; }
+    // corners d[z][y][x] -> coefficients; this operation order is part of the definition of the interpolant's arithmetic (oracle: TriCoeff)
+    __device__ __forceinline__ void set(float d000, float d001, float d010, float d011, float d100, float d101, float d110, float d111) {
+        a0 = d000; ax = d001 - d000; ay = d010 - d000; az = d100 - d000;
+        const float x1 = d011 - d010, x2 = d101 - d100, x3 = d111 - d110;
+        axy = x1 - ax; axz = x2 - ax; ayz = (d110 - d100) - ay;
+        axyz = (x3 - x2) - axy;
+    }
 };
 
 // Internal fetch kinds of the trilinear RIF (template parameter RIF of the kernels):
@@ -270,8 +281,7 @@ __device__ __forceinline__ void cell_fill(const DGrid &g, CellCache &cc, float p
             const int w = ((z1 & 1) * 3 + (y1 & 1)) * 3 + (x1 & 1);            // word of the cell's corner (0,0,0) in the record
             const uint32_t *words = (const uint32_t *) rec;
 #define MER_BRICK_WORD(i) __uint_as_float(words[(((w + (i)) >> 2) * 64 + lane) * 4 + ((w + (i)) & 3)])
-            cc.d000 = MER_BRICK_WORD(0); cc.d001 = MER_BRICK_WORD(1); cc.d010 = MER_BRICK_WORD(3); cc.d011 = MER_BRICK_WORD(4);
-            cc.d100 = MER_BRICK_WORD(9); cc.d101 = MER_BRICK_WORD(10); cc.d110 = MER_BRICK_WORD(12); cc.d111 = MER_BRICK_WORD(13);
+            cc.set(MER_BRICK_WORD(0), MER_BRICK_WORD(1), MER_BRICK_WORD(3), MER_BRICK_WORD(4), MER_BRICK_WORD(9), MER_BRICK_WORD(10), MER_BRICK_WORD(12), MER_BRICK_WORD(13));
 #undef MER_BRICK_WORD
         }
     } else
@@ -298,8 +308,8 @@ __device__ __forceinline__ void cell_fill(const DGrid &g, CellCache &cc, float p
                 r00 = u32x2{__float_as_uint(q[0]), __float_as_uint(q[1])}; r01 = u32x2{__float_as_uint(q[bw]), __float_as_uint(q[bw + 1])};
                 r10 = u32x2{__float_as_uint(q[bw * bw]), __float_as_uint(q[bw * bw + 1])}; r11 = u32x2{__float_as_uint(q[bw * bw + bw]), __float_as_uint(q[bw * bw + bw + 1])};
             }
-            cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
-            cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
+            cc.set(__uint_as_float(r00.x), __uint_as_float(r00.y), __uint_as_float(r01.x), __uint_as_float(r01.y),
+                   __uint_as_float(r10.x), __uint_as_float(r10.y), __uint_as_float(r11.x), __uint_as_float(r11.y));
         }
     } else
     if (MER_CELL_TEST(base != cc.cell)) {
@@ -318,7 +328,7 @@ __device__ __forceinline__ void cell_fill(const DGrid &g, CellCache &cc, float p
                 const float4 *c = (const float4 *) (g.cell8 + (size_t) cell * 8);
                 a = c[0]; b = c[1];
             }
-            cc.d000 = a.x; cc.d001 = a.y; cc.d010 = a.z; cc.d011 = a.w; cc.d100 = b.x; cc.d101 = b.y; cc.d110 = b.z; cc.d111 = b.w;
+            cc.set(a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w);
         } else if (RIFK == RIFK_DENSE_BUF) {
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.data, 0, (int) g.buf_bytes, 0x00020000);
             const int sy4 = g.res[0] * 4, sz4 = g.res[0] * g.res[1] * 4;
@@ -326,13 +336,12 @@ __device__ __forceinline__ void cell_fill(const DGrid &g, CellCache &cc, float p
             const u32x2 r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sy4, 0);
             const u32x2 r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sz4, 0);
             const u32x2 r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, dbase * 4, sz4 + sy4, 0);
-            cc.d000 = __uint_as_float(r00.x); cc.d001 = __uint_as_float(r00.y); cc.d010 = __uint_as_float(r01.x); cc.d011 = __uint_as_float(r01.y);
-            cc.d100 = __uint_as_float(r10.x); cc.d101 = __uint_as_float(r10.y); cc.d110 = __uint_as_float(r11.x); cc.d111 = __uint_as_float(r11.y);
+            cc.set(__uint_as_float(r00.x), __uint_as_float(r00.y), __uint_as_float(r01.x), __uint_as_float(r01.y),
+                   __uint_as_float(r10.x), __uint_as_float(r10.y), __uint_as_float(r11.x), __uint_as_float(r11.y));
         } else {
             const float *D = (const float *) g.data;
             const int sy = g.res[0], sz = g.res[0] * g.res[1];
-            cc.d000 = D[dbase]; cc.d001 = D[dbase + 1]; cc.d010 = D[dbase + sy]; cc.d011 = D[dbase + sy + 1];
-            cc.d100 = D[dbase + sz]; cc.d101 = D[dbase + sz + 1]; cc.d110 = D[dbase + sz + sy]; cc.d111 = D[dbase + sz + sy + 1];
+            cc.set(D[dbase], D[dbase + 1], D[dbase + sy], D[dbase + sy + 1], D[dbase + sz], D[dbase + sz + 1], D[dbase + sz + sy], D[dbase + sz + sy + 1]);
         }
     }
 
@@ -352,16 +361,13 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
         cell_fill<RIFK>(g, cc, px, py, pz);
         fx = px - cc.cx; fy = py - cc.cy; fz = pz - cc.cz;
     }
-    const float dx00 = cc.d001 - cc.d000, dx01 = cc.d011 - cc.d010, dx10 = cc.d101 - cc.d100, dx11 = cc.d111 - cc.d110;
-    const float c00 = __builtin_fmaf(fx, dx00, cc.d000), c01 = __builtin_fmaf(fx, dx01, cc.d010),
-                c10 = __builtin_fmaf(fx, dx10, cc.d100), c11 = __builtin_fmaf(fx, dx11, cc.d110);
-    const float dy0 = c01 - c00, dy1 = c11 - c10;
-    const float c0 = __builtin_fmaf(fy, dy0, c00), c1 = __builtin_fmaf(fy, dy1, c10);
-    const float gz = c1 - c0;
-    val = __builtin_fmaf(fz, gz, c0);
-    const float gy = __builtin_fmaf(fz, dy1 - dy0, dy0);
-    const float gxa = __builtin_fmaf(fy, dx01 - dx00, dx00), gxb = __builtin_fmaf(fy, dx11 - dx10, dx10);
-    const float gx = __builtin_fmaf(fz, gxb - gxa, gxa);
+    // value + gradient from the monomial coefficients (Horner in z, then y, then x): 11 fused multiply-adds
+    const float A = __builtin_fmaf(cc.axyz, fz, cc.axy), B = __builtin_fmaf(cc.axz, fz, cc.ax),
+                C = __builtin_fmaf(cc.ayz, fz, cc.ay), D = __builtin_fmaf(cc.az, fz, cc.a0);
+    const float gx = __builtin_fmaf(A, fy, B);                 // df/dx = (ax + axz z) + (axy + axyz z) y
+    val = __builtin_fmaf(gx, fx, __builtin_fmaf(C, fy, D));    // f = f(x = 0) + x df/dx   (f is linear in x)
+    const float gy = __builtin_fmaf(A, fx, C);                 // df/dy = (ay + ayz z) + (axy + axyz z) x
+    const float gz = __builtin_fmaf(__builtin_fmaf(cc.axyz, fx, cc.ayz), fy, __builtin_fmaf(cc.axz, fx, cc.az));    // df/dz = (az + axz x) + (ayz + axyz x) y
     grad = f3(gx * g.s[0], gy * g.s[1], gz * g.s[2]);
 }
 
@@ -942,6 +948,12 @@ __device__ __forceinline__ bool decode_work(const Params &P, uint64_t w, int &x,
 // what one path edge adds to the quantity a decomposed film bins by: its optical length (transient) or 1 (bounce: bdpt_proc.cpp:179-187)
 __device__ __forceinline__ float edge_length(const Params &P, float optical_length) {
     return P.sc.decomposition == MER_DECOMPOSITION_BOUNCE ? 1.0f : optical_length;
+}
+
+// `calibratedTransient` drops the camera edge from a TRANSIENT film's path length (bdpt_proc.cpp:163-170: startIndex 3); a BOUNCE film counts
+// every edge whatever the flag says (:179-187 loops from i = 2 unconditionally)
+__device__ __forceinline__ bool camera_edge_counts(const Params &P) {
+    return !(P.sc.calibrated_transient && P.sc.decomposition == MER_DECOMPOSITION_TRANSIENT);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {

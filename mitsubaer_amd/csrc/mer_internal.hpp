@@ -42,7 +42,7 @@ struct Options {
     int64_t ksteps = 128;         // eikonal steps / tentative collisions per lane per K_march launch
     int64_t mq_sort = -1;         // march lists sorted by steps-to-boundary class: -1 = by field size, 0 / 1 = off / on
     int64_t connect_launches = 2;    // K_connect launches per pass (one solver unit per pending connection per launch; 1-3 measured equal, 6+ slower)
-    int64_t adaptive_k = 1;       // lengthen passes in the tail of a render
+    int64_t adaptive_k = 0;       // pass length in the tail of a render: 0 fixed (default), 1 longer (rounds 1-2: measured a loss), 2 shorter
     int64_t pass_events = 1;      // per-pass HIP events (mer_last_render_stats)
     int64_t buffer_loads = 1;     // 0: global loads even for fields below 4 GiB (the kernels a >= 4 GiB field selects)
     int64_t gen_all = 0;          // K_gen hands every camera sample to K_event (A/B)
@@ -114,6 +114,7 @@ bool kernels_cell8(int rifk, int stepper, int sigma, bool extra, KernelSet &k);
 bool kernels_brick(int rifk, int stepper, int sigma, bool extra, KernelSet &k);
 bool kernels_bspline(int stepper, int sigma, bool extra, KernelSet &k);
 bool kernels_sdf_curved(int rifk, int stepper, int sigma, KernelSet &k);
+bool kernels_sdf_curved_records(int rifk, int stepper, int sigma, KernelSet &k);      // BRICK27 (both load kinds), CELL8 with global loads
 int tile_skew_for(int tiles_x, int tile_count, int tile_deal);
 int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed, float *film_dev, float *path_out_dev,
                   uint64_t n_film, uint64_t n_path_out);

@@ -19,7 +19,7 @@ static bool pick_kernels(mer_context *ctx, const mer_scene_desc *sc, bool extra,
     const int bnd = sc->boundary == MER_BOUNDARY_SDF ? 1 : 0;
     if (!curved) return kernels_straight(sigma, bnd, extra, k);
     const int rifk = rif_fetch_kind(ctx, sc);
-    if (bnd) return kernels_sdf_curved(rifk, sc->stepper, sigma, k);
+    if (bnd) return kernels_sdf_curved(rifk, sc->stepper, sigma, k) || kernels_sdf_curved_records(rifk, sc->stepper, sigma, k);
     switch (rifk) {
     case RIFK_ACOUSTIC: return kernels_acoustic(sc->stepper, sigma, extra, k);
     case MER_RIF_TRILINEAR: case RIFK_DENSE_BUF: return kernels_dense(rifk, sc->stepper, sigma, extra, k);
@@ -69,7 +69,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
     const bool extra = scene->boundary == MER_BOUNDARY_SDF || has_point || scene->modulation != MER_MODULATION_NONE || scene->boundary_bsdf != MER_BSDF_NULL;
     KernelSet ks{};
     if (!pick_kernels(ctx, scene, extra, ks)) {
-        if (scene->boundary == MER_BOUNDARY_SDF && curved) return fail(ctx, "signed-distance boundary: the RIF must be dense, cell8 below 4 GiB, or a B-spline volume");
+        if (scene->boundary == MER_BOUNDARY_SDF && curved) return fail(ctx, "signed-distance boundary: no kernel for this RIF layout (MER_LAYOUT_BRICK125 is not built with it)");
         return fail(ctx, "unsupported rif_mode / stepper combination");
     }
     if (opt.lds_bricks && ks.march_lds && curved) {      // LDS staging holds 27-corner records: BRICK27, not BRICK125
@@ -87,6 +87,9 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
     int npipes = (int) opt.pipes;
     if (shard->spp_count < npipes) npipes = std::max(1, shard->spp_count);
     uint32_t want = opt.nslots > 0 ? (uint32_t) opt.nslots : (uint32_t) ctx->prop.multiProcessorCount * 2048u * 4u;   // 4 x the resident lanes of the chip, over all pipelines
+    // a small render (a tile shard of a strong-scaled job, a preview): with fewer than ~8 paths per slot the slots are never refilled and the
+    // lists only get sparser; a quarter of the slots keeps the wavefront denser while it drains (+3 ... 5 % at 8 ... 32 spp, ab_adaptive_k.txt)
+    if (opt.nslots == 0 && opt.small_render_slots && P.total_work / 8 < want) want = (uint32_t) std::max<uint64_t>(want / 4, P.total_work / 8);
     want = (want / (uint32_t) npipes + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;       // per pipeline
     const int ksteps0 = (int) opt.ksteps;
     // sorting the march lists by exit time scatters the lanes of a wave over the volume: a gain while the RIF sits near the caches
@@ -174,7 +177,6 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
     }
 
     const uint32_t check_every = 8;
-    const bool adaptive = opt.adaptive_k != 0;
     const bool pass_events = opt.pass_events != 0;          // per-kernel timing of every pass (mer_last_render_stats)
     // one batch = check_every passes of a pipeline followed by the read-back of its finished-slot count into slot `rb`.  Two batches
     // are kept in flight per pipeline, so that a pipeline never runs dry while the host waits for another one's read-back (a
@@ -227,9 +229,19 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
                         q, R.pass, finished_slots, R.nslots, *(unsigned long long *) (pp.host_live + 4 * rb + 2), (unsigned long long) R.P.total_work, R.P.ksteps);
             if (finished_slots >= R.nslots) { R.done = true; continue; }
             R.work_left = *(unsigned long long *) (pp.host_live + 4 * rb + 2) < R.P.total_work;
-            if (adaptive) {          // tail: few lanes left => longer passes, fewer launches
+            // Pass length in the tail.  The tail of a render is the serial latency of its deepest paths, and a path advances by ONE walk (free
+            // flight, NEE or look-up: ~65 steps) per pass however long the pass may be, so a pass should end when most lanes have parked.
+            // Rounds 1-2 LENGTHENED the passes as lanes ran out (fewer launches); with K x 32 every pass lasts as long as the longest walk in
+            // flight (~1 ms) and every other lane gets one event per millisecond.  Measured (profiles/round3/ab_adaptive_k.txt): fixed K
+            // 307.7 vs 286.7 Mpaths/s on the headline job, 143.7 vs 116.8 on an eighth of it, 26.3 vs 22.3 at 1024^3 x 8 spp; halving K
+            // in the tail instead (mode 2) is within 1-5 % of fixed K, below it.  Default: fixed.
+            if (opt.adaptive_k == 1) {
                 const uint32_t alive = R.nslots - finished_slots;
                 R.P.ksteps = alive < R.nslots / 64 ? ksteps0 * 32 : (alive < R.nslots / 16 ? ksteps0 * 8 : (alive < R.nslots / 4 ? ksteps0 * 2 : ksteps0));
+            } else if (opt.adaptive_k == 2) {   // the opposite: the tail of a render is the serial latency of its deepest paths -- one walk (free flight, NEE or look-up) per
+                // pass -- so a pass should end as soon as most lanes have parked: shorter passes once few lanes are left
+                const uint32_t alive = R.nslots - finished_slots;
+                R.P.ksteps = alive < R.nslots / 16 ? std::max(16, ksteps0 / 2) : ksteps0;
             }
             if (R.pass > (1u << 24)) { ctx->error = "mer_render: pass limit exceeded"; return abort_render(); }
             if (enqueue_batch(q, rb)) return abort_render();

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
                     bool medium = true;
                     if (!CURVED) { const f3 ro = o + d * itsT; medium = intersect_shape_b<BND>(P, ro, d, MER_EPSILON, MER_INF) >= 0; }
                     if (!(2 <= maxDepth || maxDepth < 0)) { }
-                    else if (!medium) { if (!S.hide_emitters) L = env; if (!S.calibrated_transient) plen = edge_length(P, itsT); }
+                    else if (!medium) { if (!S.hide_emitters) L = env; if (camera_edge_counts(P)) plen = edge_length(P, itsT); }
                     else hit = true;
                 }
                 if (!hit) {
@@ -436,7 +436,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             } else if (depth >= maxDepth && maxDepth != -1) ev = EV_PATH_DONE;
             else if (dielectric) {
                 // hdielectric boundary (N2): reflect away (the ray escapes: environment, weight 1) or refract into the medium
-                if (!S.calibrated_transient) plen += edge_length(P, itsT);
+                if (camera_edge_counts(P)) plen += edge_length(P, itsT);
                 f3 x, wo;
                 if (!dielectric_event<CURVED, RIF, BND>(P, rng, o, d, itsT, false, T, etaPath, x, wo)) {
                     L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen);
@@ -449,7 +449,7 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
                 }
             } else {
                 (void) rng.next1D(); (void) rng.next1D();                      // null bsdf->sample(..., nextSample2D())
-                if (!S.calibrated_transient) plen += edge_length(P, itsT);     // the camera edge (bdpt_proc.cpp:163-176)
+                if (camera_edge_counts(P)) plen += edge_length(P, itsT);       // the camera edge (bdpt_proc.cpp:163-176)
                 const f3 ro = o + d * itsT;
                 bool medium = true;
                 if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }

@@ -252,7 +252,20 @@ struct Grid {
 
 /* trilinear value + analytic gradient of the interpolant, cell clamped to the grid (new: SURVEY D2 --
    gridvolume has no value()/gradient()).  Being new functionality its arithmetic is a definition, not a
-   restatement: fused lerps lerp(a,b,f) = fma(f, b-a, a), the same expression tree the HIP kernel uses. */
+   restatement: the cell's interpolant in monomial form about its base corner,
+   f = a0 + ax x + ay y + az z + axy xy + axz xz + ayz yz + axyz xyz, coefficients from the corners in the operation order below,
+   evaluated by fused Horner steps -- the same expression tree the HIP kernel uses (CellCache::set, trilinear_value_grad). */
+template <typename FLOAT> struct TriCoeff {
+    FLOAT a0, ax, ay, az, axy, axz, ayz, axyz;
+    TriCoeff(const float *D, int base, int sy, int sz) {
+        const FLOAT d000 = D[base], d001 = D[base + 1], d010 = D[base + sy], d011 = D[base + sy + 1],
+                    d100 = D[base + sz], d101 = D[base + sz + 1], d110 = D[base + sz + sy], d111 = D[base + sz + sy + 1];
+        a0 = d000; ax = d001 - d000; ay = d010 - d000; az = d100 - d000;
+        const FLOAT x1 = d011 - d010, x2 = d101 - d100, x3 = d111 - d110;
+        axy = x1 - ax; axz = x2 - ax; ayz = (d110 - d100) - ay;
+        axyz = (x3 - x2) - axy;
+    }
+};
 template <typename FLOAT>
 inline void trilinearValueGrad(const Grid &g, const V3<FLOAT> &pw, FLOAT &val, V3<FLOAT> &grad) {
     /* pw: the point in VOLUME space (Rif applies worldToVolume first when the grid has a toWorld) */
@@ -266,18 +279,12 @@ inline void trilinearValueGrad(const Grid &g, const V3<FLOAT> &pw, FLOAT &val, V
     const FLOAT fx = px - x1, fy = py - y1, fz = pz - z1;
     const float *D = (const float *) g.data;
     const int base = (z1 * g.res[1] + y1) * g.res[0] + x1, sy = g.res[0], sz = g.res[0] * g.res[1];
-    const FLOAT d000 = D[base], d001 = D[base + 1], d010 = D[base + sy], d011 = D[base + sy + 1],
-                d100 = D[base + sz], d101 = D[base + sz + 1], d110 = D[base + sz + sy], d111 = D[base + sz + sy + 1];
-    const FLOAT dx00 = d001 - d000, dx01 = d011 - d010, dx10 = d101 - d100, dx11 = d111 - d110;
-    const FLOAT c00 = std::fma(fx, dx00, d000), c01 = std::fma(fx, dx01, d010),
-                c10 = std::fma(fx, dx10, d100), c11 = std::fma(fx, dx11, d110);
-    const FLOAT dy0 = c01 - c00, dy1 = c11 - c10;
-    const FLOAT c0 = std::fma(fy, dy0, c00), c1 = std::fma(fy, dy1, c10);
-    const FLOAT gz = c1 - c0;
-    val = std::fma(fz, gz, c0);
-    const FLOAT gy = std::fma(fz, dy1 - dy0, dy0);
-    const FLOAT gxa = std::fma(fy, dx01 - dx00, dx00), gxb = std::fma(fy, dx11 - dx10, dx10);
-    const FLOAT gx = std::fma(fz, gxb - gxa, gxa);
+    const TriCoeff<FLOAT> c(D, base, sy, sz);
+    const FLOAT A = std::fma(c.axyz, fz, c.axy), B = std::fma(c.axz, fz, c.ax), C = std::fma(c.ayz, fz, c.ay), Dz = std::fma(c.az, fz, c.a0);
+    const FLOAT gx = std::fma(A, fy, B);
+    val = std::fma(gx, fx, std::fma(C, fy, Dz));
+    const FLOAT gy = std::fma(A, fx, C);
+    const FLOAT gz = std::fma(std::fma(c.axyz, fx, c.ayz), fy, std::fma(c.axz, fx, c.az));
     grad = V3<FLOAT>(gx * (FLOAT) g.s[0], gy * (FLOAT) g.s[1], gz * (FLOAT) g.s[2]);
 }
 
@@ -588,12 +595,11 @@ template <typename FLOAT> struct Rif {
         const FLOAT fx = px - x1, fy = py - y1, fz = pz - z1;
         const float *D = (const float *) G.data;
         const int base = (z1 * G.res[1] + y1) * G.res[0] + x1, sy = G.res[0], sz = G.res[0] * G.res[1];
-        const FLOAT d000 = D[base], d001 = D[base + 1], d010 = D[base + sy], d011 = D[base + sy + 1],
-                    d100 = D[base + sz], d101 = D[base + sz + 1], d110 = D[base + sz + sy], d111 = D[base + sz + sy + 1];
+        const TriCoeff<FLOAT> c(D, base, sy, sz);
         const FLOAT sx = G.s[0], syy = G.s[1], szz = G.s[2];
-        const FLOAT hxy = ((d011 - d010 - d001 + d000) * (1 - fz) + (d111 - d110 - d101 + d100) * fz) * sx * syy;
-        const FLOAT hyz = ((d110 - d100 - d010 + d000) * (1 - fx) + (d111 - d101 - d011 + d001) * fx) * syy * szz;
-        const FLOAT hzx = ((d101 - d100 - d001 + d000) * (1 - fy) + (d111 - d110 - d011 + d010) * fy) * szz * sx;
+        const FLOAT hxy = std::fma(c.axyz, fz, c.axy) * sx * syy;          /* the mixed second derivatives of the monomial form */
+        const FLOAT hyz = std::fma(c.axyz, fx, c.ayz) * syy * szz;
+        const FLOAT hzx = std::fma(c.axyz, fy, c.axz) * szz * sx;
         H[1] = H[3] = hxy; H[5] = H[7] = hyz; H[2] = H[6] = hzx;
     }
 };
@@ -1909,7 +1915,7 @@ struct Walker {
                         const Float tHit = S.intersectShape(ro, rd, 0.0f, std::numeric_limits<Float>::infinity());
                         itsT = tHit >= 0 ? tHit : 0;
                     }
-                    if (!medium && !P.calibrated_transient) plen += el(itsT);
+                    if (!medium && !(P.calibrated_transient && P.decomposition == 1)) plen += el(itsT);
                     const Vec x = ro + rd * itsT;
                     const Vec n = S.shapeNormal(x);
                     const Float cosI = dot(-rd, n);            /* Frame::cosTheta(bRec.wi), wi = -ray.d */
@@ -1943,7 +1949,7 @@ struct Walker {
                 } else {
                 /* null BSDF (shape.cpp:48-70): no NEE (not smooth), pass-through sample */
                 (void) rng.next1D(); (void) rng.next1D();     /* bsdf->sample(bRec, pdf, rRec.nextSample2D()) */
-                if (!medium && !P.calibrated_transient) plen += el(itsT);  /* the camera edge (bdpt_proc.cpp:163-176: startIndex 2 | 3) */
+                if (!medium && !(P.calibrated_transient && P.decomposition == 1)) plen += el(itsT);  /* the camera edge (bdpt_proc.cpp:163-176: startIndex 2 | 3) */
                 ro = ro + rd * itsT;
                 medium = !medium;
                 emitted = !scattered;                         /* volpath.cpp:293-301 */

@@ -2,7 +2,7 @@
 GPU vs the oracle per path, and the SDF-grid sphere against the analytic sphere boundary."""
 import numpy as np
 import pytest
-from mitsubaer_amd import params as P, synth
+from mitsubaer_amd import params as P, synth, capi
 from tests import scenes
 
 pytestmark = pytest.mark.gpu
@@ -42,6 +42,25 @@ def test_sdf_boundary_paths_match_oracle(ctx, orc, name):
         close = np.abs(a - b).max(2) <= 1e-4 * np.maximum(1.0, np.abs(b).max(2))
         assert close.mean() > (0.92 if name.startswith("point_curved") else 0.99), close.mean()
     for v in vols:
+        v.destroy()
+
+
+@pytest.mark.parametrize("layout,buffer_loads", [(capi.LAYOUT_BRICK27, 1), (capi.LAYOUT_BRICK27, 0), (capi.LAYOUT_CELL8, 0), (capi.LAYOUT_AUTO, 1)])
+@pytest.mark.parametrize("name", ["curved_null_rk4", "aggressive_dielectric_verlet", "point_curved_sdf"])
+def test_sdf_boundary_with_the_record_layouts_of_large_fields(ctx, orc, name, layout, buffer_loads):
+    """the signed-distance boundary with the RIF in BRICK27 records (buffer and global loads) and CELL8 records read with global loads (what a
+    field of 4 GiB or more selects; option buffer_loads = 0 selects it for a small one): per path against the oracle, and no bit different
+    from the dense layout where no connection solver runs"""
+    p = CASES[name]()
+    with ctx.options(buffer_loads=buffer_loads):
+        sc, vols = ctx.upload_scene(p, layout=layout)
+        a = ctx.render_paths(sc, 0, seed=3)
+    b = orc.render_paths(p, 0, 3)
+    close = np.abs(a - b).max(2) <= 1e-4 * np.maximum(1.0, np.abs(b).max(2))
+    assert close.mean() > (0.92 if name.startswith("point_curved") else 0.99), close.mean()
+    sd, vd = ctx.upload_scene(p, layout=capi.LAYOUT_DENSE)
+    assert np.array_equal(ctx.render_paths(sd, 0, seed=3), a)
+    for v in vols + vd:
         v.destroy()
 
 

@@ -92,6 +92,20 @@ def test_bounce_film_matches_oracle(ctx, orc, name):
         v.destroy()
 
 
+def test_bounce_film_ignores_calibrated_transient_on_the_gpu(ctx, orc):
+    """bdpt_proc.cpp:179-187: a bounce film counts the camera edge whatever `calibratedTransient` says (K_gen and K_event gate the flag on the
+    transient decomposition)"""
+    p = scenes.curved_scene(N=24, w=24, h=20, rfilter=P.FILTER_BOX, rfilter_param=0.5, decomposition=P.DECOMPOSITION_BOUNCE, min_bound=0.0, max_bound=16.0, bin_width=1.0)
+    sc, vols = ctx.upload_scene(p)
+    sc2, vols2 = ctx.upload_scene(p.copy(calibrated_transient=True))
+    a = ctx.render_to_host(sc, 0, 6, seed=4); b = ctx.render_to_host(sc2, 0, 6, seed=4)
+    np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+    ref, _ = orc.render(p.copy(calibrated_transient=True), 0, 6, 4)
+    assert _rel_l2(a[..., :-2], ref[..., :-2]) < 2e-2
+    for v in vols + vols2:
+        v.destroy()
+
+
 def test_frames_sum_to_steady_state_on_the_gpu(ctx):
     p = scenes.curved_scene(N=24, w=24, h=20, rfilter=P.FILTER_BOX, rfilter_param=0.5, max_depth=10)
     pt = p.copy(decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=0.0, max_bound=64.0, bin_width=0.5)

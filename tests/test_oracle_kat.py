@@ -479,6 +479,21 @@ def test_bounce_frames_are_bounce_orders(orc, kind):
         assert hi[:, :, t + 1].sum() > 0 and hi[:, :, t + 2:].sum() == 0
 
 
+def test_bounce_film_ignores_calibrated_transient(orc):
+    """Known answer from the reference's code: the EBounce loop runs from i = 2 whatever m_calibratedTransient says (bdpt_proc.cpp:179-187),
+    only the ETransient branch starts at 3 (:163-170) -- so `calibratedTransient` changes no bin of a bounce film, and shifts a transient
+    film by the camera edge."""
+    base = scenes.curved_scene(N=16, w=8, h=8).copy(rfilter=P.FILTER_BOX, rfilter_param=0.5, max_depth=6)
+    pb = base.copy(decomposition=P.DECOMPOSITION_BOUNCE, min_bound=0.0, max_bound=12.0, bin_width=1.0)
+    f0, _ = orc.render(pb, 0, 16, 5)
+    f1, _ = orc.render(pb.copy(calibrated_transient=True), 0, 16, 5)
+    np.testing.assert_array_equal(f0, f1)
+    pt = base.copy(decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=0.0, max_bound=12.0, bin_width=1.0)
+    t0, _ = orc.render(pt, 0, 16, 5)
+    t1, _ = orc.render(pt.copy(calibrated_transient=True), 0, 16, 5)
+    assert not np.array_equal(t0, t1)
+
+
 def test_transient_single_scatter_profile_matches_quadrature(orc):
     """Time-resolved known answer: homogeneous isotropic medium, point emitter, exactly one scattering event.  A path that
     scatters at depth t along the central camera ray has optical length 2 + t + d(t) (camera edge 2, n = 1), so frame k holds
