@@ -180,17 +180,33 @@ __device__ __forceinline__ void queue_push(const SegQueue &q, uint32_t row, bool
 //    the lanes of a wave park at about the same trip of K_march's loop instead of idling until the slowest one has.
 #define MER_EV_CLASSES 4
 #define MER_MQ_CLASSES 8
-#ifndef MER_CQ_CLASSES
-#define MER_CQ_CLASSES 16        // 8 / 16 / 32 classes: configs[4] 27.7 / 28.5 / 28.4 Mpaths/s (profiles/round2/ab_connect_waves.txt)
-#endif
-// class of a pending connection: the length of the rays its solver traces (the chord to the emitter over the size of the shape), longest first
-__device__ __forceinline__ int connect_class(const Params &P, f3 ps) {
+// Pending connections are sorted by WHAT their next solver unit does and by HOW LONG it will run (one segment per class):
+//   group 0 (classes 0 .. 19):  a shooting ray with its sensitivity matrices (Connector::computefdf: phases NEW / EVAL0 / TRIAL)
+//   group 1 (classes 20 .. 25): the arc / optical length of the converged ray (path_lengths: PATHLEN, a plain Verlet march)
+//   group 2 (classes 26 .. 31): the luminaire sample along the found ray (connection_value: OK -- RK4 steps + delta tracking)
+// and inside a group by the predicted number of steps, longest first: the ray runs to its closest approach to the emitter, i.e. over the
+// projection of the chord p1 -> p2 on its launch direction (a NEW connection draws that direction in its first unit: cos = the next number
+// of the path's sampler stream, which K_event peeks without consuming).  Round 2 sorted by the chord alone: every wave then held all three
+// kinds of unit and ran the three loops one after another with the other lanes masked (and a first shot, whose direction is random in the
+// hemisphere about the chord, ran half as long on average as the trials beside it).
+#define MER_CQ_CLASSES 32
+#define MER_CQ_G0 20
+#define MER_CQ_G1 6
+#define MER_CQ_G2 6
+__device__ __forceinline__ int connect_class(const Params &P, int group, float predicted_len) {
     const mer_scene_desc &S = P.sc;
-    const f3 d(S.point_position[0] - ps.x, S.point_position[1] - ps.y, S.point_position[2] - ps.z);
     float diag2 = 4.0f * S.sph_radius * S.sph_radius;
     if (S.boundary != MER_BOUNDARY_SPHERE) { diag2 = 0; for (int k = 0; k < 3; k++) diag2 += (S.bmax[k] - S.bmin[k]) * (S.bmax[k] - S.bmin[k]); }
-    const float f = sqrtf(dot(d, d) * __builtin_amdgcn_rcpf(diag2)) * (float) (2 * MER_CQ_CLASSES);      // chords beyond half the diagonal share class 0
-    return max(0, MER_CQ_CLASSES - 1 - (int) f);
+    const int n = group == 0 ? MER_CQ_G0 : (group == 1 ? MER_CQ_G1 : MER_CQ_G2), first = group == 0 ? 0 : (group == 1 ? MER_CQ_G0 : MER_CQ_G0 + MER_CQ_G1);
+    const float f = fmaxf(predicted_len, 0.0f) * __builtin_amdgcn_rsqf(diag2) * (float) (2 * n);      // lengths beyond half the diagonal share the group's first class
+    return first + max(0, n - 1 - (int) fminf(f, (float) n));
+}
+// group and predicted length of the unit a parked solver state will run next
+__device__ __forceinline__ int connect_class_of(const Params &P, const ConnState &S, f3 ps) {
+    const f3 d(P.sc.point_position[0] - ps.x, P.sc.point_position[1] - ps.y, P.sc.point_position[2] - ps.z);
+    if (S.phase == CP_OK) return connect_class(P, 2, S.dist);
+    const f3 dir = S.phase == CP_TRIAL ? S.xn : (S.phase == CP_PATHLEN ? S.dir : S.x);
+    return connect_class(P, S.phase == CP_PATHLEN ? 1 : 0, dot(d, dir) * __builtin_amdgcn_rsqf(dot(dir, dir)));
 }
 template <int NCLS>
 __device__ __forceinline__ void queue_push_class(const SegQueue &q, uint32_t row, bool pred, uint32_t i, int cls) {
@@ -554,7 +570,12 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             // own (K_connect) in which every lane solves one; the path resumes at EV_PHASE2 in the next pass.
             if (EXTRA && hasPoint && ev == EV_PHASE) {
                 if (CURVED) {                        // park the slot: K_connect takes the connection from here (state CP_NEW)
-                    connecting = true; cq_class = connect_class(P, ps);
+                    connecting = true;
+                    {   // its first unit shoots along a direction whose cosine to the chord is the NEXT sampler number (Connector::uniform_sample): peek
+                        Rng peek = rng; const float cosChord = peek.next1D();
+                        const f3 dch(S.point_position[0] - ps.x, S.point_position[1] - ps.y, S.point_position[2] - ps.z);
+                        cq_class = connect_class(P, 0, cosChord * sqrtf(dot(dch, dch)));
+                    }
                     P.cstate[(size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots) * MER_CSTATE_WORDS + MER_CSTATE_WORDS - 1] = (uint32_t) CP_NEW << 15;
                     break;
                 }
@@ -719,7 +740,7 @@ __global__ void MER_CONNECT_BOUNDS connect_stage_kernel(const Params P, uint32_t
             K.unit(S, ps, pp, rng, rev);
             usteps = K.nsteps;
             if (S.phase == CP_FAIL) finished = true;            // no connection: the luminaire sample is zero
-            else { S.store(cs); again = true; cls = connect_class(P, ps); }
+            else { S.store(cs); again = true; cls = connect_class_of(P, S, ps); }
         }
         SLOT(H_RNG_LO) = (uint32_t) rng.state; SLOT(H_RNG_HI) = (uint32_t) (rng.state >> 32);
     }
