@@ -27,7 +27,94 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (guides/MI355X_MICROARCH.md); ~
 # wave64 VALU instructions the chip can issue per second: 256 CUs x 4 SIMDs x 2.4 GHz / 2.3 cycles per independent v_fma_f32
 # (profiles/round1/ubench_valu_issue_rate.txt: 2.25-2.40 cycles measured; a DEPENDENT v_fma_f32 issues every 4.2-4.4 cycles)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.3
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round2", "hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "round3", "hbm_traffic.json")
+PMC_PASSES = {      # one rocprofv3 --pmc pass each (the counters of a pass must fit the hardware's counter slots; gpurun allows --pmc with --kernel-trace only)
+    "rd": "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum",
+    "write": "WRITE_SIZE TCC_EA0_RDREQ_DRAM_sum",
+    "sq": "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY",
+}
+
+
+def source_hash():
+    """sha256 over the kernel sources (csrc/*.hpp, *.hip): a committed counter pass is only valid for the kernels it was taken on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "mitsubaer_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(fn).encode()); h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_sums(outdir, family="march_kernel"):
+    """{counter: sum over the dispatches of the kernel family} from the counter_collection CSV of one rocprofv3 pass"""
+    import csv
+    import glob
+    import re
+    acc = {}
+    files = sorted(glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    n = 0
+    for fn in files[-1:]:
+        for r in csv.DictReader(open(fn)):
+            m = re.match(r"(?:void )?(?:mer::)?([A-Za-z_0-9]+)", r["Kernel_Name"])
+            if m and m.group(1) == family:
+                acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"]); n += 1
+    return acc if n else None
+
+
+def live_pmc(workload, res, size, spp, layout, options, budget_s=150.0):
+    """Counter passes of THIS workload taken in THIS run: for every entry of PMC_PASSES one child process `rocprofv3 --pmc <counters>
+    --kernel-trace -- python3 bench.py <one single-pipeline step>`, started before this process touches the GPU (a GPU process must not
+    exec; and the profiler's counters need the chip to themselves).  Returns the traffic entry (as profiles/round3/hbm_traffic.json
+    holds them) or (None, reason)."""
+    import shutil
+    import tempfile
+    if os.environ.get("MER_BENCH_PMC_CHILD") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return None, "this process is itself being profiled"
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    t0 = time.time()
+    got = {}
+    child = None
+    opts = ",".join(filter(None, [options, "pipes=1"]))
+    for name, ctrs in PMC_PASSES.items():
+        left = budget_s - (time.time() - t0)
+        if left < 20:
+            return None, "counter passes exceeded their %d s budget" % budget_s
+        out = tempfile.mkdtemp(prefix="mer_pmc_%s_" % name, dir="/tmp")
+        cmd = [exe, "--pmc"] + ctrs.split() + ["--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+               "--workload", workload, "--res", str(res), "--size", str(size), "--spp", str(spp), "--layout", layout, "--steps", "1", "--warmup", "0",
+               "--no-cpu-baseline", "--no-solo-step", "--no-target-512", "--no-live-pmc", "--options", opts]
+        env = dict(os.environ); env["TMPDIR"] = "/tmp"; env["MER_BENCH_PMC_CHILD"] = "1"
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(out, ignore_errors=True)
+            return None, "counter pass '%s' timed out" % name
+        sums = pmc_sums(out)
+        shutil.rmtree(out, ignore_errors=True)
+        if r.returncode != 0 or not sums:
+            return None, "counter pass '%s' failed (rc %d): %s" % (name, r.returncode, r.stderr.decode(errors="replace")[-200:])
+        got[name] = sums
+        if child is None:
+            try:
+                child = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            except Exception:
+                return None, "counter pass '%s' printed no bench line" % name
+    c = child["counters_per_step"]
+    steps = c["eikonal_steps"] if c["eikonal_steps"] > 0 else c["tentative_collisions"]
+    wave_steps = c["lane_slots"] / 64.0
+    rd, wr, sq = got["rd"], got["write"], got["sq"]
+    read_b = 128 * rd.get("TCC_EA0_RDREQ_128B_sum", 0.0) + 64 * rd.get("TCC_EA0_RDREQ_64B_sum", 0.0) + 32 * rd.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+    write_b = 1024 * wr.get("WRITE_SIZE", 0.0)
+    return {"method": "rocprofv3 --pmc passes taken by this bench run (one single-pipeline step each, child processes): read = 128*TCC_EA0_RDREQ_128B + "
+                      "64*RDREQ_64B + 32*RDREQ_32B, write = WRITE_SIZE (KiB); fabric bytes, Infinity-Cache hits included",
+            "live": True, "seconds": time.time() - t0, "layout": layout, "options": opts, "source_hash": source_hash(),
+            "unit_steps": steps, "wave_steps": wave_steps, "read_bytes": read_b, "write_bytes": write_b,
+            "hbm_bytes_per_eikonal_step": (read_b + write_b) / max(steps, 1.0),
+            "valu_inst_per_wave_step": sq.get("SQ_INSTS_VALU", 0.0) / max(wave_steps, 1.0),
+            "vmem_rd_inst_per_wave_step": sq.get("SQ_INSTS_VMEM_RD", 0.0) / max(wave_steps, 1.0),
+            "wave_cycles_waiting_for_issue": sq.get("SQ_WAIT_INST_ANY", 0.0) / max(sq.get("SQ_WAVE_CYCLES", 0.0), 1.0)}, None
 
 
 def workload_tag(name, res, size):
@@ -127,16 +214,24 @@ def cpu_baseline(p, target_seconds=20.0):
             "sample": "%dx%d x %d spp of the same scene (%.1f s), oracle/libmer_oracle.so fp32, std::thread over rows" % (p.width, p.height, spp, dt)}
 
 
-def measured_traffic(tag):
-    """HBM bytes per eikonal step of K_march for this workload, from the committed rocprofv3 --pmc passes (they cannot be counted
-    inside this process): profiles/round2/hbm_traffic.json, written by scratch/pmc_traffic.py."""
+def committed_traffic(tag, layout, options):
+    """Fallback when the counters could not be taken in this run: the committed pass of this workload (profiles/round3/hbm_traffic.json,
+    scratch/pmc_traffic.py) -- used only if it was taken on THESE kernel sources, THIS RIF layout and THESE options; (entry, None) or (None, why)."""
     try:
-        return json.load(open(TRAFFIC_FILE)).get(tag)
+        e = json.load(open(TRAFFIC_FILE)).get(tag)
     except Exception:
-        return None
+        e = None
+    if not e:
+        return None, "no counter pass committed for %s" % tag
+    want = ",".join(filter(None, [options, "pipes=1"]))
+    if e.get("source_hash") != source_hash():
+        return None, "the committed counter pass of %s was taken on other kernel sources (%s, now %s)" % (tag, e.get("source_hash"), source_hash())
+    if e.get("layout") != layout or e.get("options") != want:
+        return None, "the committed counter pass of %s was taken with layout %s, options %s" % (tag, e.get("layout"), e.get("options"))
+    return e, None
 
 
-def roofline_block(ctx, capi, p, tag, solo, timed, layout_name):
+def roofline_block(ctx, capi, p, tag, solo, timed, layout_name, traffic=None, traffic_why=None):
     """roofline of the dominant kernel (K_march).  `solo` = (passes, march_ms, event_ms, counters, wall_s) of one step rendered as ONE
     pipeline -- its launches have the chip to themselves, so bytes / duration is a chip-level rate; `timed` = the same for the timed
     region's average step (concurrent pipelines: only the aggregate over the step means anything there)."""
@@ -145,9 +240,11 @@ def roofline_block(ctx, capi, p, tag, solo, timed, layout_name):
     b_alg = algorithmic_bytes(c1, p) - 40.0 * paths                       # K_march performs every field fetch; the film write is K_event's
     launches = max(n1, 1)
     launch_ms = m1 / launches
-    tr = measured_traffic(tag)
+    tr = traffic
+    curved = p.rif_mode != 0
+    unit_steps = steps if curved else tent           # the unit the counter bytes are quoted per: eikonal steps (curved rays) or tentative collisions (straight)
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "kernel": "mer::march_kernel<curved, %s trilinear, rk4, grid>" % layout_name,
+           "kernel": ("mer::march_kernel<curved, %s trilinear, rk4, grid>" % layout_name) if curved else "mer::march_kernel<straight, grid sigma_t (cell8 records)>",
            "kernel_avg_launch_ms": launch_ms, "launches_per_step": n1, "kernel_ms_per_step": m1, "event_kernel_ms_per_step": e1,
            "step_wall_ms": wall1 * 1e3, "pipelines": 1,
            "what": "one untimed step rendered as ONE pipeline (option pipes = 1): K_march's launches have the chip to themselves, HIP events on the launch stream",
@@ -156,17 +253,21 @@ def roofline_block(ctx, capi, p, tag, solo, timed, layout_name):
            "counters_per_step": {"paths": paths, "eikonal_steps": steps, "tentative_collisions": tent, "real_collisions": float(c1[capi.C_REAL])},
            "active_lane_fraction": float(c1[capi.C_ACTIVE_LANES] / max(c1[capi.C_LOOP_ITERS], 1.0))}
     if tr:
-        # measured HBM-side bytes per eikonal step (rocprofv3 --pmc, TCC_EA0_RDREQ by request size + WRREQ), scaled by this run's steps
-        hbm = tr["hbm_bytes_per_eikonal_step"] * steps
+        # fabric-side bytes per unit step (rocprofv3 --pmc: TCC_EA0_RDREQ by request size + WRITE_SIZE) x this step's unit steps
+        hbm = tr["hbm_bytes_per_eikonal_step"] * unit_steps
         out.update({"achieved": hbm / max(m1, 1e-9) / 1e6, "traffic": hbm / launches,
-                    "reuse_factor": b_alg / max(hbm, 1.0),
-                    "traffic_source": "%s [%s]: %s" % (os.path.relpath(TRAFFIC_FILE, ROOT), tag, tr.get("method", ""))})
+                    "reuse_factor": b_alg / max(hbm, 1.0), "bytes_per_unit_step": tr["hbm_bytes_per_eikonal_step"],
+                    "traffic_source": ("counter passes taken inside this run (%.0f s): " % tr.get("seconds", 0) if tr.get("live") else
+                                       "extrapolated from the committed counter pass %s [%s] (same kernel sources %s, layout, options): " % (os.path.relpath(TRAFFIC_FILE, ROOT), tag, tr.get("source_hash")))
+                                      + tr.get("method", "")})
         out["frac"] = out["achieved"] / HBM_PEAK_GBS
     else:
-        # no counter pass committed for this workload: the algorithmic rate is an UPPER bound of the HBM rate only when nothing is
-        # reused, which is not the case here (register cell cache, L2, Infinity Cache) -- report no fraction rather than a wrong one
-        out.update({"achieved": None, "frac": None, "traffic": None, "traffic_source": "no rocprofv3 --pmc pass committed for %s" % tag})
-    if tr and tr.get("valu_inst_per_wave_step"):
+        # no valid counter pass: the algorithmic rate is an UPPER bound of the HBM rate only when nothing is reused, which is not the case
+        # here (register cell cache, L2, Infinity Cache) -- report no fraction rather than a wrong one
+        out.update({"achieved": None, "frac": None, "traffic": None, "traffic_source": traffic_why or "no counter pass"})
+    out["note"] = ("achieved / traffic are FABRIC bytes (what L2 requests beyond itself, Infinity-Cache hits included), an upper bound of the DRAM bytes: at 256^3 the "
+                   "working set (~0.3 GiB) is about the size of the 256 MiB Infinity Cache, so the DRAM share is unknown there; the 512^3 block (2.5 GiB) can be read as HBM")
+    if tr and tr.get("valu_inst_per_wave_step") and curved:
         wave_steps = float(c1[capi.C_LOOP_ITERS]) / 64.0
         ginst = tr["valu_inst_per_wave_step"] * wave_steps / max(m1, 1e-9) / 1e6
         out["valu"] = {"inst_per_wave_step": tr["valu_inst_per_wave_step"], "achieved_Ginst_s": ginst, "peak_Ginst_s": VALU_PEAK_GINST,
@@ -180,7 +281,7 @@ def roofline_block(ctx, capi, p, tag, solo, timed, layout_name):
               "launches": n_pass, "algorithmic_bytes": b_step, "algorithmic_GBps": b_step / max(k_ms, 1e-9) / 1e6,
               "note": "timed region: concurrent pipelines stretch one another's launches, so only the aggregate over the step is a chip-level figure"}
         if tr:
-            hb = tr["hbm_bytes_per_eikonal_step"] * float(counters[capi.C_STEPS])
+            hb = tr["hbm_bytes_per_eikonal_step"] * float(counters[capi.C_STEPS] if curved else counters[capi.C_TENTATIVE])
             ws.update({"hbm_bytes": hb, "achieved": hb / max(k_ms, 1e-9) / 1e6, "frac": hb / max(k_ms, 1e-9) / 1e6 / HBM_PEAK_GBS})
         out["whole_step"] = ws
     return out
@@ -214,11 +315,31 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-target-512", action="store_true", help="skip the 512^3 block of the default run")
     ap.add_argument("--no-solo-step", action="store_true", help="skip the extra single-pipeline step (profiled runs)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not take the roofline's counter passes (child rocprofv3 runs) inside this run; fall back to the committed pass")
     ap.add_argument("--options", default="", help="mer_context_set_option pairs, e.g. pipes=1,ksteps=96")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    if args.layout == "auto":
+        args.layout = "brick27" if args.res ** 3 <= 1 << 28 else "cell8"
+    # the roofline's byte counters, taken by child processes BEFORE this one touches the GPU (N = 1 only)
+    single = args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1
+    traffic = traffic_why = traffic5 = traffic5_why = None
+    want_512 = args.workload == "cfg3" and args.res == 256 and single and not args.no_target_512 and not args.no_cpu_baseline
+    if single and not args.no_solo_step:
+        if not args.no_live_pmc:
+            traffic, traffic_why = live_pmc(args.workload, args.res, args.size, args.spp, args.layout, args.options)
+            if want_512 and traffic:
+                traffic5, traffic5_why = live_pmc("cfg3", 512, args.size, args.spp, "brick27", args.options, budget_s=120.0)
+        if not traffic:
+            why_live = traffic_why or "live counter passes disabled (--no-live-pmc)"
+            traffic, traffic_why = committed_traffic(workload_tag(args.workload, args.res, args.size), args.layout, args.options)
+            traffic_why = "%s; %s" % (why_live, traffic_why) if traffic_why else None
+        if want_512 and not traffic5:
+            why_live = traffic5_why or "live counter passes not taken"
+            traffic5, traffic5_why = committed_traffic(workload_tag("cfg3", 512, args.size), "brick27", args.options)
+            traffic5_why = "%s; %s" % (why_live, traffic5_why) if traffic5_why else None
 
     import numpy as np
     import torch
@@ -242,8 +363,6 @@ def main():
     for kv in filter(None, args.options.split(",")):
         k, v = kv.split("="); ctx.set_option(k, int(v))
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    if args.layout == "auto":
-        args.layout = "brick27" if args.res ** 3 <= 1 << 28 else "cell8"
     layout = {"cell8": capi.LAYOUT_CELL8, "brick27": capi.LAYOUT_BRICK27, "brick125": capi.LAYOUT_BRICK125, "dense": capi.LAYOUT_DENSE}[args.layout]
     sc, vols = upload(ctx, args.workload, args.res, p, layout)
     film = torch.zeros((p.height, p.width, 5), dtype=torch.float32, device=dev)
@@ -334,10 +453,10 @@ def main():
                                   "connect_units": counters[capi.C_CONNECT_UNITS] / max(args.steps, 1), "connect_steps": counters[capi.C_CONNECT_STEPS] / max(args.steps, 1),
                                   "connect_lane_slots": counters[capi.C_CONNECT_LANE_SLOTS] / max(args.steps, 1)},
         }
-        if solo is not None and p.rif_mode != 0:
+        if solo is not None:
             timed = (float(np.mean(kernel_ms)), float(np.mean(march_ms)), float(np.mean(event_ms)), float(np.mean(passes)),
                      counters / max(args.steps, 1), pipes)
-            out["roofline"] = roofline_block(ctx, capi, p, tag, solo, timed, args.layout)
+            out["roofline"] = roofline_block(ctx, capi, p, tag, solo, timed, args.layout, traffic, traffic_why)
         if not args.no_cpu_baseline and world == 1:
             if p.density is None:
                 pc, _ = scene_params(args.workload, args.res, args.size, with_fields=True)
@@ -345,7 +464,7 @@ def main():
                 pc = p
             out["cpu_baseline"] = cpu_baseline(pc, args.cpu_seconds)
         # the north star's target volume (512^3) in the same run: two steps + its CPU baseline on a bounded sample
-        if (args.workload == "cfg3" and args.res == 256 and world == 1 and not args.no_target_512 and not args.no_cpu_baseline):
+        if want_512:
             for v in vols:
                 v.destroy()
             vols = []
@@ -362,7 +481,7 @@ def main():
                 n5, m5, e5 = ctx.last_render_stats(); c5 = ctx.counters().astype(np.float64)
             t512 = {"workload": d5 + ", %d^2 x %d spp" % (args.size, args.spp), "value": p5.width * p5.height * args.spp / dt5 / 1e6, "unit": "Mpaths/s",
                     "ms_per_step": dt5 * 1e3, "steps": 2,
-                    "roofline": roofline_block(ctx, capi, p5, workload_tag("cfg3", 512, args.size), (n5, m5, e5, c5, w5), None, "brick27")}
+                    "roofline": roofline_block(ctx, capi, p5, workload_tag("cfg3", 512, args.size), (n5, m5, e5, c5, w5), None, "brick27", traffic5, traffic5_why)}
             pc5, _ = scene_params("cfg3", 512, args.size, with_fields=True)
             t512["cpu_baseline"] = cpu_baseline(pc5, 12.0)
             t512["gpu_over_cpu"] = t512["value"] / t512["cpu_baseline"]["value"]

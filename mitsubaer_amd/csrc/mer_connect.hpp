@@ -40,18 +40,6 @@ __device__ __forceinline__ m33 mul(const m33 &a, const m33 &b) {
         for (int j = 0; j < 3; j++) { float s = 0; for (int k = 0; k < 3; k++) s += a.m[i][k] * b.m[k][j]; r.m[i][j] = s; }
     return r;
 }
-// H dp for the Hessian of a TRILINEAR interpolant: its diagonal is identically zero (the interpolant is linear along every axis), so the three
-// products with it are left out -- bit-identical to mul() on finite input (0 * b adds +-0 to a sum that starts at +0), a third fewer operations
-__device__ __forceinline__ m33 mul_zero_diag(const m33 &a, const m33 &b) {
-    m33 r;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        r.m[0][j] = a.m[0][1] * b.m[1][j] + a.m[0][2] * b.m[2][j];
-        r.m[1][j] = a.m[1][0] * b.m[0][j] + a.m[1][2] * b.m[2][j];
-        r.m[2][j] = a.m[2][0] * b.m[0][j] + a.m[2][1] * b.m[1][j];
-    }
-    return r;
-}
 __device__ __forceinline__ m33 scale(const m33 &a, float s) { m33 r;
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -201,24 +189,46 @@ template <int RIF, int BND = 0, bool XC = true> struct Connector {
     }
     __device__ float rif_value(f3 p) const { float n; f3 g; rif_value_grad<RIF>(P.rif, cc, p, n, g); return n; }
 
-    // er_derivativestep (:798-814)
+    // er_derivativestep (:798-814): one velocity-Verlet step of the ray with its sensitivities dp/dv0, dv/dv0.  The solver's iterates are not
+    // pinned to the reference (its minimiser is Ceres), so the step's ARITHMETIC is defined here, in fused form, and restated identically in
+    // the oracle: (v (x) G) dp is formed as v (x) (G^T dp) -- 9 + 9 multiply-adds instead of a 3x3 product of an outer product -- and every
+    // accumulation is a fused multiply-add.  ~200 VALU instructions per step against ~350 for the literal matrix expression.
+    //   H dp: s = H[i][0] dp[0][j]; s = fma(H[i][1], dp[1][j], s); s = fma(H[i][2], dp[2][j], s).  The Hessian of a TRILINEAR interpolant has a
+    //   zero diagonal (the interpolant is linear along every axis): its term is skipped, which leaves every result bit for bit (fma(0, b, s) = s).
+    __device__ __forceinline__ void add_hess_dp(m33 &dv, const m33 &H, const m33 &dp, float t) const {
+        constexpr bool trilinear = RIF != MER_RIF_BSPLINE3 && RIF != RIFK_ACOUSTIC;
+        const bool zero_diag = trilinear && !(rif_affine_capable<RIF>() && P.rif.affine);       // a grid with a `toWorld` is rotated: full product
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float sum;
+                if (zero_diag) {
+                    const int k0 = i == 0 ? 1 : 0, k1 = i == 2 ? 1 : 2;
+                    sum = __builtin_fmaf(H.m[i][k1], dp.m[k1][j], H.m[i][k0] * dp.m[k0][j]);
+                } else sum = __builtin_fmaf(H.m[i][2], dp.m[2][j], __builtin_fmaf(H.m[i][1], dp.m[1][j], H.m[i][0] * dp.m[0][j]));
+                dv.m[i][j] = __builtin_fmaf(t, sum, dv.m[i][j]);
+            }
+    }
     __device__ void dstep(f3 &p, f3 &v, m33 &dp, m33 &dv, float h) const {
         float n; f3 G; m33 H;
+        const float t = 0.5f * h;
         rif_value_grad_hess<RIF>(P.rif, cc, p, n, G, H);
-        v = v + 0.5f * h * G;
-        dv = add(dv, scale(hess_mul(H, dp), 0.5f * h));
+        v = fma3(t, G, v);
+        add_hess_dp(dv, H, dp, t);
         p = p + h * v / n;
         rif_value_grad_hess<RIF>(P.rif, cc, p, n, G, H);
-        const float invn = 1.0f / n;
-        dp = add(dp, scale(add(scale(mul(outer(v, G), dp), -invn * invn), scale(dv, invn)), h));
-        v = v + 0.5f * h * G;
-        dv = add(dv, scale(hess_mul(H, dp), 0.5f * h));
-    }
-    // H dp: the trilinear kinds' Hessian has a zero diagonal (a grid with a `toWorld` is rotated: full product)
-    __device__ __forceinline__ m33 hess_mul(const m33 &H, const m33 &dp) const {
-        constexpr bool trilinear = RIF != MER_RIF_BSPLINE3 && RIF != RIFK_ACOUSTIC;
-        if (trilinear && !(rif_affine_capable<RIF>() && P.rif.affine)) return mul_zero_diag(H, dp);
-        return mul(H, dp);
+        const float invn = 1.0f / n, c = -(invn * invn);
+        const float V[3] = {c * v.x, c * v.y, c * v.z};
+        float w[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) w[j] = __builtin_fmaf(G.z, dp.m[2][j], __builtin_fmaf(G.y, dp.m[1][j], G.x * dp.m[0][j]));       // G^T dp
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) dp.m[i][j] = __builtin_fmaf(h, __builtin_fmaf(V[i], w[j], invn * dv.m[i][j]), dp.m[i][j]);
+        v = fma3(t, G, v);
+        add_hess_dp(dv, H, dp, t);
     }
     // boundaryVelocity (:1040-1055): Snell's law for the optical momentum v at a surface with unit normal N, index ni on the ray's side and
     // ne beyond (total internal reflection when the root is imaginary)

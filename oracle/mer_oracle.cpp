@@ -1099,18 +1099,31 @@ template <typename FLOAT> struct Connector {
         if (S.s.boundary == ORC_BOUNDARY_SPHERE) diag = 4 * S.s.sph_radius * S.s.sph_radius;
         return std::min(100000, (int) (4 * std::sqrt(diag) / S.s.stepsize) + 16);
     }
-    /* :798-814 */
+    /* :798-814.  The solver's iterates are not pinned to the reference (Ceres), so the arithmetic of this step is a DEFINITION shared with the
+       HIP kernel (Connector::dstep, csrc/mer_connect.hpp): (v (x) G) dp formed as v (x) (G^T dp), every accumulation a fused multiply-add. */
+    static void addHessDp(M33<FLOAT> &dv, const FLOAT H[9], const M33<FLOAT> &dp, FLOAT t) {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                const FLOAT sum = std::fma(H[3 * i + 2], dp.m[2][j], std::fma(H[3 * i + 1], dp.m[1][j], H[3 * i] * dp.m[0][j]));
+                dv.m[i][j] = std::fma(t, sum, dv.m[i][j]);
+            }
+    }
     void er_derivativestep(V3<FLOAT> &p, V3<FLOAT> &v, M33<FLOAT> &dpdv0, M33<FLOAT> &dvdv0, FLOAT h) const {
-        FLOAT n, invn, H[9]; V3<FLOAT> G;
+        FLOAT n, H[9]; V3<FLOAT> G;
+        const FLOAT t = SplineConst<FLOAT>::half() * h;
         R.valueGradientAndHessian(p, n, G, H, C);
-        v += SplineConst<FLOAT>::half() * h * G;
-        dvdv0 = dvdv0 + (fromH(H) * dpdv0) * (SplineConst<FLOAT>::half() * h);
+        v = V3<FLOAT>(std::fma(t, G.x, v.x), std::fma(t, G.y, v.y), std::fma(t, G.z, v.z));
+        addHessDp(dvdv0, H, dpdv0, t);
         p += h * v / n;
         R.valueGradientAndHessian(p, n, G, H, C);
-        invn = 1 / n;
-        dpdv0 = dpdv0 + ((M33<FLOAT>::outer(v, G) * dpdv0) * (-invn * invn) + dvdv0 * invn) * h;
-        v += SplineConst<FLOAT>::half() * h * G;
-        dvdv0 = dvdv0 + (fromH(H) * dpdv0) * (SplineConst<FLOAT>::half() * h);
+        const FLOAT invn = 1 / n, c = -(invn * invn);
+        const FLOAT Vc[3] = {c * v.x, c * v.y, c * v.z};
+        FLOAT w[3];
+        for (int j = 0; j < 3; j++) w[j] = std::fma(G.z, dpdv0.m[2][j], std::fma(G.y, dpdv0.m[1][j], G.x * dpdv0.m[0][j]));
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) dpdv0.m[i][j] = std::fma(h, std::fma(Vc[i], w[j], invn * dvdv0.m[i][j]), dpdv0.m[i][j]);
+        v = V3<FLOAT>(std::fma(t, G.x, v.x), std::fma(t, G.y, v.y), std::fma(t, G.z, v.z));
+        addHessDp(dvdv0, H, dpdv0, t);
         C.c[ORC_C_STEPS]++;
     }
     /* boundaryVelocity (:1040-1055): Snell's law for the optical momentum at a surface (normal N, index ni on the ray's side, ne beyond) */

@@ -2,7 +2,7 @@
 # The counter passes of one workload (GPU box, repo root): scratch/pmc_all.sh <tag> <bench.py args...>
 # Every pass is the same single-pipeline render (one bench step) under a different counter set; scratch/pmc_traffic.py merges them.
 tag=$1; shift
-B="bench.py $* --steps 1 --warmup 0 --no-cpu-baseline --no-solo-step --options pipes=1"
+B="bench.py $* --steps 1 --warmup 0 --no-cpu-baseline --no-solo-step --no-live-pmc --options pipes=1"
 bash scratch/pmc_pass.sh pmc_${tag}_rd "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" -- $B
 bash scratch/pmc_pass.sh pmc_${tag}_fetch "FETCH_SIZE" -- $B
 bash scratch/pmc_pass.sh pmc_${tag}_write "WRITE_SIZE TCC_EA0_RDREQ_DRAM_sum" -- $B

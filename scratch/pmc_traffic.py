@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Merges the rocprofv3 --pmc passes of one workload (scratch/pmc_all.sh <tag> ...) into profiles/round2/hbm_traffic.json[<bench tag>].
+"""Merges the rocprofv3 --pmc passes of one workload (scratch/pmc_all.sh <tag> ...) into profiles/round3/hbm_traffic.json[<bench tag>].
 
   python scratch/pmc_traffic.py <pass tag> <bench tag> [limiter text]
 
@@ -32,11 +32,15 @@ def sums(kind):
 rd, d_rd = sums("rd"); fe, _ = sums("fetch"); wr, _ = sums("write"); l2, _ = sums("l2"); sq, _ = sums("sq"); sq2, _ = sums("sq2")
 bench = json.loads(open(os.path.join(d_rd, "stdout.txt")).read().strip().splitlines()[-1])
 c = bench["counters_per_step"]
-steps = c["eikonal_steps"]; wave_steps = c["lane_slots"] / 64.0
+steps = c["eikonal_steps"] or c["tentative_collisions"]; wave_steps = c["lane_slots"] / 64.0
 v = lambda d, k: d.get(k, {}).get("sum", 0.0)
 read_b = 128 * v(rd, "TCC_EA0_RDREQ_128B_sum") + 64 * v(rd, "TCC_EA0_RDREQ_64B_sum") + 32 * v(rd, "TCC_EA0_RDREQ_32B_sum")
 write_b = 1024 * v(wr, "WRITE_SIZE")
+sys.path.insert(0, ROOT)
+import bench as _bench
 entry = {
+    # what the pass was taken on: bench.py uses a committed entry only for the same kernel sources, RIF layout and options
+    "source_hash": _bench.source_hash(), "layout": bench["config"]["layout"], "options": "pipes=1",
     "method": "rocprofv3 --pmc, separate passes of one single-pipeline bench step each (scratch/pmc_all.sh %s): read = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B, write = WRITE_SIZE; includes Infinity-Cache hits" % tag,
     "workload": bench["config"]["workload"], "march_launches": rd.get("TCC_EA0_RDREQ_sum", {}).get("dispatches"),
     "eikonal_steps": steps, "wave_steps": wave_steps,
@@ -55,7 +59,7 @@ entry = {
 }
 if limiter:
     entry["limiter"] = limiter
-path = os.path.join(ROOT, "profiles", "round2", "hbm_traffic.json")
+path = os.path.join(ROOT, "profiles", "round3", "hbm_traffic.json")
 allv = json.load(open(path)) if os.path.exists(path) else {}
 allv[btag] = entry
 json.dump(allv, open(path, "w"), indent=1)

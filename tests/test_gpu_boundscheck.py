@@ -98,3 +98,35 @@ def test_connect_leaf_with_degenerate_pairs_stays_in_bounds(cctx):
         assert np.isfinite(out[ok]).all()
         for v in vols:
             v.destroy()
+
+
+def test_configs3_at_1024_cubed_stays_in_bounds(cctx, ctx):
+    """The size where index WIDTH matters (round 2's fault: 2^27 bricks x 32 words overflowed a 32-bit record index): configs[3]'s 1024^3 fields
+    in both record layouts -- CELL8 (32 GiB: global loads, 64-bit addresses) and BRICK27 (16 GiB, 2^32 record words) -- under the bounds-checking
+    build: zero violations, and the same per-path image as the product build.  Also the connection queues with many K_connect launches per pass
+    (event-queue segments are sized by the number of producer launches)."""
+    import bench
+    NN, W = 1024, 1024
+    p, _ = bench.scene_params("cfg4", NN, W, with_fields=False)
+    ref = None
+    for lay in (capi.LAYOUT_CELL8, capi.LAYOUT_BRICK27):
+        sc, vols = bench.upload(cctx, "cfg4", NN, p, lay)
+        a = cctx.render_paths(sc, 0, seed=5)
+        _clean(cctx, "1024^3 layout %d paths" % lay)
+        cctx.render_to_host(sc, 0, 1, seed=5, tile_rank=3, tile_count=8)
+        _clean(cctx, "1024^3 layout %d tile shard" % lay)
+        for v in vols:
+            v.destroy()
+        if ref is None:
+            s2, v2 = bench.upload(ctx, "cfg4", NN, p, lay)
+            ref = ctx.render_paths(s2, 0, seed=5)
+            for v in v2:
+                v.destroy()
+        assert np.array_equal(a, ref)
+    pc = RENDER_CASES["point_curved_cfg5_rgb_albedo_emissive"]()
+    with cctx.options(connect_launches=8):
+        sc, vols = cctx.upload_scene(pc, layout=capi.LAYOUT_BRICK27)
+        cctx.render_to_host(sc, 0, 16, seed=2)
+        _clean(cctx, "8 K_connect launches per pass")
+        for v in vols:
+            v.destroy()
