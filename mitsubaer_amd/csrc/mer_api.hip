@@ -415,7 +415,7 @@ int mer_context_set_option(mer_context *ctx, const char *name, int64_t value) {
         (n == "connect_launches" && (value < 1 || value > 64)) ||
         // nslots: 0 = default, otherwise at least one block per pipeline (a smaller value would launch empty grids)
         (n == "nslots" && (value < 0 || (value > 0 && value < MER_BLOCK * MER_MAX_PIPES) || value > ((int64_t) 1 << 28))) ||
-        (n == "prefilter" && (value < 0 || value > 4)) || (n == "mq_sort" && (value < -1 || value > 1)) ||
+        (n == "prefilter" && (value < 0 || value > 5)) || (n == "mq_sort" && (value < -1 || value > 1)) ||
         (n == "march_lds_kb" && (value < 0 || value > 64)) ||          // dynamic LDS above 64 KiB would need hipFuncSetAttribute
         (n == "debug_pixel" && (value < -1 || value > ((int64_t) 1 << 31) - 1)) || (n == "tile_deal" && (value < 0 || value > 1)) ||
         (n == "small_render_slots" && (value < 0 || value > 1)) || (n == "adaptive_k" && (value < 0 || value > 2)))
@@ -602,8 +602,19 @@ int mer_volume_build_spline(mer_context *ctx, mer_volume h) {
             hipLaunchKernelGGL(bspline_anticausal_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, (const float *) t, dst, na, nb, sa, sb, sl, size);
         };
         auto win = [&](const float *src, float *dst, int na, int nb, int64_t sb, int64_t sl, int size) {     // fused sweeps, unit stride in a
-            const int64_t threads = (int64_t) na * nb * ((size + MER_PF_SEG - 1) / MER_PF_SEG);
-            hipLaunchKernelGGL(bspline_win_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, src, dst, na, nb, sb, sl, size);
+            const int nseg = (size + MER_PF_SEG - 1) / MER_PF_SEG;
+            // interior segments (window inside the line): wave-uniform addressing, no per-sample conditions (bspline_win2_kernel); border segments: generic kernel
+            int s_lo = 0, s_hi = nseg;
+            if (form != 5 && nb <= 65535 && sl * 4 * (int64_t) MER_PFX_W < ((int64_t) 1 << 31)) {
+                while (s_lo < nseg && !(s_lo * MER_PF_SEG - MER_PF_WARM > 0)) s_lo++;
+                s_hi = s_lo;
+                while (s_hi < nseg && s_hi * MER_PF_SEG - MER_PF_WARM + MER_PFX_W < size) s_hi++;
+            } else s_lo = nseg;
+            if (s_hi > s_lo)
+                hipLaunchKernelGGL(bspline_win2_kernel, dim3((unsigned) ((na + 255) / 256), (unsigned) (s_hi - s_lo), (unsigned) nb), dim3(256), 0, ctx->stream, src, dst, na, sb, sl, size, s_lo);
+            else { s_lo = nseg; s_hi = nseg; }
+            const int64_t threads = (int64_t) na * nb * (s_lo + (nseg - s_hi));
+            if (threads > 0) hipLaunchKernelGGL(bspline_win_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, src, dst, na, nb, sb, sl, size, s_lo, s_hi);
         };
         const bool two_kernel = form == 2;
         if (two_kernel) pass((const float *) v.dense, a, nx, nz, 1, (int64_t) nx * ny, nx, ny);          // y
@@ -611,12 +622,22 @@ int mer_volume_build_spline(mer_context *ctx, mer_volume h) {
         if (form == 3) pass(a, b, ny, nz, nx, (int64_t) nx * ny, 1, nx);           // x, strided form
         else {                                                                                        // x: lines are contiguous -> LDS tiles
             const int64_t nlines = (int64_t) ny * nz;
+            const int ntile = (nx + MER_PFX_COLS - 1) / MER_PFX_COLS;
+            int t_lo = ntile, t_hi = ntile;                       // interior segments in registers (n % 4 == 0), border tiles through LDS
             if (nx % 4 == 0 && form != 4) {
-                const int64_t threads = nlines * ((nx + MER_PF_SEG - 1) / MER_PF_SEG);
-                hipLaunchKernelGGL(bspline_x_reg_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, (const float *) a, b, nlines, nx);
-            } else {
-                const int64_t blocks = ((nlines + MER_PFX_ROWS - 1) / MER_PFX_ROWS) * ((nx + MER_PFX_COLS - 1) / MER_PFX_COLS);
-                hipLaunchKernelGGL(bspline_x_kernel, dim3((unsigned) blocks), dim3(256), 0, ctx->stream, (const float *) a, b, nlines, nx);
+                t_lo = 0; while (t_lo < ntile && !(t_lo * MER_PF_SEG - MER_PF_WARM > 0)) t_lo++;
+                t_hi = t_lo; while (t_hi < ntile && t_hi * MER_PF_SEG - MER_PF_WARM + MER_PFX_W < nx) t_hi++;
+                if (t_hi > t_lo) {
+                    const int64_t threads = nlines * (t_hi - t_lo);
+                    hipLaunchKernelGGL(bspline_x_reg_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, (const float *) a, b, nlines, nx, t_lo, t_hi - t_lo);
+                } else t_lo = t_hi = ntile;
+            }
+            if (nx % 4 == 0 && form != 4) {        // border segments: the guarded register form
+                const int64_t threads = nlines * (t_lo + (ntile - t_hi));
+                if (threads > 0) hipLaunchKernelGGL(bspline_x_reg_border_kernel, dim3(nblocks(threads)), dim3(256), 0, ctx->stream, (const float *) a, b, nlines, nx, t_lo, t_hi);
+            } else {                                // any line length: LDS tiles
+                const int64_t blocks = ((nlines + MER_PFX_ROWS - 1) / MER_PFX_ROWS) * (t_lo + (ntile - t_hi));
+                if (blocks > 0) hipLaunchKernelGGL(bspline_x_kernel, dim3((unsigned) blocks), dim3(256), 0, ctx->stream, (const float *) a, b, nlines, nx, t_lo, t_hi);
             }
         }
         if (two_kernel) pass(b, a, nx, ny, 1, nx, (int64_t) nx * ny, nz);                                // z

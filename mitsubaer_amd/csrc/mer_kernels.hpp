@@ -227,13 +227,19 @@ __global__ void bspline_pass_kernel(const float *src, float *dst, int nlines_a, 
 }
 
 // K_prefilter, parallel form.  The filter's pole is z1 = sqrt(3)-2 = -0.268: a coefficient depends on samples k positions away with
-// weight z1^k, below float resolution (2^-24 relative) after 13 samples and below 1e-23 after 40.  So a line is cut into segments that
+// weight z1^k, below float resolution (2^-24 relative) after 13 samples: a warm-up of 16 samples (7e-10) is exact in float.  Rounds 1-2 used
+// 40 samples and segments of 32 outputs -- 3.5 reads per output; 16 + 64 + 16 makes it 1.5 (1024^3: 13.4 -> 8.7 ms with the wave-uniform
+// addressing of bspline_win2_kernel, profiles/round3/prefilter_variants.txt).  So a line is cut into segments that
 // are filtered independently after a warm-up of MER_PF_WARM samples (the first segment starts from the exact mirror sum, the last
 // anti-causal one from the exact end condition): same arithmetic per sample as the sequential recursion, N^3 / SEG threads instead
 // of N^2, every global access coalesced.  Two kernels per axis (causal -> tmp, anti-causal -> out): the anti-causal warm-up of one
 // segment reads causal values that a neighbouring segment would otherwise already have overwritten.
-#define MER_PF_WARM 40
-#define MER_PF_SEG 32
+#ifndef MER_PF_WARM
+#define MER_PF_WARM 16
+#endif
+#ifndef MER_PF_SEG
+#define MER_PF_SEG 64
+#endif
 __device__ __forceinline__ float bspline_cp0(const float *src, int64_t offset, int64_t stride_line, int size, float z1) {
     // basisspline.h:826-838: pow(z1, i) in double, sum in float; terms beyond z1^64 (< 1e-36) cannot change a float sum
     const int nf = size < 64 ? size : 64;
@@ -280,17 +286,20 @@ __global__ void bspline_anticausal_kernel(const float *tmp, float *out, int na, 
     for (; i >= i0; i--) { cn = z1 * (cn - tmp[offset + (int64_t) i * stride_line]); out[offset + (int64_t) i * stride_line] = 6 * cn; }
 }
 
-// The pass along x (lines contiguous in memory): a block stages 256 lines x (32 outputs + 40 warm-up samples on either side) in LDS
-// with row-contiguous (coalesced) loads, each thread filters one line of the tile causally and anti-causally in place (row pitch
-// 113 words: conflict-free), and the 32 outputs per line go back with coalesced stores -- one read and one write of the volume.
+// The pass along x (lines contiguous in memory), any line length: a block stages 256 lines x (SEG outputs + WARM warm-up samples on either side) in LDS
+// with row-contiguous (coalesced) loads, each thread filters one line of the tile causally and anti-causally in place (odd row pitch:
+// conflict-free), and the 32 outputs per line go back with coalesced stores -- one read and one write of the volume.
 #define MER_PFX_ROWS 256
-#define MER_PFX_COLS 32
+#define MER_PFX_COLS MER_PF_SEG
 #define MER_PFX_W (MER_PFX_COLS + 2 * MER_PF_WARM)
 #define MER_PFX_LD (MER_PFX_W + 1)
-__global__ void __launch_bounds__(256) bspline_x_kernel(const float *src, float *out, int64_t nlines, int n) {
+// tile_lo / tile_hi: the kernel covers the column tiles [0, tile_lo) and [tile_hi, ntile) only (the border tiles beside bspline_x_reg_kernel's
+// interior segments); tile_lo = tile_hi = ntile: all of them
+__global__ void __launch_bounds__(256) bspline_x_kernel(const float *src, float *out, int64_t nlines, int n, int tile_lo, int tile_hi) {
     __shared__ float lds[MER_PFX_ROWS * MER_PFX_LD];
-    const int ntile = (n + MER_PFX_COLS - 1) / MER_PFX_COLS;
-    const int tile = (int) (blockIdx.x % (unsigned) ntile);              // neighbouring column tiles run together: the warm-up overlap is an L2 hit
+    const int ntile_all = (n + MER_PFX_COLS - 1) / MER_PFX_COLS, ntile = tile_lo + (ntile_all - tile_hi);
+    const int tidx = (int) (blockIdx.x % (unsigned) ntile);              // neighbouring column tiles run together: the warm-up overlap is an L2 hit
+    const int tile = tidx < tile_lo ? tidx : tile_hi + (tidx - tile_lo);
     const int64_t row0 = (int64_t) (blockIdx.x / (unsigned) ntile) * MER_PFX_ROWS;
     const int c0 = tile * MER_PFX_COLS, c1 = min(c0 + MER_PFX_COLS, n);
     const int lo = max(c0 - MER_PF_WARM, 0), hi = min(c1 + MER_PF_WARM, n), w = hi - lo;
@@ -303,7 +312,7 @@ __global__ void __launch_bounds__(256) bspline_x_kernel(const float *src, float 
     const float z1 = -2.0f + sqrtf(3.0f);
     if (row0 + threadIdx.x < nlines) {
         float *L = lds + threadIdx.x * MER_PFX_LD;
-        float c = (lo == 0) ? bspline_cp0(L, 0, 1, n, z1) : L[0];
+        float c = (lo == 0) ? bspline_cp0(src + (row0 + threadIdx.x) * n, 0, 1, n, z1) : L[0];     // the mirror sum reads up to 64 samples: from the line itself (the tile may hold fewer)
         L[0] = c;
         for (int i = 1; i < w; i++) { c = L[i] + z1 * c; L[i] = c; }
         float cn; int i;
@@ -319,14 +328,36 @@ __global__ void __launch_bounds__(256) bspline_x_kernel(const float *src, float 
     }
 }
 
-// x pass, register form (n % 4 == 0): thread <-> (segment of 32 outputs, line); the 112-sample window (40 + 32 + 40) is fetched with
-// 28 independent 16-byte loads -- adjacent lanes own adjacent 128-byte segments of one line, so a wave reads one contiguous 8 KB
-// span (plus halo) and every line it touches is shared through L1 -- filtered in registers, and written with 8 16-byte stores.
-__global__ void __launch_bounds__(256) bspline_x_reg_kernel(const float *src, float *out, int64_t nlines, int n) {
-    const int nseg = (n + MER_PF_SEG - 1) / MER_PF_SEG;
+// x pass, register form (n % 4 == 0), INTERIOR segments only (the window lies inside the line; the border tiles run in bspline_x_kernel):
+// thread <-> (segment, line); the window (WARM + SEG + WARM samples) is fetched with independent 16-byte loads at immediate offsets from one
+// address -- adjacent lanes own adjacent segments of one line, so a wave reads one contiguous span and every cache line it touches is shared
+// through L1 --, filtered in registers without any per-sample condition, and written with 16-byte stores.
+__global__ void __launch_bounds__(256) bspline_x_reg_kernel(const float *src, float *out, int64_t nlines, int n, int seg_first, int nseg) {
     const int64_t id = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nlines * nseg) return;
-    const int seg = (int) (id % nseg); const int64_t row = id / nseg;
+    const int seg = seg_first + (int) (id % nseg); const int64_t row = id / nseg;
+    const int c0 = seg * MER_PF_SEG, g0 = c0 - MER_PF_WARM;
+    const float4 *S = (const float4 *) (src + row * n + g0); float4 *O = (float4 *) (out + row * n + c0);
+    const float z1 = -2.0f + sqrtf(3.0f);
+    float v[MER_PFX_W];
+#pragma unroll
+    for (int q = 0; q < MER_PFX_W / 4; q++) { const float4 t = S[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+    float c = v[0];
+#pragma unroll
+    for (int j = 1; j < MER_PFX_W; j++) { c = v[j] + z1 * c; v[j] = c; }
+    float cn = 0.0f;
+#pragma unroll
+    for (int j = MER_PFX_W - 1; j >= MER_PF_WARM; j--) { cn = z1 * (cn - v[j]); v[j] = 6 * cn; }
+#pragma unroll
+    for (int q = 0; q < MER_PF_SEG / 4; q++) O[q] = make_float4(v[MER_PF_WARM + 4 * q], v[MER_PF_WARM + 4 * q + 1], v[MER_PF_WARM + 4 * q + 2], v[MER_PF_WARM + 4 * q + 3]);
+}
+
+// x pass, register form, the BORDER segments [0, seg_lo) and [seg_hi, nseg) (n % 4 == 0): every sample guarded (line ends, mirror-sum start)
+__global__ void __launch_bounds__(256) bspline_x_reg_border_kernel(const float *src, float *out, int64_t nlines, int n, int seg_lo, int seg_hi) {
+    const int nseg_all = (n + MER_PF_SEG - 1) / MER_PF_SEG, nseg = seg_lo + (nseg_all - seg_hi);
+    const int64_t id = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nlines * nseg) return;
+    const int sidx = (int) (id % nseg); const int seg = sidx < seg_lo ? sidx : seg_hi + (sidx - seg_lo); const int64_t row = id / nseg;
     const float *S = src + row * n; float *O = out + row * n;
     const int c0 = seg * MER_PF_SEG, g0 = c0 - MER_PF_WARM;
     const float z1 = -2.0f + sqrtf(3.0f);
@@ -361,13 +392,15 @@ __global__ void __launch_bounds__(256) bspline_x_reg_kernel(const float *src, fl
     }
 }
 
-// y / z passes, register-window form: thread <-> (a = x index, segment, b); the 112-sample window is strided by the line pitch, every
+// y / z passes, register-window form: thread <-> (a = x index, segment, b); the window is strided by the line pitch, every
 // load and store is coalesced across the wave (adjacent lanes = adjacent x); causal and anti-causal sweeps fused: one read, one write.
-__global__ void __launch_bounds__(256) bspline_win_kernel(const float *src, float *out, int na, int nb, int64_t stride_b, int64_t stride_line, int n) {
-    const int nseg = (n + MER_PF_SEG - 1) / MER_PF_SEG;
+// seg_lo / seg_hi: the kernel covers the segments [0, seg_lo) and [seg_hi, nseg) only (the border segments beside bspline_win2_kernel's
+// interior ones); seg_lo = nseg, seg_hi = nseg: all of them
+__global__ void __launch_bounds__(256) bspline_win_kernel(const float *src, float *out, int na, int nb, int64_t stride_b, int64_t stride_line, int n, int seg_lo, int seg_hi) {
+    const int nseg_all = (n + MER_PF_SEG - 1) / MER_PF_SEG, nseg = seg_lo + (nseg_all - seg_hi);
     const int64_t id = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (int64_t) na * nseg * nb) return;
-    const int64_t a = id % na, r = id / na; const int seg = (int) (r % nseg); const int64_t b = r / nseg;
+    const int64_t a = id % na, r = id / na; const int sidx = (int) (r % nseg); const int seg = sidx < seg_lo ? sidx : seg_hi + (sidx - seg_lo); const int64_t b = r / nseg;
     const float *S = src + a + b * stride_b; float *O = out + a + b * stride_b;
     const int c0 = seg * MER_PF_SEG, g0 = c0 - MER_PF_WARM;
     const float z1 = -2.0f + sqrtf(3.0f);
@@ -392,6 +425,40 @@ __global__ void __launch_bounds__(256) bspline_win_kernel(const float *src, floa
     }
 #pragma unroll
     for (int j = 0; j < MER_PF_SEG; j++) { const int g = c0 + j; if (g < n) O[(int64_t) g * stride_line] = v[MER_PF_WARM + j]; }
+}
+
+// y / z passes, register-window form with WAVE-UNIFORM line addresses (option prefilter = 0, the default): blockIdx = (x block, segment, b),
+// threadIdx = x.  Segment and b are block-uniform, so the address of sample j is one SCALAR base (advanced by the line pitch with scalar adds)
+// plus the lane's 32-bit byte offset (global_load ... v_off, s[base]) -- bspline_win_kernel forms a 64-bit vector address per sample, which
+// put 2 x (window) address registers beside the window itself (183 - 256 VGPRs, 1 - 2 waves per SIMD).  Interior segments (the window lies
+// inside the line: all but the first and the last one or two) run here, without any per-sample condition; the border segments run in
+// bspline_win_kernel.
+__global__ void __launch_bounds__(256) bspline_win2_kernel(const float *src, float *out, int na, int64_t stride_b, int64_t stride_line, int n, int seg_first) {
+    const int a = (int) (blockIdx.x * 256 + threadIdx.x);
+    if (a >= na) return;
+    const int seg = seg_first + (int) blockIdx.y;                       // interior segments only (host: g0 > 0 and g0 + window < n)
+    const int c0 = seg * MER_PF_SEG, g0 = c0 - MER_PF_WARM;
+    const float *S = src + (int64_t) blockIdx.z * stride_b; float *O = out + (int64_t) blockIdx.z * stride_b;        // uniform
+    const uint32_t off = (uint32_t) a * 4u;                                                                           // the lane's byte offset
+    const float z1 = -2.0f + sqrtf(3.0f);
+    float v[MER_PFX_W];
+    // one buffer descriptor per block (base = the window's first line: wave-uniform, 4 SGPRs); sample j sits at scalar offset j x pitch, the
+    // lane adds its 32-bit x offset: no vector address arithmetic at all.  pitch x window < 2^31 bytes (host-checked).
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) (S + (int64_t) g0 * stride_line), 0, 0x7FFFFFFF, 0x00020000);
+    const int pitch = (int) stride_line * 4;
+#pragma unroll
+    for (int j = 0; j < MER_PFX_W; j++) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int) off, j * pitch, 0));
+    // causal sweep started from the window's first sample (its error has decayed by z1^WARM at the first output), anti-causal sweep started
+    // from 0 at the window's end; the same arithmetic per sample as the sequential recursion
+    float c = v[0];
+#pragma unroll
+    for (int j = 1; j < MER_PFX_W; j++) { c = v[j] + z1 * c; v[j] = c; }
+    float cn = 0.0f;
+#pragma unroll
+    for (int j = MER_PFX_W - 1; j >= MER_PF_WARM; j--) { cn = z1 * (cn - v[j]); v[j] = 6 * cn; }
+    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc((void *) (O + (int64_t) c0 * stride_line), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < MER_PF_SEG; j++) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[MER_PF_WARM + j]), ws, (int) off, j * pitch, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------
