@@ -62,7 +62,7 @@ def test_trilinear_value_grad_bit_exact(ctx, orc, layout):
 
 @pytest.mark.parametrize("shape", [(40, 33, 70), (16, 130, 17), (97, 16, 64), (20, 18, 16), (18, 24, 128), (17, 19, 36)])
 def test_bspline_parallel_prefilter_matches_sequential_and_oracle(ctx, orc, shape, monkeypatch):
-    """K_prefilter's segmented form (warm-up 40, segments of 32) against the one-thread-per-line form and the oracle's build3d
+    """K_prefilter's segmented form (warm-up 16, segments of 64; interior segments without guards, border segments guarded) against the one-thread-per-line form and the oracle's build3d
     (include/mitsuba/core/basisspline.h:812-890): lines shorter than, equal to and longer than a segment + warm-up, ragged tails."""
     rng = np.random.RandomState(7)
     data = (1.3 + 0.3 * rng.rand(*shape)).astype(np.float32)
