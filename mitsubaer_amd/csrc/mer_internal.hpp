@@ -51,6 +51,7 @@ struct Options {
     int64_t debug_pixel = -1;
     int64_t march_lds_kb = 0;     // KiB of (unused) dynamic LDS per K_march block: caps its occupancy (160 KiB per CU; 33 -> 4 blocks, 41 -> 3) for A/B runs
     int64_t tile_deal = 1;        // tile shards dealt on diagonals (1, default) or in plain row-major round robin (0): decode_work
+    int64_t inline_walks = 1;     // straight rays in a gridded sigma_t: K_event runs the walks itself (persistent lanes) instead of handing them to K_march
     int64_t small_render_slots = 1;   // a render with few paths per slot uses fewer slots / pipelines, so that the wavefront stays full while it drains
     int64_t lds_bricks = 0;       // K_march keeps every lane's current BRICK27 record in LDS (BRICK27 below 4 GiB only; measured slower)
 };
@@ -104,7 +105,7 @@ struct Run {
 // the kernels of one (CURVED, RIF, STEPPER, SIGMA, BND) combination, as launchable function pointers
 typedef void (*GenKernel)(const Params);
 typedef void (*PassKernel)(const Params, uint32_t);
-struct KernelSet { GenKernel gen; PassKernel event, march, connect, connect_cross, march_lds; };   // connect_cross: the point emitter lies outside the medium shape;
+struct KernelSet { GenKernel gen; PassKernel event, march, connect, connect_cross, march_lds, event_inline; };   // event_inline: K_event that runs straight walks itself (or null)   // connect_cross: the point emitter lies outside the medium shape;
                                                                                                     // march_lds: K_march with LDS-staged BRICK27 records (or null)
 // each mer_render_<group>.hip answers for the combinations it instantiates (returns false if the combination is not in its group)
 bool kernels_straight(int sigma, int bnd, bool extra, KernelSet &k);

@@ -76,6 +76,9 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         auto it = ctx->volumes.find(scene->rif);
         if (it != ctx->volumes.end() && it->second.layout == MER_LAYOUT_BRICK27) ks.march = ks.march_lds;
     }
+    // straight rays through a gridded sigma_t: K_event runs every walk itself (a walk is ~3 tentative collisions: the hand-over to K_march costs
+    // more than the walk).  K_march is still launched: its list is empty, and it is where the hit ring's head is clamped between passes.
+    if (opt.inline_walks && ks.event_inline && !curved && scene->method != MER_METHOD_SIMPSON) ks.event = ks.event_inline;
     const bool connect_stage = has_point && curved;
     if (connect_stage) {            // an emitter outside the shape is reached through the boundary: the kernel that carries the refraction code
         bool inside = false;        // (signed-distance shapes: the plain kernel carries it too, the side is tested per connection)

@@ -16,6 +16,11 @@ static inline void fill_kernels(bool extra, KernelSet &k) {
     k.gen = gen_kernel_for(CURVED, extra || X, BND);
     if (extra || X) k.event = event_kernel<CURVED, RIF, STEPPER, SIGMA, true, BND>;
     else k.event = event_kernel<CURVED, RIF, STEPPER, SIGMA, X, BND>;
+    k.event_inline = nullptr;
+    if constexpr (!CURVED && SIGMA == MER_SIGMA_GRID) {
+        if (extra || X) k.event_inline = event_kernel<CURVED, RIF, STEPPER, SIGMA, true, BND, true>;
+        else k.event_inline = event_kernel<CURVED, RIF, STEPPER, SIGMA, X, BND, true>;
+    }
     k.march = march_kernel<CURVED, RIF, STEPPER, SIGMA, BND>;
     if constexpr (RIF == RIFK_BRICK27_BUF) k.march_lds = march_kernel<CURVED, RIFK_BRICK27_LDS, STEPPER, SIGMA, BND>;
     else k.march_lds = nullptr;

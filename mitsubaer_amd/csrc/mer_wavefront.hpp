@@ -358,8 +358,17 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
 #else
 #define MER_EVENT_BOUNDS __launch_bounds__(MER_BLOCK)
 #endif
-template <bool CURVED, int RIF, int STEPPER, int SIGMA, bool EXTRA, int BND = 0>
-__global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
+// INLINE (straight rays in a gridded sigma_t only): a walk is run to its end HERE instead of parking the lane for K_march.  A straight walk is ~3
+// tentative collisions (a log, a sampler draw and one 32-byte cell fetch each), far less than what the hand-over costs: 80 + 216 bytes of slot
+// record out, two list appends, a launch boundary, 80 + 216 bytes back in.  A lane then carries its path from the camera to the film inside one
+// launch, pops the next sample from the hit ring and goes on until the ring is empty -- a persistent-lane megakernel, which for curved rays
+// (hundreds of 350-instruction steps per walk) was the slowest form of all (section 4's table) and for straight rays is the fastest.  Same
+// sampler draws in the same order: per-path results do not change (tested).
+#ifndef MER_INLINE_EVENT_WAVES
+#define MER_INLINE_EVENT_WAVES 1
+#endif
+template <bool CURVED, int RIF, int STEPPER, int SIGMA, bool EXTRA, int BND = 0, bool INLINE = false>
+__global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1) event_kernel(const Params P, uint32_t pass) {
     typedef Walk<CURVED, RIF, STEPPER, SIGMA, BND> WalkT;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots) return;
@@ -477,7 +486,17 @@ __global__ void MER_EVENT_BOUNDS event_kernel(const Params P, uint32_t pass) {
             }
             st = ST_MARCH;
         }
-        if (ev == EV_NONE) break;                  // marching again: K_march takes over
+        if (ev == EV_NONE) {
+            if (INLINE && !CURVED) {               // the walk, inline: K_march's loop for straight rays (heterogeneous.cpp:633-656, :562-585) without its pass limit
+                sigma = 0.0f;
+                do {
+                    ev = W.advance(P, rng, C);
+                    if (ev == EV_ARRIVED) ev = W.on_arrived(P, rng, C, sigma);
+                } while (ev == EV_NONE);
+                continue;
+            }
+            break;                                 // marching again: K_march takes over
+        }
 
         // ---------------------------------------------------------------- one event
         if (ev == EV_ARRIVED) {

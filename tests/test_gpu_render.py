@@ -231,6 +231,25 @@ def test_tile_shards_are_dealt_on_diagonals(ctx):
         v.destroy()
 
 
+@pytest.mark.parametrize("name", ["cfg2_straight_ratio", "cfg2_straight_woodcock2", "point_straight_inside", "dielectric_straight_grid", "max_depth_3", "toworld_straight"])
+def test_inline_walks_change_no_path(ctx, name):
+    """straight rays in a gridded sigma_t: K_event runs the walks itself (option inline_walks = 1, the default: persistent lanes, no hand-over to
+    K_march) or parks the lane for K_march (0) -- the same sampler draws in the same order, so no bit of any path differs; films agree to summation
+    order and the counters are equal"""
+    p = CASES[name]()
+    sc, vols = ctx.upload_scene(p)
+    a = ctx.render_paths(sc, 1, seed=6)
+    ctx.counters_reset(); fa = ctx.render_to_host(sc, 0, 8, seed=6); ca = ctx.counters()
+    with ctx.options(inline_walks=0):
+        assert np.array_equal(ctx.render_paths(sc, 1, seed=6), a)
+        ctx.counters_reset(); fb = ctx.render_to_host(sc, 0, 8, seed=6); cb = ctx.counters()
+    assert np.allclose(fa, fb, rtol=1e-4, atol=1e-5)
+    for k in (capi.C_PATHS, capi.C_TENTATIVE, capi.C_REAL, capi.C_SEGMENTS, capi.C_NEE):
+        assert ca[k] == cb[k], (k, ca[k], cb[k])
+    for v in vols:
+        v.destroy()
+
+
 def test_determinism(ctx):
     p = scenes.straight_scene(N=24)
     sc, vols = ctx.upload_scene(p)
