@@ -68,7 +68,7 @@ def live_pmc(workload, res, size, spp, layout, options, budget_s=150.0):
     holds them) or (None, reason)."""
     import shutil
     import tempfile
-    if os.environ.get("MER_BENCH_PMC_CHILD") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+    if os.environ.get("MER_BENCH_PMC_CHILD") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD") or os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROF_OUTPUT_PATH"):
         return None, "this process is itself being profiled"
     exe = shutil.which("rocprofv3")
     if not exe:

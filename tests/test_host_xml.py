@@ -302,3 +302,56 @@ def test_volume_toworld_through_the_xml_path_equals_direct_render(tmp_path, ctx)
     assert close.mean() > 0.4 and abs(film[..., :3].sum() / ref[..., :3].sum() - 1) < 2e-2, (close.mean(), film[..., :3].sum() / ref[..., :3].sum())
     for v in vols:
         v.destroy()
+
+
+def test_medium_options_the_shim_forwards_flatten(tmp_path):
+    """The fields plugins/volpath_hip.cpp forwards from its own properties because the reference's media keep them private -- sampling `strategy`,
+    `samplingDensity`, `mediumSamplingWeight` (src/medium/homogeneous.cpp:156-228), a gridded RGB `albedo` volume (src/medium/heterogeneous.cpp:262-281)
+    and `emission` -- through the stand-alone host's XML path into the same mer_scene_desc fields."""
+    hom = ('<integrator type="volpath"/>' + CAM + '<medium type="homogeneous" id="m"><spectrum name="sigmaS" value="1, 2, 3"/><spectrum name="sigmaA" value="0.1"/>%s</medium>'
+           '<shape type="cube"><ref name="interior" id="m"/></shape>')
+    d, _ = host.flatten_xml(_scene(tmp_path, hom % '<string name="strategy" value="maximum"/>'))
+    assert d.strategy == P.STRATEGY_MAXIMUM and d.medium_sampling_weight == -1
+    d, _ = host.flatten_xml(_scene(tmp_path, hom % '<string name="strategy" value="manual"/><float name="samplingDensity" value="2.5"/><float name="mediumSamplingWeight" value="0.7"/>'))
+    assert d.strategy == P.STRATEGY_MANUAL and d.sampling_density == 2.5 and abs(d.medium_sampling_weight - 0.7) < 1e-7
+    d, _ = host.flatten_xml(_scene(tmp_path, hom % '<string name="strategy" value="single"/>'))
+    assert d.strategy == P.STRATEGY_SINGLE
+    with pytest.raises(host.HostError):
+        host.flatten_xml(_scene(tmp_path, hom % '<string name="strategy" value="manual"/>'))           # samplingDensity is required (homogeneous.cpp:223)
+    dens, _ = _vols(tmp_path, 16)
+    alb = str(tmp_path / "albedo.vol")
+    volio.write_vol(alb, scenes.rgb_albedo(16), [-1] * 3, [1] * 3)
+    het = ('<integrator type="volpath"/>' + CAM + '<medium type="heterogeneous" id="m"><volume name="density" type="gridvolume"><string name="filename" value="%s"/></volume>'
+           '<volume name="albedo" type="gridvolume"><string name="filename" value="%s"/></volume><spectrum name="emission" value="0.2, 0.12, 0.06"/><float name="scale" value="4"/></medium>'
+           '<shape type="cube"><ref name="interior" id="m"/></shape>' % (dens, alb))
+    d, _ = host.flatten_xml(_scene(tmp_path, het))
+    assert d.albedo_mode == P.ALBEDO_GRID and np.allclose(list(d.emission), [0.2, 0.12, 0.06]) and d.density_scale == 4.0
+
+
+@pytest.mark.gpu
+def test_albedo_volume_emission_and_strategy_render_like_the_direct_c_abi(tmp_path, ctx):
+    """the same fields rendered: XML (gridded RGB albedo + emission in a heterogeneous medium; strategy = maximum in a homogeneous one) = direct C-ABI"""
+    N = 16
+    dens, _ = _vols(tmp_path, N)
+    alb = str(tmp_path / "albedo.vol")
+    volio.write_vol(alb, scenes.rgb_albedo(N), [-1] * 3, [1] * 3)
+    cam = ('<sensor type="perspective"><float name="fov" value="45"/><transform name="toWorld"><lookat origin="-3,0,0" target="-2,0,0" up="0,1,0"/></transform>'
+           '<sampler type="independent"><integer name="sampleCount" value="4"/></sampler>'
+           '<film type="hdrfilm"><integer name="width" value="40"/><integer name="height" value="32"/><rfilter type="box"/></film></sensor>'
+           '<emitter type="constant"><spectrum name="radiance" value="1"/></emitter>')
+    het = ('<integrator type="volpath"/><medium type="heterogeneous" id="m"><volume name="density" type="gridvolume"><string name="filename" value="%s"/></volume>'
+           '<volume name="albedo" type="gridvolume"><string name="filename" value="%s"/></volume><spectrum name="emission" value="0.2, 0.12, 0.06"/><float name="scale" value="4"/>'
+           '<phase type="hg"><float name="g" value="0.8"/></phase></medium><shape type="cube"><ref name="interior" id="m"/></shape>' % (dens, alb)) + cam
+    film = host.render_xml(_scene(tmp_path, het), seed=2, layout=capi.LAYOUT_DENSE)
+    p = scenes.straight_scene(N=N, w=40, h=32, fov_x_deg=45.0, rfilter=P.FILTER_BOX, rfilter_param=0.5, albedo_mode=P.ALBEDO_GRID, albedo_grid=scenes.rgb_albedo(N),
+                              emission=[0.2, 0.12, 0.06], density_scale=4.0, phase=P.PHASE_HG, g=0.8, tr_estimator=P.TR_WOODCOCK2)     # the plugin's default estimator
+    sc, vols = ctx.upload_scene(p)
+    assert np.allclose(film, ctx.render_to_host(sc, 0, 4, seed=2), rtol=1e-5, atol=1e-6)
+    for v in vols:
+        v.destroy()
+    hom = ('<integrator type="volpath"/><medium type="homogeneous" id="m"><spectrum name="sigmaS" value="0.5, 3.5, 7.5"/><spectrum name="sigmaA" value="0.05"/>'
+           '<string name="strategy" value="maximum"/></medium><shape type="cube"><ref name="interior" id="m"/></shape>') + cam
+    film = host.render_xml(_scene(tmp_path, hom), seed=2)
+    p = scenes.homogeneous_scene(w=40, h=32, fov_x_deg=45.0, rfilter=P.FILTER_BOX, rfilter_param=0.5, strategy=P.STRATEGY_MAXIMUM, sigma_s=[0.5, 3.5, 7.5], sigma_a=[0.05] * 3)
+    sc, vols = ctx.upload_scene(p)
+    assert np.allclose(film, ctx.render_to_host(sc, 0, 4, seed=2), rtol=1e-5, atol=1e-6)
