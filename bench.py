@@ -61,7 +61,7 @@ def pmc_sums(outdir, family="march_kernel"):
     return acc if n else None
 
 
-def live_pmc(workload, res, size, spp, layout, options, budget_s=150.0):
+def live_pmc(workload, res, size, spp, layout, options, budget_s=240.0):
     """Counter passes of THIS workload taken in THIS run: for every entry of PMC_PASSES one child process `rocprofv3 --pmc <counters>
     --kernel-trace -- python3 bench.py <one single-pipeline step>`, started before this process touches the GPU (a GPU process must not
     exec; and the profiler's counters need the chip to themselves).  Returns the traffic entry (as profiles/round3/hbm_traffic.json
@@ -329,6 +329,7 @@ def main():
     want_512 = args.workload == "cfg3" and args.res == 256 and single and not args.no_target_512 and not args.no_cpu_baseline
     if single and not args.no_solo_step:
         if not args.no_live_pmc:
+            import torch  # noqa: F401  -- pages the image in (1-2 min on a fresh box) so that the children's imports are fast; importing touches no GPU
             traffic, traffic_why = live_pmc(args.workload, args.res, args.size, args.spp, args.layout, args.options)
             if want_512 and traffic:
                 traffic5, traffic5_why = live_pmc("cfg3", 512, args.size, args.spp, "brick27", args.options, budget_s=120.0)
