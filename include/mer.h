@@ -292,8 +292,8 @@ int  mer_multi_volume_upload(mer_multi *m, const mer_grid_desc *desc, const void
 int  mer_multi_volume_build_spline(mer_multi *m, mer_volume v);
 int  mer_multi_volume_destroy(mer_multi *m, mer_volume v);
 /* renders sample indices spp_begin .. spp_begin + spp_count - 1 of every pixel, sharded over the contexts, and returns the reduced film
-   float[height][width][mer_film_channels] in film_host.  rccl: 1 = use RCCL when the devices allow it (default choice), 0 = always
-   peer copy + add, 2 = RCCL even for a single context (a one-rank communicator: exercises the library binding on one GPU). */
+   float[height][width][mer_film_channels] in film_host.  rccl: 1 = use RCCL when the devices allow it and the library initialises (default choice; peer copy + add otherwise --
+   mer_multi_last_stats reports which), 0 = always peer copy + add, 2 = RCCL even for a single context (a one-rank communicator: exercises the library binding on one GPU). */
 int  mer_multi_render(mer_multi *m, const mer_scene_desc *scene, int32_t shard_mode, int32_t spp_begin, int32_t spp_count, uint64_t seed,
                       int32_t rccl, float *film_host);
 /* of the last mer_multi_render: how the films were reduced (MER_REDUCE_*), wall milliseconds of every context's render (n floats, may be

@@ -816,7 +816,6 @@ int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0,
     if (a.upload(p0, n * 12) || b.upload(d0, n * 12) || c.upload(dist, n * 4) || op.alloc(n * 12) || ov.alloc(n * 12) ||
         od.alloc(n * 4) || oo.alloc(n * 4) || ok.alloc(n * 4)) return 1;
     const int rifk = rif_fetch_kind(ctx, scene);
-    if (rifk == RIFK_BRICK27 || rifk == RIFK_BRICK27_BUF) return fail(ctx, "this leaf entry point takes the RIF in the dense or cell8 layout");
 #define MER_TRACE_CASE(R, S)                                                                                       \
     if (rifk == R && scene->stepper == S)                                                                          \
         hipLaunchKernelGGL((er_trace_kernel<R, S>), dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), \
@@ -825,6 +824,8 @@ int mer_er_trace(mer_context *ctx, const mer_scene_desc *scene, const float *p0,
     MER_TRACE_CASE(RIFK_DENSE_BUF, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_DENSE_BUF, MER_STEP_RK4)
     MER_TRACE_CASE(RIFK_CELL8, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_CELL8, MER_STEP_RK4)
     MER_TRACE_CASE(RIFK_CELL8_BUF, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_CELL8_BUF, MER_STEP_RK4)
+    MER_TRACE_CASE(RIFK_BRICK27_BUF, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_BRICK27_BUF, MER_STEP_RK4)      // the bench layout (< 4 GiB: buffer loads)
+    MER_TRACE_CASE(RIFK_BRICK27, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_BRICK27, MER_STEP_RK4)
     MER_TRACE_CASE(MER_RIF_BSPLINE3, MER_STEP_VERLET) MER_TRACE_CASE(MER_RIF_BSPLINE3, MER_STEP_RK4)
     MER_TRACE_CASE(RIFK_ACOUSTIC, MER_STEP_VERLET) MER_TRACE_CASE(RIFK_ACOUSTIC, MER_STEP_RK4)
 #undef MER_TRACE_CASE
@@ -844,11 +845,11 @@ int mer_connect(mer_context *ctx, const mer_scene_desc *scene, const float *p1, 
     DevBuf a(ctx), b(ctx), r(ctx);
     if (a.upload(p1, n * 12) || b.upload(p2, n * 12) || r.alloc(n * 48)) return 1;
     const int rifk = rif_fetch_kind(ctx, scene);
-    if (rifk == RIFK_BRICK27 || rifk == RIFK_BRICK27_BUF) return fail(ctx, "this leaf entry point takes the RIF in the dense or cell8 layout");
     bool launched = false;
 #define MER_CONNECT_CASE(R, B) if (!launched && rifk == R && (scene->boundary == MER_BOUNDARY_SDF) == (B == 1)) { launched = true;   \
         hipLaunchKernelGGL((connect_kernel<R, B>), dim3(nblocks(n, 64)), dim3(64), 0, ctx->stream, P, a.as<float>(), b.as<float>(), n, r.as<float>()); }
     MER_CONNECT_CASE(MER_RIF_TRILINEAR, 0) MER_CONNECT_CASE(MER_RIF_BSPLINE3, 0) MER_CONNECT_CASE(RIFK_DENSE_BUF, 0) MER_CONNECT_CASE(RIFK_CELL8, 0) MER_CONNECT_CASE(RIFK_CELL8_BUF, 0)
+    MER_CONNECT_CASE(RIFK_BRICK27_BUF, 0) MER_CONNECT_CASE(RIFK_BRICK27, 0)
     // signed-distance boundary: the fetch kinds mer_render instantiates for it
     MER_CONNECT_CASE(MER_RIF_TRILINEAR, 1) MER_CONNECT_CASE(RIFK_CELL8_BUF, 1) MER_CONNECT_CASE(MER_RIF_BSPLINE3, 1)
 #undef MER_CONNECT_CASE

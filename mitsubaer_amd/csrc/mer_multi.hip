@@ -190,13 +190,20 @@ int mer_multi_render(mer_multi *m, const mer_scene_desc *scene, int32_t shard_mo
     const auto t0 = std::chrono::steady_clock::now();
     const bool want_rccl = (rccl == 2) || (rccl == 1 && n > 1 && m->distinct);
     m->last_reduce = MER_REDUCE_NONE;
-    if (want_rccl && m->distinct && m->rccl.load()) {
+    bool use_rccl = want_rccl && m->distinct && m->rccl.load();
+    if (use_rccl && m->comms.empty()) {
         Rccl &R = m->rccl;
-        if (m->comms.empty()) {
-            m->comms.assign(n, nullptr);
-            const ncclResult_t r = R.CommInitAll(m->comms.data(), n, m->devices.data());
-            if (r != ncclSuccess) { m->comms.clear(); return mfail(m, std::string("ncclCommInitAll failed: ") + R.GetErrorString(r)); }
+        m->comms.assign(n, nullptr);
+        const ncclResult_t r = R.CommInitAll(m->comms.data(), n, m->devices.data());
+        if (r != ncclSuccess) {
+            m->comms.clear();
+            m->rccl.why = std::string("ncclCommInitAll failed: ") + R.GetErrorString(r);
+            if (rccl == 2) return mfail(m, m->rccl.why);
+            use_rccl = false;                   // rccl = 1 is "RCCL where it works": the films still get reduced, by peer copies (mer_multi_last_stats says which)
         }
+    }
+    if (use_rccl) {
+        Rccl &R = m->rccl;
         ncclResult_t r = R.GroupStart();
         for (int i = 0; i < n && r == ncclSuccess; i++) {
             MULTI_HIP(m, hipSetDevice(m->devices[i]));
@@ -207,7 +214,7 @@ int mer_multi_render(mer_multi *m, const mer_scene_desc *scene, int32_t shard_mo
         for (int i = 0; i < n; i++) { MULTI_HIP(m, hipSetDevice(m->devices[i])); MULTI_HIP(m, hipStreamSynchronize(m->streams[i])); }
         m->last_reduce = MER_REDUCE_RCCL;
     } else if (rccl == 2) {
-        return mfail(m, "mer_multi_render: RCCL requested but unavailable: " + (m->distinct ? m->rccl.why : std::string("a device is listed twice")));
+        return mfail(m, "mer_multi_render: RCCL requested but unavailable: " + (m->distinct ? m->rccl.why : std::string("a device is listed twice")));      // rccl = 2 demands it
     } else if (n > 1) {
         MULTI_HIP(m, hipSetDevice(m->devices[0]));
         if (m->staging_floats < floats) {

@@ -141,6 +141,35 @@ def test_camera_rays(ctx, orc):
     assert np.allclose(d[0], [1, 0, 0], atol=1e-6)
 
 
+@pytest.mark.parametrize("buffer_loads", [1, 0])
+@pytest.mark.parametrize("layout", ["cell8", "brick27"])
+def test_er_trace_and_connect_in_the_record_layouts(ctx, orc, layout, buffer_loads):
+    """the leaf entry points on the record layouts the renders use (BRICK27 = the bench layout; buffer loads below 4 GiB, global loads as a
+    >= 4 GiB field selects): mer_er_trace against the oracle AND bit for bit against the dense layout; mer_connect equal to the dense layout's"""
+    lay = {"cell8": capi.LAYOUT_CELL8, "brick27": capi.LAYOUT_BRICK27}[layout]
+    p = scenes.curved_scene(N=24, rif="radial", stepper=P.STEP_RK4)
+    n = 4096
+    p0 = scenes.rand_points(n, -0.9, 0.9); d0 = scenes.rand_dirs(n)
+    dist = np.random.RandomState(9).uniform(0.0, 1.5, n).astype(np.float32); dist[::7] = np.inf
+    sd, vd = ctx.upload_scene(p, layout=capi.LAYOUT_DENSE)
+    dense = ctx.er_trace(sd, p0, d0, dist)
+    a = scenes.rand_points(256, -0.6, 0.6, seed=3); b = scenes.rand_points(256, -0.6, 0.6, seed=4)
+    cd = ctx.connect(sd, a, b, 7)
+    with ctx.options(buffer_loads=buffer_loads):
+        sc, vols = ctx.upload_scene(p, layout=lay)
+        got = ctx.er_trace(sc, p0, d0, dist)
+        cg = ctx.connect(sc, a, b, 7)
+    for x, y in zip(got, dense):
+        assert np.array_equal(x, y)                      # the record layouts return the same corner values: not a bit differs
+    assert np.array_equal(cg, cd)
+    rp, rv, rds, roo, rok = orc.er_trace(p, p0, d0, dist)
+    same = got[4] == rok
+    assert same.mean() > 0.999 and np.abs(got[0] - rp)[same].max() < 2e-5 and np.abs(got[3] - roo)[same].max() < 1e-3
+    assert cd[:, 0].mean() > 0.8                         # most pairs connect
+    for v in vols + vd:
+        v.destroy()
+
+
 @pytest.mark.parametrize("stepper", [P.STEP_VERLET, P.STEP_RK4])
 @pytest.mark.parametrize("rifkind", ["trilinear", "bspline"])
 def test_er_trace(ctx, orc, stepper, rifkind):
