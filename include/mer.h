@@ -125,6 +125,14 @@ typedef struct {
        inversion for the free flight (invertDensityIntegral, :419-544); sigma_mode = GRID, rif_mode = CONST only.  het_stepsize = the
        plugin's `stepSize`; 0 = inferred as the reference does (:245-257): 0.5 x the smallest voxel extent of the density / albedo grids. */
     int32_t method; float het_stepsize;
+    /* emitter `area` on a `rectangle` shape (src/emitters/area.cpp:67-187, src/shapes/rectangle.cpp:99-222): the rectangle is the image of
+       [-1,1]^2 x {0} under area_to_world (row-major 3x4, no shear: "Error: 'toWorld' transformation contains shear!"); one-sided -- radiance
+       area_radiance into the half space of its normal toWorld(0,0,1) -- and all-absorbing otherwise (an emitter shape without a BSDF gets a
+       diffuse one of reflectance 0, src/librender/shape.cpp:48-56): it shadows the environment.  Sampled at every real collision
+       (Shape::sampleDirect, src/librender/shape.cpp:102-115: area sampling converted to solid angle) with the phase-function sample as its
+       MIS partner (volpath.cpp:120-173,370-428).  All-zero radiance = none.  The rectangle lies outside the medium shape.  Straight rays
+       (rif_mode = MER_RIF_CONST), index-matched cube / sphere boundary. */
+    float   area_to_world[12], area_radiance[3];
 } mer_scene_desc;
 enum { MER_METHOD_WOODCOCK = 0, MER_METHOD_SIMPSON = 1 };
 enum { MER_BSDF_NULL = 0, MER_BSDF_HDIELECTRIC = 1 };

@@ -65,6 +65,7 @@ class SceneDesc(C.Structure):
         ("sdf_max_error", C.c_float),
         ("ac_n_o", C.c_float), ("ac_n_max", C.c_float), ("ac_k_r", C.c_float), ("ac_mode", C.c_int32),
         ("method", C.c_int32), ("het_stepsize", C.c_float),
+        ("area_to_world", C.c_float * 12), ("area_radiance", C.c_float * 3),
     ]
 
 
@@ -275,6 +276,9 @@ class Context:
         s.boundary_bsdf = p.boundary_bsdf
         s.sdf = sdf.handle if sdf is not None else 0
         s.aggressive_tracing = int(p.aggressive_tracing); s.sdf_max_error = P.sdf_max_error(p)
+        m = np.eye(4); t = np.asarray(p.area_to_world if p.area_to_world is not None else np.eye(4), np.float64); m[:t.shape[0], :4] = t
+        s.area_to_world[:] = [float(v) for v in m[:3, :4].astype(np.float32).reshape(-1)]
+        s.area_radiance[:] = p.area_radiance
         return s
 
     def upload_scene(self, p, layout=LAYOUT_DENSE, rif_layout=None):

@@ -252,6 +252,37 @@ int make_params(mer_context *ctx, const mer_scene_desc *sc, Params &P, bool allo
     }
     if (P.fradius > 7.0f) return fail(ctx, "reconstruction filter radius too large");
     if (sc->boundary_bsdf != MER_BSDF_NULL && sc->boundary_bsdf != MER_BSDF_HDIELECTRIC) return fail(ctx, "boundary BSDF must be null or hdielectric");
+    P.has_area = (sc->area_radiance[0] != 0 || sc->area_radiance[1] != 0 || sc->area_radiance[2] != 0) ? 1 : 0;
+    if (P.has_area) {               // Rectangle::configure (src/shapes/rectangle.cpp:99-110)
+        if (sc->rif_mode != MER_RIF_CONST) return fail(ctx, "the area emitter is built for straight rays (rif_mode = CONST)");
+        if (sc->boundary_bsdf != MER_BSDF_NULL || sc->boundary == MER_BOUNDARY_SDF) return fail(ctx, "the area emitter needs an index-matched cube / sphere boundary");
+        double M[3][4], inv[3][3];
+        for (int i = 0; i < 12; i++) { P.rect_o2w[i] = sc->area_to_world[i]; M[i / 4][i % 4] = sc->area_to_world[i]; }
+        const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+        if (!(std::fabs(det) > 0)) return fail(ctx, "area emitter: 'toWorld' is singular");
+        inv[0][0] = (M[1][1] * M[2][2] - M[1][2] * M[2][1]) / det; inv[0][1] = (M[0][2] * M[2][1] - M[0][1] * M[2][2]) / det; inv[0][2] = (M[0][1] * M[1][2] - M[0][2] * M[1][1]) / det;
+        inv[1][0] = (M[1][2] * M[2][0] - M[1][0] * M[2][2]) / det; inv[1][1] = (M[0][0] * M[2][2] - M[0][2] * M[2][0]) / det; inv[1][2] = (M[0][2] * M[1][0] - M[0][0] * M[1][2]) / det;
+        inv[2][0] = (M[1][0] * M[2][1] - M[1][1] * M[2][0]) / det; inv[2][1] = (M[0][1] * M[2][0] - M[0][0] * M[2][1]) / det; inv[2][2] = (M[0][0] * M[1][1] - M[0][1] * M[1][0]) / det;
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) P.rect_w2o[4 * i + j] = (float) inv[i][j];
+            P.rect_w2o[4 * i + 3] = (float) -(inv[i][0] * M[0][3] + inv[i][1] * M[1][3] + inv[i][2] * M[2][3]);
+        }
+        const double du[3] = {2 * M[0][0], 2 * M[1][0], 2 * M[2][0]}, dv[3] = {2 * M[0][1], 2 * M[1][1], 2 * M[2][1]};
+        const double lu = std::sqrt(du[0] * du[0] + du[1] * du[1] + du[2] * du[2]), lv = std::sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+        if (std::fabs((du[0] * dv[0] + du[1] * dv[1] + du[2] * dv[2]) / (lu * lv)) > MER_EPSILON) return fail(ctx, "Error: 'toWorld' transformation contains shear!");    // :108-109
+        const double nn[3] = {inv[2][0], inv[2][1], inv[2][2]}, ln = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);   // o2w(Normal(0,0,1)): inverse transpose
+        for (int i = 0; i < 3; i++) P.rect_n[i] = (float) (nn[i] / ln);
+        P.rect_inv_area = (float) (1.0 / (lu * lv));
+        // the rectangle must lie outside the (convex) medium shape: corners and centre are tested
+        for (int k = 0; k < 5; k++) {
+            const float lx = k == 4 ? 0.0f : (k & 1 ? 1.0f : -1.0f), ly = k == 4 ? 0.0f : (k & 2 ? 1.0f : -1.0f);
+            const float q[3] = {(float) (M[0][0] * lx + M[0][1] * ly + M[0][3]), (float) (M[1][0] * lx + M[1][1] * ly + M[1][3]), (float) (M[2][0] * lx + M[2][1] * ly + M[2][3])};
+            bool in = true;
+            if (sc->boundary == MER_BOUNDARY_SPHERE) { float d2 = 0; for (int i = 0; i < 3; i++) d2 += (q[i] - sc->sph_center[i]) * (q[i] - sc->sph_center[i]); in = d2 < sc->sph_radius * sc->sph_radius; }
+            else for (int i = 0; i < 3; i++) in = in && q[i] >= sc->bmin[i] && q[i] <= sc->bmax[i];
+            if (in) return fail(ctx, "the area emitter's rectangle must lie outside the medium shape");
+        }
+    }
     if (film_frames(ctx, sc, P.frames)) return 1;
     P.film_ch = P.frames * 3 + 2;
     P.mod_phase = (float) (sc->mod_phase_deg * M_PI / 180);                                                   // pathlengthsampler.cpp:15

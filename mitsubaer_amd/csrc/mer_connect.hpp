@@ -506,6 +506,34 @@ template <int RIF, int BND = 0, bool XC = true> struct Connector {
     }
 };
 
+// Medium::evalTransmittance over [0, L] of the straight ray ps + t dvec (homogeneous.cpp:264-273; heterogeneous.cpp:546-587: the reference's 2-walk
+// Woodcock estimator or ratio tracking; :301-376 for method = simpson), run synchronously inside K_event (luminaire samples of the point and
+// area emitters).  The sampler draws are the oracle's evalTransmittance's.
+template <int SIGMA>
+__device__ __forceinline__ f3 straight_transmittance(const Params &P, Rng &rng, LaneCounters &C, f3 ps, f3 dvec, float L) {
+    const mer_scene_desc &S = P.sc;
+    if (SIGMA == MER_SIGMA_HOMOGENEOUS) return homogeneous_transmittance(P, 0.0f - L);
+    if (S.method == MER_METHOD_SIMPSON) { const float tv = expf(-simpson_integrate(P, C, ps, dvec, L)); return f3(tv, tv, tv); }    // heterogeneous.cpp:547-548
+    const int nwalks = S.tr_estimator == MER_TR_WOODCOCK2 ? 2 : 1;
+    float mint, maxt;                                            // heterogeneous.cpp:546-587
+    if (!aabb_intersect(P.density.wmin, P.density.wmax, ps, dvec, mint, maxt)) return f3(1, 1, 1);
+    mint = fmaxf(mint, 0.0f); maxt = fminf(maxt, L);
+    float result = 0.0f;
+    for (int w = 0; w < nwalks; ++w) {
+        float Tr = 1.0f, t = mint;
+        for (;;) {
+            t -= logf(1 - rng.next1D()) * P.inv_max_density;
+            if (t >= maxt) break;
+            const float sigma = lookup_float(P.density, ps + dvec * t) * S.density_scale; C.tentative++;
+            if (S.tr_estimator == MER_TR_RATIO) { Tr *= 1.0f - sigma * P.inv_max_density; if (Tr == 0.0f) break; }
+            else if (sigma * P.inv_max_density > rng.next1D()) { Tr = 0.0f; break; }
+        }
+        result += Tr;
+    }
+    const float tv = result / (float) nwalks;
+    return f3(tv, tv, tv);
+}
+
 // Luminaire sampling of a point emitter at a medium interaction: PointEmitter::sampleDirect (src/emitters/point.cpp:
 // pdf 1, EDiscrete => no MIS partner) + Scene::evalTransmittance (straight rays, src/librender/scene.cpp:619-678) or
 // Medium::eval through the RIF (curved rays, heterogeneousrefractive.cpp:571-640).  Returns value * phase (to be
@@ -517,7 +545,6 @@ __device__ __forceinline__ f3 point_nee(const Params &P, Rng &rng, LaneCounters 
     const f3 I(S.point_intensity[0], S.point_intensity[1], S.point_intensity[2]);
     const f3 pp(S.point_position[0], S.point_position[1], S.point_position[2]);
     const int interactions = S.max_depth - depth - 1;
-    const int nwalks = (SIGMA == MER_SIGMA_GRID && S.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
     C.nee++;
     static_assert(!CURVED, "curved-ray connections run in K_connect");
     {
@@ -531,27 +558,7 @@ __device__ __forceinline__ f3 point_nee(const Params &P, Rng &rng, LaneCounters 
         const float L = crosses ? tExit : dist;
         f3 tr(1, 1, 1);
         if (crosses && interactions == 0) tr = f3(0, 0, 0);
-        else if (SIGMA == MER_SIGMA_HOMOGENEOUS) tr = homogeneous_transmittance(P, 0.0f - L);
-        else if (S.method == MER_METHOD_SIMPSON) { const float tv = expf(-simpson_integrate(P, C, ps, dvec, L)); tr = f3(tv, tv, tv); }    // heterogeneous.cpp:547-548
-        else {
-            float mint, maxt;                                            // heterogeneous.cpp:546-587
-            if (aabb_intersect(P.density.wmin, P.density.wmax, ps, dvec, mint, maxt)) {
-                mint = fmaxf(mint, 0.0f); maxt = fminf(maxt, L);
-                float result = 0.0f;
-                for (int w = 0; w < nwalks; ++w) {
-                    float Tr = 1.0f, t = mint;
-                    for (;;) {
-                        t -= logf(1 - rng.next1D()) * P.inv_max_density;
-                        if (t >= maxt) break;
-                        const float sigma = lookup_float(P.density, ps + dvec * t) * S.density_scale; C.tentative++;
-                        if (S.tr_estimator == MER_TR_RATIO) { Tr *= 1.0f - sigma * P.inv_max_density; if (Tr == 0.0f) break; }
-                        else if (sigma * P.inv_max_density > rng.next1D()) { Tr = 0.0f; break; }
-                    }
-                    result += Tr;
-                }
-                const float tv = result / (float) nwalks; tr = f3(tv, tv, tv);
-            }
-        }
+        else tr = straight_transmittance<SIGMA>(P, rng, C, ps, dvec, L);
         value = value * tr;
         if (is_zero(value)) return f3(0, 0, 0);
         return value * phase_eval(S.phase, S.g, wi, dvec);

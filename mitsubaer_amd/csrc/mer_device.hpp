@@ -635,6 +635,8 @@ struct Params {
     int32_t mq_sort;                    // 1: march lists sorted by estimated steps to the boundary (option mq_sort = 0 turns it off for A/B runs)
     unsigned long long *chk;            // MER_BOUNDS_CHECK: violation record (NULL in the product build)
     uint64_t n_film, n_path_out;        // float counts of film / path_out: the extents the checks use
+    // emitter `area` on a `rectangle` (EXTRA kernels, straight rays): objectToWorld, its inverse, the frame normal, 1 / area (make_params)
+    int32_t has_area; float rect_o2w[12], rect_w2o[12], rect_n[3], rect_inv_area;
 };
 #define MER_LIVE_SLOTS 4096
 #define MER_COUNTER_REPLICAS 64        // counters are flushed into one of this many copies (summed on the host)
@@ -839,6 +841,56 @@ __device__ __forceinline__ bool dielectric_event(const Params &P, Rng &rng, f3 r
     T = T * (factor * factor);
     etaPath *= (cosT < 0 ? etaB : invEtaB);                                          // bRec.eta (:208)
     return cosT < 0;
+}
+
+// ---- emitter `area` on a `rectangle` shape (src/emitters/area.cpp:67-187, src/shapes/rectangle.cpp:99-222, src/librender/shape.cpp:102-126)
+// Rectangle::rayIntersect (:125-148): t in [mint, maxt] or -1
+__device__ __forceinline__ float rect_intersect(const Params &P, f3 o, f3 d, float mint, float maxt) {
+    const float *W = P.rect_w2o;
+    const float oz = W[8] * o.x + W[9] * o.y + W[10] * o.z + W[11], dz = W[8] * d.x + W[9] * d.y + W[10] * d.z;
+    const float hit = -oz / dz;
+    if (!(hit >= mint && hit <= maxt)) return -1.0f;
+    const float lx = (W[0] * o.x + W[1] * o.y + W[2] * o.z + W[3]) + hit * (W[0] * d.x + W[1] * d.y + W[2] * d.z),
+                ly = (W[4] * o.x + W[5] * o.y + W[6] * o.z + W[7]) + hit * (W[4] * d.x + W[5] * d.y + W[6] * d.z);
+    return (fabsf(lx) <= 1 && fabsf(ly) <= 1) ? hit : -1.0f;
+}
+// AreaLight::eval (area.cpp:102-107): the radiance a ray travelling along d picks up on the rectangle (one-sided)
+__device__ __forceinline__ f3 rect_le(const Params &P, f3 d) {
+    const f3 n(P.rect_n[0], P.rect_n[1], P.rect_n[2]);
+    return dot(n, -d) <= 0 ? f3(0, 0, 0) : f3(P.sc.area_radiance[0], P.sc.area_radiance[1], P.sc.area_radiance[2]);
+}
+// Shape::sampleDirect + AreaLight::sampleDirect (shape.cpp:102-115, area.cpp:162-177) for a reference point inside a medium (refN = 0):
+// radiance / pdf (0 on the back side), direction, distance, solid-angle pdf
+__device__ __forceinline__ f3 rect_sample_direct(const Params &P, f3 ref, float sx, float sy, f3 &d, float &dist, float &pdf) {
+    const float *M = P.rect_o2w; const float lx = sx * 2 - 1, ly = sy * 2 - 1;
+    const f3 p(M[0] * lx + M[1] * ly + M[3], M[4] * lx + M[5] * ly + M[7], M[8] * lx + M[9] * ly + M[11]);
+    const f3 n(P.rect_n[0], P.rect_n[1], P.rect_n[2]);
+    d = p - ref;
+    const float distSquared = dot(d, d);
+    dist = sqrtf(distSquared);
+    d = d / dist;
+    const float dp = fabsf(dot(d, n));
+    pdf = P.rect_inv_area * (dp != 0 ? (distSquared / dp) : 0.0f);
+    if (dot(d, n) < 0 && pdf != 0) return f3(P.sc.area_radiance[0], P.sc.area_radiance[1], P.sc.area_radiance[2]) / pdf;
+    pdf = 0.0f;
+    return f3(0, 0, 0);
+}
+// AreaLight::pdfDirect (area.cpp:179-187) for a hit at distance dist along d
+__device__ __forceinline__ float rect_pdf_direct(const Params &P, f3 d, float dist) {
+    const f3 n(P.rect_n[0], P.rect_n[1], P.rect_n[2]);
+    return dot(d, n) < 0 ? P.rect_inv_area * (dist * dist) / fabsf(dot(d, n)) : 0.0f;
+}
+// what a ray sees that has left the convex medium shape for good (or never meets it): the rectangle if it is hit -- front side: its radiance, back
+// side: black, and either way it hides the environment (all-absorbing BSDF, shape.cpp:48-56) -- else the environment.  extra = the optical length of
+// the free-space leg to the rectangle (transient films).  AREA is a compile-time switch: the plain kernels carry none of this.
+template <bool AREA>
+__device__ __forceinline__ f3 escape_radiance(const Params &P, f3 env, f3 o, f3 d, float mint, float &extra) {
+    extra = 0.0f;
+    if (AREA && P.has_area) {
+        const float t = rect_intersect(P, o, d, mint, MER_INF);
+        if (t >= 0) { extra = t * P.sc.rif_const; return rect_le(P, d); }
+    }
+    return env;
 }
 
 // ImageBlock::put (include/mitsuba/render/imageblock.h:124-205) with one block = the whole image;

@@ -66,7 +66,8 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
     const bool curved = scene->rif_mode != MER_RIF_CONST;
     // EXTRA kernels carry the point emitter, the modulated film and the dielectric boundary; the signed-distance boundary exists in
     // the EXTRA kernels only
-    const bool extra = scene->boundary == MER_BOUNDARY_SDF || has_point || scene->modulation != MER_MODULATION_NONE || scene->boundary_bsdf != MER_BSDF_NULL;
+    const bool has_area = scene->area_radiance[0] != 0 || scene->area_radiance[1] != 0 || scene->area_radiance[2] != 0;
+    const bool extra = scene->boundary == MER_BOUNDARY_SDF || has_point || has_area || scene->modulation != MER_MODULATION_NONE || scene->boundary_bsdf != MER_BSDF_NULL;
     KernelSet ks{};
     if (!pick_kernels(ctx, scene, extra, ks)) {
         if (scene->boundary == MER_BOUNDARY_SDF && curved) return fail(ctx, "signed-distance boundary: no kernel for this RIF layout (MER_LAYOUT_BRICK125 is not built with it)");

@@ -123,14 +123,22 @@ __global__ void __launch_bounds__(MER_BLOCK) gen_kernel(const Params P) {
                 f3 L(0, 0, 0);
                 float plen = 0.0f;                                   // transient film: optical path length so far
                 const float itsT = intersect_shape_b<BND>(P, o, d, mint, maxt);
-                if (itsT < 0) { if (!S.hide_emitters) L = env; }
+                // the area emitter's rectangle in front of the medium shape (or hit instead of it): its.isEmitter() => Le, then the all-absorbing BSDF ends the path
+                const float tRect = (EXTRA && P.has_area) ? rect_intersect(P, o, d, mint, maxt) : -1.0f;
+                if (tRect >= 0 && (itsT < 0 || tRect < itsT)) { if (!S.hide_emitters) { L = rect_le(P, d); if (camera_edge_counts(P)) plen = edge_length(P, tRect * S.rif_const); } }
+                else if (itsT < 0) { if (!S.hide_emitters) L = env; }
                 else if (1 >= maxDepth && maxDepth != -1) { }
                 else if (EXTRA && S.boundary_bsdf == MER_BSDF_HDIELECTRIC) hit = true;      // Fresnel sampling at the surface: K_event
                 else {
                     bool medium = true;
                     if (!CURVED) { const f3 ro = o + d * itsT; medium = intersect_shape_b<BND>(P, ro, d, MER_EPSILON, MER_INF) >= 0; }
                     if (!(2 <= maxDepth || maxDepth < 0)) { }
-                    else if (!medium) { if (!S.hide_emitters) L = env; if (camera_edge_counts(P)) plen = edge_length(P, itsT); }
+                    else if (!medium) {
+                        float extra = 0.0f;
+                        if (!S.hide_emitters) L = escape_radiance<EXTRA>(P, env, o + d * itsT, d, 0.0f, extra);
+                        if (camera_edge_counts(P)) plen = edge_length(P, itsT);
+                        if (S.decomposition != MER_DECOMPOSITION_BOUNCE) plen += extra;
+                    }
                     else hit = true;
                 }
                 if (!hit) {
@@ -455,6 +463,11 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
             C.paths++;
             ev = EV_NONE;
             itsT = intersect_shape_b<BND>(P, o, d, mint, maxt);                       // rRec.rayIntersect(ray)
+            const float tRect = (EXTRA && P.has_area) ? rect_intersect(P, o, d, mint, maxt) : -1.0f;
+            if (tRect >= 0 && (itsT < 0 || tRect < itsT)) {                              // the area emitter's rectangle is met first (K_gen retires these; gen_all hands them over)
+                if (!S.hide_emitters) { if (camera_edge_counts(P)) plen = edge_length(P, tRect * S.rif_const); const f3 Le = rect_le(P, d); L = L + mod_weight<EXTRA>(P, Le, plen); film_contribute(P, px, py, Le, plen); }
+                ev = EV_PATH_DONE;
+            } else
             if (itsT < 0) {
                 if (!S.hide_emitters) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }   // volpath.cpp:194-201
                 ev = EV_PATH_DONE;
@@ -481,7 +494,14 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
                 else { itsT = intersect_shape_b<BND>(P, ro, d, MER_EPSILON, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); if (!itsValid) medium = false; }
                 depth++;
                 if (!(depth <= maxDepth || maxDepth < 0)) ev = EV_PATH_DONE;
-                else if (!medium) { if (!S.hide_emitters) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); } ev = EV_PATH_DONE; }
+                else if (!medium) {
+                    if (!S.hide_emitters) {
+                        float extra; const f3 Le = escape_radiance<EXTRA>(P, env, ro, d, 0.0f, extra);
+                        const float pl = plen + (S.decomposition != MER_DECOMPOSITION_BOUNCE ? extra : 0.0f);
+                        L = L + mod_weight<EXTRA>(P, T * Le, pl); film_contribute(P, px, py, T * Le, pl);
+                    }
+                    ev = EV_PATH_DONE;
+                }
                 else { C.segments++; ps = ro; dsave = d; ev = W.begin(P, rng, C, K_FREE, ro, d, itsT); }
             }
             st = ST_MARCH;
@@ -556,10 +576,12 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
                 } else { trv = f3(0, 0, 0); ev = EV_TR_DONE; }
             } else ev = EV_PHASE;
         } else if (ev == EV_TR_DONE) {
-            const f3 tr = trv;
+            f3 tr = trv;
             if (W.kind == K_NEE) {
                 const float dpdf = MER_INV_FOURPI;
                 f3 value = env / dpdf;
+                // the rectangle shadows the environment (Scene::evalTransmittance stops at a non-null surface); tested after the walk so that the sampler draws stay the oracle's
+                if (EXTRA && P.has_area && rect_intersect(P, ps, dd, 0.0f, MER_INF) >= 0) tr = f3(0, 0, 0);
                 value = value * tr;
                 if (!is_zero(value)) {
                     const float phaseVal = phase_eval(S.phase, S.g, wi, dd);
@@ -576,10 +598,19 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
                 const int maxInteractions = maxDepth - depth - 1;
                 const bool blocked = (maxInteractions == 0) && (CURVED || itsValid);
                 if (!blocked && !is_zero(tr)) {
-                    const f3 value = tr * env;
-                    const f3 c = T * value * mi_weight(phasePdf, MER_INV_FOURPI);
-                    L = L + mod_weight<EXTRA>(P, c, plen + edge_length(P, trOpt));
-                    film_contribute(P, px, py, c, plen + edge_length(P, trOpt));
+                    f3 value = tr * env;
+                    float emitterPdf = MER_INV_FOURPI, extra = 0.0f;
+                    if (EXTRA && P.has_area) {
+                        // rayIntersectAndLookForEmitter (volpath.cpp:370-428): beyond the null boundary the ray meets the rectangle or the environment
+                        const float tR = rect_intersect(P, ps, dsave, 0.0f, MER_INF);
+                        if (tR >= 0) { value = tr * rect_le(P, dsave); emitterPdf = rect_pdf_direct(P, dsave, tR); extra = (tR - (itsValid ? itsT : 0.0f)) * S.rif_const; }
+                        else if (!hasEnv) value = f3(0, 0, 0);
+                    }
+                    if (!is_zero(value)) {
+                        const f3 c = T * value * mi_weight(phasePdf, emitterPdf);
+                        L = L + mod_weight<EXTRA>(P, c, plen + edge_length(P, trOpt + extra));
+                        film_contribute(P, px, py, c, plen + edge_length(P, trOpt + extra));
+                    }
                 }
                 ev = EV_AFTER_LOOKUP;
             }
@@ -603,6 +634,30 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
                 L = L + mod_weight<EXTRA>(P, c, plen + edge_length(P, optLen));
                 film_contribute(P, px, py, c, plen + edge_length(P, optLen));
             }
+            // ---- luminaire sampling of the area emitter (scene.cpp:854-874, area.cpp:162-177, shape.cpp:102-115); its MIS partner is the look-up below
+            if (EXTRA && !CURVED && P.has_area && ev == EV_PHASE) {
+                C.nee++;
+                const int interactions = maxDepth - depth - 1;
+                const float sx = rng.next1D(), sy = rng.next1D();
+                f3 dvec; float dist, dpdf;
+                f3 value = rect_sample_direct(P, ps, sx, sy, dvec, dist, dpdf);
+                if (!is_zero(value)) {
+                    const float tExit = intersect_shape_b<BND>(P, ps, dvec, 0.0f, MER_INF);      // the segment crosses the (null) boundary once on its way out
+                    const bool crosses = tExit >= 0 && tExit < dist;
+                    f3 trA(1, 1, 1);
+                    if (crosses && interactions == 0) trA = f3(0, 0, 0);
+                    else trA = straight_transmittance<SIGMA>(P, rng, C, ps, dvec, crosses ? tExit : dist);
+                    value = value * trA;
+                    if (!is_zero(value)) {
+                        const float phaseVal = phase_eval(S.phase, S.g, wi, dvec);
+                        if (phaseVal != 0) {
+                            const f3 c = T * value * phaseVal * mi_weight(dpdf, phaseVal);       // on-surface emitter, solid-angle measure: phasePdf = phase->pdf = its value
+                            L = L + mod_weight<EXTRA>(P, c, plen + edge_length(P, dist * S.rif_const));
+                            film_contribute(P, px, py, c, plen + edge_length(P, dist * S.rif_const));
+                        }
+                    }
+                }
+            }
             // ---- phase function sampling: volpath.cpp:149-160
             const float p2x = rng.next1D(), p2y = rng.next1D();
             f3 wo;
@@ -610,7 +665,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
             dsave = wo;
             if (CURVED) { itsT = 0; SET_FLAG(F_ITSVALID, true); }
             else { itsT = intersect_shape_b<BND>(P, ps, wo, 0.0f, MER_INF); SET_FLAG(F_ITSVALID, itsT >= 0); }
-            if (hasEnv) {
+            if (hasEnv || (EXTRA && P.has_area)) {
                 W.kind = K_LOOKUP;
                 trOpt = (!CURVED && itsValid) ? itsT * S.rif_const : 0.0f;
                 if (!CURVED && !itsValid) { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
@@ -658,13 +713,22 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
                 if (!itsValid && emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
             } else
             if (!itsValid) {
-                if (emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
+                if (emitted && (!S.hide_emitters || scattered)) {
+                    float extra; const f3 Le = escape_radiance<EXTRA && !CURVED>(P, env, ps, dsave, 0.0f, extra);
+                    const float pl = plen + (S.decomposition != MER_DECOMPOSITION_BOUNCE ? extra : 0.0f);
+                    L = L + mod_weight<EXTRA>(P, T * Le, pl); film_contribute(P, px, py, T * Le, pl);
+                }
             } else if (!(depth >= maxDepth && maxDepth != -1)) {
                 (void) rng.next1D(); (void) rng.next1D();                             // null BSDF sample
                 SET_FLAG(F_EMITTED, !scattered);
                 depth++;
                 if (depth <= maxDepth || maxDepth < 0)
-                    if (emitted && (!S.hide_emitters || scattered)) { L = L + mod_weight<EXTRA>(P, T * env, plen); film_contribute(P, px, py, T * env, plen); }
+                    if (emitted && (!S.hide_emitters || scattered)) {
+                        // outside the (convex) shape now: the environment, or the area emitter's rectangle (straight rays: from the exit point ps + itsT dsave)
+                        float extra; const f3 Le = escape_radiance<EXTRA && !CURVED>(P, env, ps + dsave * itsT, dsave, 0.0f, extra);
+                        const float pl = plen + (S.decomposition != MER_DECOMPOSITION_BOUNCE ? extra : 0.0f);
+                        L = L + mod_weight<EXTRA>(P, T * Le, pl); film_contribute(P, px, py, T * Le, pl);
+                    }
             }
         } else {  // EV_PATH_DONE: ImageBlock::put (imageblock.h:124-205)
             if (P.path_out) {

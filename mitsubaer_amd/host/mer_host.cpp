@@ -178,6 +178,13 @@ void Shape::addChild(const std::string &name, ObjRef child) {
         } else if (name == "exterior") Log_EError("Shape: an 'exterior' medium is not supported on the GPU path (the sensor must be in vacuum)");
         else Log_EError("Shape: Invalid medium child (must be named 'interior' or 'exterior')!");    // shape.cpp:186-188
     } else if (cls == "BSDF") { /* recorded before the children are attached (see build()) */ }
+    else if (cls == "Emitter") {                                         // src/librender/shape.cpp:137-146
+        auto e = std::static_pointer_cast<Emitter>(child);
+        if (areaEmitter) Log_EError("Tried to attach multiple emitters to a shape!");
+        if (e->kind != Emitter::EArea) Log_EError("Tried to attach a non-surface emitter to a shape");
+        if (!isRectangle) Log_EError("area emitter: only a 'rectangle' shape can carry one on the GPU path");
+        areaEmitter = e;
+    }
     else ConfigurableObject::addChild(name, child);
 }
 void Film::addChild(const std::string &name, ObjRef child) {
@@ -334,6 +341,15 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
     } else if (tag == "shape") {
         auto o = std::make_shared<Shape>();
         float m[16]; props.getTransform("toWorld", m);
+        if (type == "rectangle") {                                       // src/shapes/rectangle.cpp:99-110: the carrier of an `area` emitter; any shear-free toWorld
+            o->isRectangle = true;
+            for (int i = 0; i < 12; i++) o->rectToWorld[i] = m[i];
+            const double du[3] = {m[0], m[4], m[8]}, dv[3] = {m[1], m[5], m[9]};
+            const double lu = std::sqrt(du[0] * du[0] + du[1] * du[1] + du[2] * du[2]), lv = std::sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+            if (!(lu > 0 && lv > 0) || std::fabs((du[0] * dv[0] + du[1] * dv[1] + du[2] * dv[2]) / (lu * lv)) > 1e-4) Log_EError("Error: 'toWorld' transformation contains shear!");   // :108-109
+            out = o;
+            return out;
+        }
         for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
             if (r != c && std::fabs(m[r * 4 + c]) > 1e-6f) Log_EError("shape: only scale + translate 'toWorld' transforms are supported on the GPU path");
         if (type == "cube") {
@@ -355,7 +371,7 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
             }
             if (!any) Log_EError("obj: no vertices found");
             for (int i = 0; i < 3; i++) { float a = lo[i] * m[i * 4 + i] + m[i * 4 + 3], b = hi[i] * m[i * 4 + i] + m[i * 4 + 3]; o->bmin[i] = std::min(a, b); o->bmax[i] = std::max(a, b); }
-        } else Log_EError("shape \"" + type + "\" is not supported on the GPU path (cube, sphere, obj bounding box)");
+        } else Log_EError("shape \"" + type + "\" is not supported on the GPU path (cube, sphere, obj bounding box; rectangle with an area emitter)");
         out = o;
     } else if (tag == "sensor") {
         if (type != "perspective") Log_EError("sensor \"" + type + "\" is not supported on the GPU path (perspective)");
@@ -422,7 +438,11 @@ ObjRef createObject(const std::string &tag, const Properties &props, const std::
                 o->position = props.getPoint("position");
             } else { float m[16]; props.getTransform("toWorld", m); o->position = Vec3{m[3], m[7], m[11]}; }
             o->radiance = props.getSpectrum("intensity", Spectrum{{1, 1, 1}});
-        } else Log_EError("emitter \"" + type + "\" is not supported on the GPU path (constant, point)");
+        } else if (type == "area") {                                     // src/emitters/area.cpp:67-80: child of a shape, which gives it its transformation
+            o->kind = Emitter::EArea;
+            if (props.hasProperty("toWorld")) Log_EError("Found a 'toWorld' transformation -- this is not allowed -- the area light inherits this transformation from its parent shape");
+            o->radiance = props.getSpectrum("radiance", Spectrum{{1, 1, 1}});
+        } else Log_EError("emitter \"" + type + "\" is not supported on the GPU path (constant, point, area)");
         out = o;
     } else Log_EError("Unsupported scene element <" + tag + ">");
     return out;
@@ -691,9 +711,18 @@ void Integrator::flatten(const Scene &scene, mer_scene_desc &d) const {
     }
     d.phase = m.phase->kind; d.g = m.phase->g;
     d.tr_estimator = m.trEstimator; d.method = m.method; d.het_stepsize = m.hetStepSize;
-    int nconst = 0, npoint = 0;
-    for (int i = 0; i < 3; i++) { d.env_radiance[i] = 0; d.point_intensity[i] = 0; d.point_position[i] = 0; d.emission[i] = m.emission.c[i]; }
+    int nconst = 0, npoint = 0, narea = 0;
+    for (int i = 0; i < 3; i++) { d.env_radiance[i] = 0; d.point_intensity[i] = 0; d.point_position[i] = 0; d.emission[i] = m.emission.c[i]; d.area_radiance[i] = 0; }
+    for (int i = 0; i < 12; i++) d.area_to_world[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    for (auto &sh : scene.shapes) {
+        if (!sh->isRectangle) continue;
+        if (!sh->areaEmitter) Log_EError("shape \"rectangle\" is supported on the GPU path as the carrier of an area emitter only");
+        if (++narea > 1) Log_EError("Only one area emitter is supported on the GPU path");
+        for (int i = 0; i < 12; i++) d.area_to_world[i] = sh->rectToWorld[i];
+        for (int i = 0; i < 3; i++) d.area_radiance[i] = sh->areaEmitter->radiance.c[i];
+    }
     for (auto &e : scene.emitters) {
+        if (e->kind == Emitter::EArea) Log_EError("An area light must be child of a shape instance");            // area.cpp:200-201
         if (e->kind == Emitter::EPoint) {
             if (++npoint > 1) Log_EError("Only one point emitter is supported on the GPU path");
             d.point_position[0] = e->position.x; d.point_position[1] = e->position.y; d.point_position[2] = e->position.z;

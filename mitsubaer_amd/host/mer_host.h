@@ -9,7 +9,7 @@
 //   Medium                homogeneous | heterogeneous | heterogeneousrefractive   include/mitsuba/render/medium.h:113-234
 //   Shape                 cube | sphere | obj (bounding box), `interior` medium, null BSDF   src/librender/shape.cpp:48-70,166-190
 //   Sensor / Film / ReconstructionFilter / Sampler      perspective, hdrfilm, gaussian | box, independent | ldsampler
-//   Emitter               constant
+//   Emitter               constant | point | area (on a rectangle shape)
 //   Integrator            volpath -> render() flattens the scene to mer_scene_desc and calls mer_render
 //   SceneHandler          scene-XML subset with $param substitution    src/librender/scenehandler.cpp, src/mitsuba/mitsuba.cpp:58,168-173
 //
@@ -133,6 +133,8 @@ public:
     int boundary = MER_BOUNDARY_AABB;
     float bmin[3] = {-1, -1, -1}, bmax[3] = {1, 1, 1}, center[3] = {0, 0, 0}, radius = 1;
     std::shared_ptr<Medium> interior;
+    bool isRectangle = false; float rectToWorld[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};   ///< `rectangle` (src/shapes/rectangle.cpp): carrier of an area emitter
+    std::shared_ptr<class Emitter> areaEmitter;
     bool hasBSDF = false;              ///< a bsdf child was given (null | hdielectric)
     int bsdf = MER_BSDF_NULL;          ///< MER_BSDF_*
 };
@@ -178,8 +180,8 @@ public:
 class Emitter : public ConfigurableObject {
 public:
     const char *getClassName() const override { return "Emitter"; }
-    enum Kind { EConstant, EPoint } kind = EConstant;
-    Spectrum radiance{};                        // constant: radiance ; point: intensity
+    enum Kind { EConstant, EPoint, EArea } kind = EConstant;
+    Spectrum radiance{};                        // constant / area: radiance ; point: intensity
     Vec3 position{0, 0, 0};                     // point (src/emitters/point.cpp:60-68)
 };
 

@@ -102,6 +102,9 @@ class SceneParams:
         self.env_radiance = [1.0, 1.0, 1.0]
         self.emission = [0.0, 0.0, 0.0]
         self.point_position = [0.0, 0.0, 0.0]; self.point_intensity = [0.0, 0.0, 0.0]     # emitter `point`
+        # emitter `area` on a `rectangle` shape (src/emitters/area.cpp, src/shapes/rectangle.cpp): the image of [-1,1]^2 x {0} under area_to_world
+        # (3x4 or 4x4, no shear; None = identity), radiance into the half space of its normal toWorld(0,0,1); zero radiance = none
+        self.area_to_world = None; self.area_radiance = [0.0, 0.0, 0.0]
         # film decomposition (src/librender/film.cpp:56-84): 0 none | 1 transient | 2 bounce (bins by edge count); frames = ceil((max-min)/binWidth)
         self.decomposition = DECOMPOSITION_NONE; self.min_bound = 0.0; self.max_bound = 0.0; self.bin_width = 1.0
         self.calibrated_transient = False

@@ -662,6 +662,63 @@ struct Scene {
     Grid sdfGrid; Float sdfEps = 0;
     int frames = 1;                /* film.cpp:71-78 */
     Float modPhase = 0;            /* radians */
+    /* `area` emitter on a `rectangle` (rectangle.cpp:99-110): objectToWorld, its inverse, the frame normal, 1 / area */
+    bool hasArea = false; Float rectO2W[12], rectW2O[12], rectInvArea = 0; Vec rectN; Spec rectRadiance;
+    bool configureArea() {
+        hasArea = s.area_radiance[0] != 0 || s.area_radiance[1] != 0 || s.area_radiance[2] != 0;
+        if (!hasArea) return true;
+        if (s.rif_mode != ORC_RIF_CONST) { g_err = "the area emitter is built for straight rays (rif_mode = CONST)"; return false; }
+        if (s.boundary_bsdf != ORC_BSDF_NULL || s.boundary == 2) { g_err = "the area emitter needs an index-matched cube / sphere boundary"; return false; }
+        double M[3][4], inv[3][3];
+        for (int i = 0; i < 12; i++) { rectO2W[i] = s.area_to_world[i]; M[i / 4][i % 4] = s.area_to_world[i]; }
+        const double det = M[0][0] * (M[1][1] * M[2][2] - M[1][2] * M[2][1]) - M[0][1] * (M[1][0] * M[2][2] - M[1][2] * M[2][0]) + M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
+        if (!(std::fabs(det) > 0)) { g_err = "area emitter: 'toWorld' is singular"; return false; }
+        inv[0][0] = (M[1][1] * M[2][2] - M[1][2] * M[2][1]) / det; inv[0][1] = (M[0][2] * M[2][1] - M[0][1] * M[2][2]) / det; inv[0][2] = (M[0][1] * M[1][2] - M[0][2] * M[1][1]) / det;
+        inv[1][0] = (M[1][2] * M[2][0] - M[1][0] * M[2][2]) / det; inv[1][1] = (M[0][0] * M[2][2] - M[0][2] * M[2][0]) / det; inv[1][2] = (M[0][2] * M[1][0] - M[0][0] * M[1][2]) / det;
+        inv[2][0] = (M[1][0] * M[2][1] - M[1][1] * M[2][0]) / det; inv[2][1] = (M[0][1] * M[2][0] - M[0][0] * M[2][1]) / det; inv[2][2] = (M[0][0] * M[1][1] - M[0][1] * M[1][0]) / det;
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) rectW2O[4 * i + j] = (Float) inv[i][j];
+            rectW2O[4 * i + 3] = (Float) -(inv[i][0] * M[0][3] + inv[i][1] * M[1][3] + inv[i][2] * M[2][3]);
+        }
+        /* rectangle.cpp:102-110: dpdu = o2w(2,0,0), dpdv = o2w(0,2,0), normal = normalize(o2w(Normal(0,0,1))) = the inverse transpose's third column */
+        const double du[3] = {2 * M[0][0], 2 * M[1][0], 2 * M[2][0]}, dv[3] = {2 * M[0][1], 2 * M[1][1], 2 * M[2][1]};
+        const double lu = std::sqrt(du[0] * du[0] + du[1] * du[1] + du[2] * du[2]), lv = std::sqrt(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2]);
+        if (std::fabs((du[0] * dv[0] + du[1] * dv[1] + du[2] * dv[2]) / (lu * lv)) > Epsilon) { g_err = "Error: 'toWorld' transformation contains shear!"; return false; }   /* :108-109 */
+        const double nn[3] = {inv[2][0], inv[2][1], inv[2][2]}, ln = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+        rectN = Vec((Float) (nn[0] / ln), (Float) (nn[1] / ln), (Float) (nn[2] / ln));
+        rectInvArea = (Float) (1.0 / (lu * lv));                                   /* :107,121-123 */
+        rectRadiance = Spec(s.area_radiance[0], s.area_radiance[1], s.area_radiance[2]);
+        return true;
+    }
+    /* Rectangle::rayIntersect (rectangle.cpp:125-148): t or -1 */
+    inline Float rectIntersect(const Vec &o, const Vec &d, Float mint, Float maxt) const {
+        const Float *W = rectW2O;
+        const Float oz = W[8] * o.x + W[9] * o.y + W[10] * o.z + W[11], dz = W[8] * d.x + W[9] * d.y + W[10] * d.z;
+        const Float hit = -oz / dz;
+        if (!(hit >= mint && hit <= maxt)) return -1;
+        const Float lx = (W[0] * o.x + W[1] * o.y + W[2] * o.z + W[3]) + hit * (W[0] * d.x + W[1] * d.y + W[2] * d.z),
+                    ly = (W[4] * o.x + W[5] * o.y + W[6] * o.z + W[7]) + hit * (W[4] * d.x + W[5] * d.y + W[6] * d.z);
+        return (std::abs(lx) <= 1 && std::abs(ly) <= 1) ? hit : -1;
+    }
+    /* AreaLight::eval (area.cpp:102-107): radiance leaving the rectangle along -d for a ray travelling along d */
+    inline Spec rectLe(const Vec &d) const { return dot(rectN, -d) <= 0 ? Spec(0.0f) : rectRadiance; }
+    /* Shape::sampleDirect + AreaLight::sampleDirect (shape.cpp:102-115, area.cpp:162-177) for a reference point in a medium (refN = 0);
+       returns radiance / pdf (0 = back side), direction, distance and the solid-angle pdf */
+    inline Spec rectSampleDirect(const Vec &ref, Float sx, Float sy, Vec &d, Float &dist, Float &pdf) const {
+        const Float *M = rectO2W; const Float lx = sx * 2 - 1, ly = sy * 2 - 1;
+        const Vec p(M[0] * lx + M[1] * ly + M[3], M[4] * lx + M[5] * ly + M[7], M[8] * lx + M[9] * ly + M[11]);
+        d = p - ref;
+        const Float distSquared = dot(d, d);
+        dist = std::sqrt(distSquared);
+        d = d / dist;                                                              /* TVector3::operator/=: reciprocal, then multiply */
+        const Float dp = std::abs(dot(d, rectN));
+        pdf = rectInvArea * (dp != 0 ? (distSquared / dp) : 0.0f);
+        if (dot(d, rectN) < 0 && pdf != 0) return rectRadiance / pdf;
+        pdf = 0.0f;
+        return Spec(0.0f);
+    }
+    /* AreaLight::pdfDirect (area.cpp:179-187) for a hit at distance dist along d */
+    inline Float rectPdfDirect(const Vec &d, Float dist) const { return dot(d, rectN) < 0 ? rectInvArea * (dist * dist) / std::abs(dot(d, rectN)) : 0.0f; }
     /* include/mitsuba/render/pathlengthsampler.h:32-42 */
     inline Float mSeq(Float t, Float phase) const {
         const Float lambda = s.mod_lambda; const int mP = s.mod_P;
@@ -762,7 +819,7 @@ struct Scene {
         cotHalfFov = 1.0f / std::tan((s.fov_x_deg / 2.0f) * (M_PI_F / 180.0f));  /* transform.cpp:99-123 */
         invResX = 1.0f / s.width; invResY = 1.0f / s.height;
         filterTable(s.rfilter, s.rfilter_param, fvalues, fradius, fscale);
-        return true;
+        return configureArea();
     }
     static Float filterEval(int kind, Float param, Float radius, Float x) {
         if (kind == ORC_FILTER_BOX) return std::abs(x) <= radius ? 1.0f : 0.0f;     /* src/rfilters/box.cpp */
@@ -1778,6 +1835,15 @@ struct Walker {
         const Spec pointI(P.point_intensity[0], P.point_intensity[1], P.point_intensity[2]);
         const bool hasPoint = !pointI.isZero();
         const Vec pointP(P.point_position[0], P.point_position[1], P.point_position[2]);
+        const bool hasArea = S.hasArea;
+        const Float INF = std::numeric_limits<Float>::infinity();
+        /* what a ray sees that has left the convex medium shape for good (or never meets it): the rectangle emitter if it is hit -- its front
+           side emits, its back side is black, and it hides the environment either way (all-absorbing BSDF) -- else the environment */
+        auto escape = [&](const Vec &o, const Vec &d, Float mint, Float &extra) -> Spec {
+            extra = 0;
+            if (hasArea) { const Float t = S.rectIntersect(o, d, mint, INF); if (t >= 0) { extra = t * P.rif_const; return S.rectLe(d); } }
+            return env;
+        };
         Spec Li(0.0f), throughput(1.0f);
         Float plen = 0;                                            /* optical path length sensor -> current vertex (transient film) */
         Float eta = 1.0f;
@@ -1787,6 +1853,15 @@ struct Walker {
         Float itsT = S.intersectShape(ro, rd, rmint, rmaxt);       /* rRec.rayIntersect(ray) */
         bool itsValid = itsT >= 0;
         const int maxDepth = P.max_depth;
+        if (hasArea) {
+            /* the camera ray meets the rectangle before the medium shape (or instead of it): its.isEmitter() => Li += Le (volpath.cpp:203-206), then
+               the all-absorbing BSDF ends the path */
+            const Float tr = S.rectIntersect(ro, rd, rmint, rmaxt);
+            if (tr >= 0 && (!itsValid || tr < itsT)) {
+                if (!P.hide_emitters) { const Spec Le = S.rectLe(rd); Li += Le; contribute(Le, (P.calibrated_transient && P.decomposition == 1) ? 0.0f : el(tr * P.rif_const)); }
+                return S.s.modulation != 0 ? modL : Li;
+            }
+        }
 
         while (depth <= maxDepth || maxDepth < 0) {
             if (medium && sampleDistance(ro, rd, itsT, mRec)) {
@@ -1819,6 +1894,7 @@ struct Walker {
                             tr = tExit >= 0 ? evalTransmittance(mRec.p, dd, tExit) : Spec(1.0f);
                         } else tr = evalTransmittance(mRec.p, dd, 0);
                     }
+                    if (hasArea && S.rectIntersect(mRec.p, dd, 0.0f, INF) >= 0) tr = Spec(0.0f);     /* the rectangle shadows the environment (Scene::evalTransmittance stops at a non-null surface) */
                     value *= tr;
                     if (dbg) printf("orc NEE depth=%d T=%g L=%g tr=%g rng=%llu\n", depth, throughput[0], Li[0], tr[0], (unsigned long long) rng.state);
                     if (!value.isZero()) {
@@ -1875,6 +1951,31 @@ struct Walker {
                         }
                     }
                 }
+                /* ---- luminaire sampling of the area emitter: scene.cpp:854-874 + area.cpp:162-177 + shape.cpp:102-115; MIS partner = phase sampling */
+                if (hasArea) {
+                    C.c[ORC_C_NEE]++;
+                    const int interactions = maxDepth - depth - 1;
+                    const Float sx = rng.next1D(), sy = rng.next1D();
+                    Vec dvec; Float dist, dpdf;
+                    Spec value = S.rectSampleDirect(mRec.p, sx, sy, dvec, dist, dpdf);
+                    if (!value.isZero()) {
+                        /* the segment crosses the (null) boundary of the convex medium shape once on its way out (scene.cpp:619-678) */
+                        const Float tExit = S.intersectShape(mRec.p, dvec, 0.0f, INF);
+                        const bool crosses = tExit >= 0 && tExit < dist;
+                        Spec tr(1.0f);
+                        if (crosses && interactions == 0) tr = Spec(0.0f);
+                        else tr = evalTransmittance(mRec.p, dvec, crosses ? tExit : dist);
+                        value *= tr;
+                        if (!value.isZero()) {
+                            const Float phaseVal = phaseEval(P.phase, P.g, wi, dvec);
+                            if (phaseVal != 0) {
+                                const Float weight = miWeight(dpdf, phaseVal);       /* emitter->isOnSurface(), solid-angle measure: phasePdf = phase->pdf = its value */
+                                Li += throughput * value * phaseVal * weight;
+                                contribute(throughput * value * phaseVal * weight, plen + el(dist * P.rif_const));
+                            }
+                        }
+                    }
+                }
                 /* ---- phase function sampling: volpath.cpp:149-158 */
                 Float phasePdf; Vec wo;
                 Float p2x = rng.next1D(), p2y = rng.next1D();
@@ -1885,7 +1986,7 @@ struct Walker {
                 /* rayIntersectAndLookForEmitter: volpath.cpp:370-428 */
                 if (S.curved) { itsT = 0; itsValid = true; }
                 else { itsT = S.intersectShape(ro, rd, 0.0f, std::numeric_limits<Float>::infinity()); itsValid = itsT >= 0; }
-                if (hasEnv) {
+                if (hasEnv || hasArea) {
                     Spec tr(1.0f);
                     lastTrOpt = 0;
                     int maxInteractions = maxDepth - depth - 1;
@@ -1899,9 +2000,17 @@ struct Walker {
                     if (dbg) printf("orc LOOKUP depth=%d T=%g L=%g tr=%g rng=%llu\n", depth, throughput[0], Li[0], tr[0], (unsigned long long) rng.state);
                     if (!blocked && !tr.isZero()) {
                         Spec value = tr * env;
-                        Float emitterPdf = INV_FOURPI_F;
-                        Li += throughput * value * miWeight(phasePdf, emitterPdf);
-                        contribute(throughput * value * miWeight(phasePdf, emitterPdf), plen + el(lastTrOpt));
+                        Float emitterPdf = INV_FOURPI_F, extra = 0;
+                        if (hasArea) {
+                            /* rayIntersectAndLookForEmitter (volpath.cpp:370-428): beyond the null boundary the ray meets the rectangle or the environment */
+                            const Float tRect = S.rectIntersect(ro, rd, 0.0f, INF);
+                            if (tRect >= 0) { value = tr * S.rectLe(rd); emitterPdf = S.rectPdfDirect(rd, tRect); extra = (tRect - (itsValid ? itsT : 0)) * P.rif_const; }
+                            else if (!hasEnv) value = Spec(0.0f);
+                        }
+                        if (!value.isZero()) {
+                            Li += throughput * value * miWeight(phasePdf, emitterPdf);
+                            contribute(throughput * value * miWeight(phasePdf, emitterPdf), plen + el(lastTrOpt + extra));
+                        }
                     }
                 }
                 emitted = false;                              /* ERadianceNoEmission */
@@ -1916,7 +2025,10 @@ struct Walker {
                     }
                 }
                 if (!itsValid) {
-                    if (emitted && (!P.hide_emitters || scattered)) { Li += throughput * env; contribute(throughput * env, plen); }   /* volpath.cpp:194-201 */
+                    if (emitted && (!P.hide_emitters || scattered)) {                                    /* volpath.cpp:194-201 (environment), :203-206 (its.isEmitter()) */
+                        Float extra; const Spec Le = escape(ro, rd, 0.0f, extra);
+                        Li += throughput * Le; contribute(throughput * Le, plen + (P.decomposition == 2 ? 0.0f : extra));     /* the free-space leg to the rectangle: optical length, no further bounce */
+                    }
                     break;
                 }
                 if (depth >= maxDepth && maxDepth != -1) break;

@@ -99,6 +99,11 @@ typedef struct {
        density along straight rays: integrateDensity / invertDensityIntegral, :301-544); het_stepsize = its `stepSize`, 0 = inferred from
        the density grid (0.5 x the smallest voxel extent, gridvolume.cpp:196-198) */
     int32_t method; float het_stepsize;
+    /* emitter `area` on a `rectangle` shape (src/emitters/area.cpp, src/shapes/rectangle.cpp:99-222): the rectangle is the image of [-1,1]^2 x {0}
+       under area_to_world (row-major 3x4, no shear); one-sided (radiance into the half space of the normal toWorld(0,0,1)); it absorbs what
+       hits it (an emitter without BSDF gets an all-absorbing diffuse one, src/librender/shape.cpp:48-56).  All-zero radiance = none.
+       Outside the medium shape; straight rays, null boundary. */
+    float   area_to_world[12], area_radiance[3];
 } orc_scene;
 enum { ORC_BSDF_NULL = 0, ORC_BSDF_HDIELECTRIC = 1 };
 

@@ -59,6 +59,7 @@ class Scene(C.Structure):
         ("sdf_max_error", C.c_float),
         ("ac_n_o", C.c_float), ("ac_n_max", C.c_float), ("ac_k_r", C.c_float), ("ac_mode", C.c_int32),
         ("method", C.c_int32), ("het_stepsize", C.c_float),
+        ("area_to_world", C.c_float * 12), ("area_radiance", C.c_float * 3),
     ]
 
 
@@ -160,6 +161,10 @@ def make_scene(p):
     s.modulation = p.modulation; s.mod_lambda = p.mod_lambda; s.mod_phase_deg = p.mod_phase_deg; s.mod_P = p.mod_P; s.mod_neighbors = p.mod_neighbors
     s.boundary_bsdf = p.boundary_bsdf
     s.aggressive_tracing = int(getattr(p, "aggressive_tracing", False)); s.sdf_max_error = _sdf_max_error(p)
+    a2w = getattr(p, "area_to_world", None)
+    m = np.eye(4); t = np.asarray(a2w if a2w is not None else np.eye(4), np.float64); m[:t.shape[0], :4] = t
+    s.area_to_world[:] = [float(v) for v in m[:3, :4].astype(np.float32).reshape(-1)]
+    s.area_radiance[:] = getattr(p, "area_radiance", [0.0, 0.0, 0.0])
     return s, keep
 
 

@@ -213,7 +213,25 @@ public:
         for (size_t i = 0; i < emitters.size(); ++i) {
             const Emitter *e = emitters[i].get();
             if (e->isEnvironmentEmitter()) continue;
-            if (e->getClass()->getName() != "PointEmitter") Log(EError, "volpath_hip: emitters must be 'constant' or 'point'");
+            if (e->getClass()->getName() == "AreaLight") {
+                /* `area` emitter on a `rectangle` shape (src/emitters/area.cpp, src/shapes/rectangle.cpp): the rectangle keeps its objectToWorld private,
+                   so the transform is recovered from three corner samples (Rectangle::samplePosition, :210-216: p = toWorld(2u - 1, 2v - 1, 0)) */
+                const Shape *rs = e->getShape();
+                if (!rs || rs->getClass()->getName() != "Rectangle") Log(EError, "volpath_hip: an area emitter must sit on a 'rectangle' shape");
+                PositionSamplingRecord p00(0.0f), p10(0.0f), p01(0.0f);
+                rs->samplePosition(p00, Point2(0, 0)); rs->samplePosition(p10, Point2(1, 0)); rs->samplePosition(p01, Point2(0, 1));
+                const Vector du = (p10.p - p00.p) * 0.5f, dv = (p01.p - p00.p) * 0.5f;
+                const Point c = p00.p + du + dv;
+                const Normal n = p00.n;                                                          /* the frame normal, toWorld(Normal(0,0,1)) normalized */
+                const float cols[3][4] = { { du.x, dv.x, n.x, c.x }, { du.y, dv.y, n.y, c.y }, { du.z, dv.z, n.z, c.z } };
+                for (int r = 0; r < 3; ++r) for (int k = 0; k < 4; ++k) d.area_to_world[4 * r + k] = cols[r][k];
+                PositionSamplingRecord pr(0.0f); rs->samplePosition(pr, Point2(0.5f));
+                const Spectrum Le = e->evalPosition(pr) * INV_PI;                                 /* AreaLight::evalPosition = radiance * pi (area.cpp:98-100) */
+                Float r, g, b; Le.toLinearRGB(r, g, b);
+                d.area_radiance[0] = r; d.area_radiance[1] = g; d.area_radiance[2] = b;
+                continue;
+            }
+            if (e->getClass()->getName() != "PointEmitter") Log(EError, "volpath_hip: emitters must be 'constant', 'point' or 'area' (on a rectangle)");
             PositionSamplingRecord pRec(0.0f);
             const Spectrum I = e->samplePosition(pRec, Point2(0.5f)) / (4 * M_PI);       /* src/emitters/point.cpp:82-90 */
             Float r, g, b; I.toLinearRGB(r, g, b);
@@ -266,7 +284,10 @@ private:
         const Shape *found = NULL;
         const ref_vector<Shape> &shapes = scene->getShapes();
         for (size_t i = 0; i < shapes.size(); ++i) {
-            if (!shapes[i]->getInteriorMedium()) continue;
+            if (!shapes[i]->getInteriorMedium()) {
+                if (!shapes[i]->isEmitter()) SLog(EError, "volpath_hip: a shape without an interior medium must be a rectangle carrying an area emitter");
+                continue;
+            }
             if (found && shapes[i]->getInteriorMedium() != found->getInteriorMedium())
                 SLog(EError, "volpath_hip: exactly one medium (on one convex shape) is supported");
             if (!found) found = shapes[i].get();

@@ -355,3 +355,39 @@ def test_albedo_volume_emission_and_strategy_render_like_the_direct_c_abi(tmp_pa
     p = scenes.homogeneous_scene(w=40, h=32, fov_x_deg=45.0, rfilter=P.FILTER_BOX, rfilter_param=0.5, strategy=P.STRATEGY_MAXIMUM, sigma_s=[0.5, 3.5, 7.5], sigma_a=[0.05] * 3)
     sc, vols = ctx.upload_scene(p)
     assert np.allclose(film, ctx.render_to_host(sc, 0, 4, seed=2), rtol=1e-5, atol=1e-6)
+
+
+def test_rectangle_area_emitter_flattens(tmp_path):
+    """<shape type="rectangle"> with an <emitter type="area"> child (src/shapes/rectangle.cpp, src/emitters/area.cpp): the shape's toWorld and the
+    emitter's radiance reach mer_scene_desc.area_to_world / area_radiance; the reference's error texts for a stray area light and a sheared rectangle"""
+    body = ('<integrator type="volpath"/>' + CAM + '<medium type="homogeneous" id="m"><spectrum name="sigmaS" value="1"/></medium><shape type="cube"><ref name="interior" id="m"/></shape>'
+            '<shape type="rectangle"><transform name="toWorld"><scale x="1.5" y="1.5"/><rotate x="1" y="0" z="0" angle="90"/><translate x="0" y="2.5" z="0"/></transform>'
+            '<emitter type="area"><spectrum name="radiance" value="3, 2, 1"/></emitter></shape>')
+    d, _ = host.flatten_xml(_scene(tmp_path, body))
+    assert np.allclose(list(d.area_radiance), [3, 2, 1])
+    m = np.array(list(d.area_to_world)).reshape(3, 4)
+    assert np.allclose(m[:, 3], [0, 2.5, 0]) and np.allclose(np.linalg.norm(m[:, 0]), 1.5) and np.allclose(np.linalg.norm(m[:, 1]), 1.5)
+    assert np.allclose(m[:, 2], [0, -1, 0], atol=1e-6)                         # rotate(x, 90): local z -> -y: the rectangle faces down, towards the cube
+    with pytest.raises(host.HostError, match="must be child of a shape"):
+        host.flatten_xml(_scene(tmp_path, body.replace('</shape>', '</shape><emitter type="area"/>', 1)))
+    with pytest.raises(host.HostError, match="carrier of an area emitter"):
+        host.flatten_xml(_scene(tmp_path, body.replace('<emitter type="area"><spectrum name="radiance" value="3, 2, 1"/></emitter>', '')))
+
+
+@pytest.mark.gpu
+def test_rectangle_area_emitter_renders_like_the_direct_c_abi(tmp_path, ctx):
+    cam = ('<sensor type="perspective"><float name="fov" value="45"/><transform name="toWorld"><lookat origin="-3,0,0" target="-2,0,0" up="0,1,0"/></transform>'
+           '<sampler type="independent"><integer name="sampleCount" value="4"/></sampler>'
+           '<film type="hdrfilm"><integer name="width" value="40"/><integer name="height" value="32"/><rfilter type="box"/></film></sensor>')
+    body = ('<integrator type="volpath"/>' + cam + '<medium type="homogeneous" id="m"><spectrum name="sigmaS" value="0.5, 3.5, 7.5"/><spectrum name="sigmaA" value="0.05"/></medium>'
+            '<shape type="cube"><ref name="interior" id="m"/></shape>'
+            '<shape type="rectangle"><transform name="toWorld"><scale x="1.5" y="1.5"/><rotate x="1" y="0" z="0" angle="90"/><translate x="0" y="2.5" z="0"/></transform>'
+            '<emitter type="area"><spectrum name="radiance" value="3, 2, 1"/></emitter></shape>')
+    f = _scene(tmp_path, body)
+    film = host.render_xml(f, seed=2)
+    d, _ = host.flatten_xml(f)
+    p = scenes.homogeneous_scene(w=40, h=32, fov_x_deg=45.0, rfilter=P.FILTER_BOX, rfilter_param=0.5, env_radiance=[0, 0, 0], area_radiance=[3, 2, 1],
+                                 area_to_world=np.array(list(d.area_to_world)).reshape(3, 4))
+    sc, vols = ctx.upload_scene(p)
+    assert np.allclose(film, ctx.render_to_host(sc, 0, 4, seed=2), rtol=1e-5, atol=1e-6)
+    assert film[..., :3].sum() > 0
