@@ -21,7 +21,7 @@ CASES = {
     "sphere_rect_in_view": lambda: scenes.straight_scene(N=24, w=48, h=40, boundary=P.BOUNDARY_SPHERE, sph_radius=0.9, area_to_world=SIDE, area_radiance=[2.0, 2.0, 4.0]),
     "rect_in_view_hidden": lambda: scenes.straight_scene(N=24, w=48, h=40, hide_emitters=True, area_to_world=SIDE, area_radiance=[2.0, 2.0, 4.0]),
     "max_depth_4": lambda: scenes.straight_scene(N=24, w=32, h=24, max_depth=4, **A),
-    "transient_rect": lambda: scenes.homogeneous_scene(w=24, h=20, env_radiance=[0, 0, 0], decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=0.0, max_bound=16.0, bin_width=1.0, **A),
+    "transient_rect": lambda: scenes.homogeneous_scene(w=24, h=20, env_radiance=[0, 0, 0], decomposition=P.DECOMPOSITION_TRANSIENT, min_bound=0.0, max_bound=64.0, bin_width=4.0, **A),     # 16 frames; no path is longer than 64
 }
 
 
