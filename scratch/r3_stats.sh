@@ -17,3 +17,4 @@ run cfg4_1024_spp128_pipes1 --workload cfg4 --res 1024 --size 1024 --spp 128 --s
 run cfg5_256_spp128 --workload cfg5 --spp 128 --steps 2 --warmup 1
 run cfg2_256 --workload cfg2 --spp 64
 run cfg2_256_pipes1 --workload cfg2 --spp 64 --options pipes=1 --no-solo-step
+run cfg2_256_two_kernels --workload cfg2 --spp 64 --options inline_walks=0
