@@ -61,6 +61,12 @@ def pmc_sums(outdir, family="march_kernel"):
     return acc if n else None
 
 
+def dominant_family(workload):
+    """kernel family whose counters the roofline is quoted on: K_march for curved rays; for straight rays K_event, which runs the walks itself
+    (option inline_walks, the default) -- unless the two-kernel form is forced"""
+    return "event_kernel" if workload == "cfg2" else "march_kernel"
+
+
 def live_pmc(workload, res, size, spp, layout, options, budget_s=240.0):
     """Counter passes of THIS workload taken in THIS run: for every entry of PMC_PASSES one child process `rocprofv3 --pmc <counters>
     --kernel-trace -- python3 bench.py <one single-pipeline step>`, started before this process touches the GPU (a GPU process must not
@@ -91,7 +97,7 @@ def live_pmc(workload, res, size, spp, layout, options, budget_s=240.0):
         except subprocess.TimeoutExpired:
             shutil.rmtree(out, ignore_errors=True)
             return None, "counter pass '%s' timed out" % name
-        sums = pmc_sums(out)
+        sums = pmc_sums(out, "march_kernel" if "inline_walks=0" in opts else dominant_family(workload))
         shutil.rmtree(out, ignore_errors=True)
         if r.returncode != 0 or not sums:
             return None, "counter pass '%s' failed (rc %d): %s" % (name, r.returncode, r.stderr.decode(errors="replace")[-200:])
@@ -103,7 +109,7 @@ def live_pmc(workload, res, size, spp, layout, options, budget_s=240.0):
                 return None, "counter pass '%s' printed no bench line" % name
     c = child["counters_per_step"]
     steps = c["eikonal_steps"] if c["eikonal_steps"] > 0 else c["tentative_collisions"]
-    wave_steps = c["lane_slots"] / 64.0
+    wave_steps = max(c["lane_slots"] / 64.0, 1.0)
     rd, wr, sq = got["rd"], got["write"], got["sq"]
     read_b = 128 * rd.get("TCC_EA0_RDREQ_128B_sum", 0.0) + 64 * rd.get("TCC_EA0_RDREQ_64B_sum", 0.0) + 32 * rd.get("TCC_EA0_RDREQ_32B_sum", 0.0)
     write_b = 1024 * wr.get("WRITE_SIZE", 0.0)
@@ -239,23 +245,30 @@ def roofline_block(ctx, capi, p, tag, solo, timed, layout_name, traffic=None, tr
     steps = float(c1[capi.C_STEPS]); tent = float(c1[capi.C_TENTATIVE]); paths = float(c1[capi.C_PATHS])
     b_alg = algorithmic_bytes(c1, p) - 40.0 * paths                       # K_march performs every field fetch; the film write is K_event's
     launches = max(n1, 1)
-    launch_ms = m1 / launches
+    inline = p.rif_mode == 0 and ctx.get_option("inline_walks") == 1 and p.sigma_mode == 1 and p.method == 0
+    if inline:
+        # straight rays: K_event runs the walks itself (persistent lanes) -- it IS the kernel that fetches the field; K_march's launches are empty
+        b_alg = algorithmic_bytes(c1, p)
+    dom_ms = e1 if inline else m1          # device time of the dominant kernel in the single-pipeline step
+    launch_ms = dom_ms / launches
     tr = traffic
     curved = p.rif_mode != 0
     unit_steps = steps if curved else tent           # the unit the counter bytes are quoted per: eikonal steps (curved rays) or tentative collisions (straight)
     out = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "kernel": ("mer::march_kernel<curved, %s trilinear, rk4, grid>" % layout_name) if curved else "mer::march_kernel<straight, grid sigma_t (cell8 records)>",
-           "kernel_avg_launch_ms": launch_ms, "launches_per_step": n1, "kernel_ms_per_step": m1, "event_kernel_ms_per_step": e1,
+           "kernel": ("mer::march_kernel<curved, %s trilinear, rk4, grid>" % layout_name) if curved else
+                     ("mer::event_kernel<straight, grid sigma_t, inline walks> (one persistent launch does most of a step: per-launch averages mean little here)" if inline
+                      else "mer::march_kernel<straight, grid sigma_t (cell8 records)>"),
+           "kernel_avg_launch_ms": launch_ms, "launches_per_step": n1, "kernel_ms_per_step": dom_ms, "march_kernel_ms_per_step": m1, "event_kernel_ms_per_step": e1,
            "step_wall_ms": wall1 * 1e3, "pipelines": 1,
            "what": "one untimed step rendered as ONE pipeline (option pipes = 1): K_march's launches have the chip to themselves, HIP events on the launch stream",
            "algorithmic_bytes_per_launch": b_alg / launches,
-           "algorithmic_GBps": b_alg / max(m1, 1e-9) / 1e6,
+           "algorithmic_GBps": b_alg / max(dom_ms, 1e-9) / 1e6,
            "counters_per_step": {"paths": paths, "eikonal_steps": steps, "tentative_collisions": tent, "real_collisions": float(c1[capi.C_REAL])},
            "active_lane_fraction": float(c1[capi.C_ACTIVE_LANES] / max(c1[capi.C_LOOP_ITERS], 1.0))}
     if tr:
         # fabric-side bytes per unit step (rocprofv3 --pmc: TCC_EA0_RDREQ by request size + WRITE_SIZE) x this step's unit steps
         hbm = tr["hbm_bytes_per_eikonal_step"] * unit_steps
-        out.update({"achieved": hbm / max(m1, 1e-9) / 1e6, "traffic": hbm / launches,
+        out.update({"achieved": hbm / max(dom_ms, 1e-9) / 1e6, "traffic": hbm / launches,
                     "reuse_factor": b_alg / max(hbm, 1.0), "bytes_per_unit_step": tr["hbm_bytes_per_eikonal_step"],
                     "traffic_source": ("counter passes taken inside this run (%.0f s): " % tr.get("seconds", 0) if tr.get("live") else
                                        "extrapolated from the committed counter pass %s [%s] (same kernel sources %s, layout, options): " % (os.path.relpath(TRAFFIC_FILE, ROOT), tag, tr.get("source_hash")))
@@ -269,11 +282,14 @@ def roofline_block(ctx, capi, p, tag, solo, timed, layout_name, traffic=None, tr
                    "working set (~0.3 GiB) is about the size of the 256 MiB Infinity Cache, so the DRAM share is unknown there; the 512^3 block (2.5 GiB) can be read as HBM")
     if tr and tr.get("valu_inst_per_wave_step") and curved:
         wave_steps = float(c1[capi.C_LOOP_ITERS]) / 64.0
-        ginst = tr["valu_inst_per_wave_step"] * wave_steps / max(m1, 1e-9) / 1e6
+        ginst = tr["valu_inst_per_wave_step"] * wave_steps / max(dom_ms, 1e-9) / 1e6
         out["valu"] = {"inst_per_wave_step": tr["valu_inst_per_wave_step"], "achieved_Ginst_s": ginst, "peak_Ginst_s": VALU_PEAK_GINST,
                        "frac": ginst / VALU_PEAK_GINST,
                        "note": "peak = independent v_fma_f32 issue (2.3 cycles per wave64 instruction, measured); a dependent one issues every ~4.3 cycles"}
     out["limiter"] = (tr or {}).get("limiter", "see DESIGN.md section 4")
+    if float(c1[capi.C_CONNECT_UNITS]) > 0:
+        out["dominant_kernel_note"] = ("this workload's device time is dominated by mer::connect_stage_kernel (curved-ray connection solver, ~90 %: "
+                                       "profiles/round3/stats/rocprofv3_kernel_stats_cfg5_256_spp128.csv); the block above is K_march's share only")
     if timed is not None:
         k_ms, m_ms, e_ms, n_pass, counters, pipes = timed
         b_step = algorithmic_bytes(counters, p)

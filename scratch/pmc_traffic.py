@@ -11,7 +11,8 @@ beyond L2, an upper bound of the HBM traffic."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, btag = sys.argv[1], sys.argv[2]
-limiter = sys.argv[3] if len(sys.argv) > 3 else None
+limiter = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] else None
+family = sys.argv[4] if len(sys.argv) > 4 else "march_kernel"      # kernel family the counters are summed over (configs[1]: event_kernel runs the walks)
 
 
 def sums(kind):
@@ -24,7 +25,7 @@ def sums(kind):
             cur = line.strip()
             continue
         m = re.match(r"\s+(\S+)\s+(\S+)\s+\(dispatches (\d+)\)", line)
-        if m and cur == "march_kernel":
+        if m and cur == family:
             out[m.group(1)] = {"sum": float(m.group(2)), "dispatches": int(m.group(3))}
     return out, d
 
@@ -41,6 +42,7 @@ import bench as _bench
 entry = {
     # what the pass was taken on: bench.py uses a committed entry only for the same kernel sources, RIF layout and options
     "source_hash": _bench.source_hash(), "layout": bench["config"]["layout"], "options": "pipes=1",
+    "kernel_family": family,
     "method": "rocprofv3 --pmc, separate passes of one single-pipeline bench step each (scratch/pmc_all.sh %s): read = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B, write = WRITE_SIZE; includes Infinity-Cache hits" % tag,
     "workload": bench["config"]["workload"], "march_launches": rd.get("TCC_EA0_RDREQ_sum", {}).get("dispatches"),
     "eikonal_steps": steps, "wave_steps": wave_steps,
