@@ -78,6 +78,9 @@ struct Rng {
         return (xorshifted >> rot) | (xorshifted << ((32u - rot) & 31u));
     }
     __device__ __forceinline__ float next1D() { return __uint_as_float((next() >> 9) | 0x3f800000u) - 1.0f; }
+    // The stream of a SIDE WALK (transmittance walk of a luminaire sample: kind 1; of an emitter look-up: kind 2): a child of the path's stream at
+    // the point where the walk starts.  The path's own stream does not advance while the walk runs, which makes the walk an independent piece of work.
+    __device__ __forceinline__ Rng fork(uint64_t kind) const { Rng c; c.state = splitmix64(state ^ (kind * 0xD1B54A32D192ED03ULL)); c.inc = inc; return c; }
 };
 
 // ------------------------------------------------------------------------------------------------

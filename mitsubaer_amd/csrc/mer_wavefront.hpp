@@ -402,13 +402,14 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
     const bool hasPoint = EXTRA && (S.point_intensity[0] != 0 || S.point_intensity[1] != 0 || S.point_intensity[2] != 0);
     const int maxDepth = S.max_depth;
     const int nwalks = (SIGMA == MER_SIGMA_GRID && S.tr_estimator == MER_TR_WOODCOCK2) ? 2 : 1;
-    enum { F_SCATTERED = 1, F_EMITTED = 2, F_ITSVALID = 4 };
+    enum { F_SCATTERED = 1, F_EMITTED = 2, F_ITSVALID = 4, F_FORKED = 8 };      // F_FORKED: the lane's sampler is a side walk's child stream; the path's own state waits in prng
 #define scattered ((flags & F_SCATTERED) != 0)
 #define emitted ((flags & F_EMITTED) != 0)
 #define itsValid ((flags & F_ITSVALID) != 0)
 #define SET_FLAG(f, v) flags = (v) ? (flags | (f)) : (flags & ~(f))
 
     WalkT W; Rng rng; uint32_t pixel = 0, sample = 0;
+    uint64_t prng = 0;                         // the path's sampler state while a side walk runs on its forked stream (Rng::fork)
     W.cc.reset();
     float px = 0, py = 0, sigma = 0, phasePdf = 0, itsT = 0;
     float etaPath = 1.0f;                      // relative index along the path (volpath.cpp:276; Russian roulette)
@@ -427,6 +428,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
         phasePdf = SLOTF(CO_PHASEPDF); itsT = SLOTF(CO_ITST); W.n0 = SLOTF(CO_N0); W.trsum = SLOTF(CO_TRSUM);
         W.sdens = SLOTF(CO_SDENS); W.tmin = SLOTF(CO_TMIN);
         plen = SLOTF(CO_PLEN); trOpt = SLOTF(CO_TROPT); if (EXTRA) etaPath = SLOTF(CO_ETA);
+        prng = (uint64_t) SLOT(CO_WNEXT_LO) | ((uint64_t) SLOT(CO_WNEXT_HI) << 32);
         px_i = (int) (pixel % (uint32_t) S.width); py_i = (int) (pixel / (uint32_t) S.width);
     } else {
         W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = 0; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.dist = 0;
@@ -570,12 +572,14 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
                     if (tExit >= 0) {
                         itsT = tExit;
                         if (!CURVED) trOpt = tExit * S.rif_const;
+                        prng = rng.state; rng = rng.fork(1); SET_FLAG(F_FORKED, true);       // the walk runs on a child stream (the oracle's sideTransmittance)
                         ev = W.begin(P, rng, C, K_NEE, ps, dd, tExit);
                         if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - tExit);
                     } else { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
                 } else { trv = f3(0, 0, 0); ev = EV_TR_DONE; }
             } else ev = EV_PHASE;
         } else if (ev == EV_TR_DONE) {
+            if (flags & F_FORKED) { rng.state = prng; SET_FLAG(F_FORKED, false); }           // the side walk is over: back on the path's own stream
             f3 tr = trv;
             if (W.kind == K_NEE) {
                 const float dpdf = MER_INV_FOURPI;
@@ -670,6 +674,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
                 trOpt = (!CURVED && itsValid) ? itsT * S.rif_const : 0.0f;
                 if (!CURVED && !itsValid) { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
                 else {
+                    prng = rng.state; rng = rng.fork(2); SET_FLAG(F_FORKED, true);
                     ev = W.begin(P, rng, C, K_LOOKUP, ps, wo, itsT);
                     if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - itsT);
                 }
@@ -761,6 +766,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
         SLOT(CO_N0) = __float_as_uint(W.n0); SLOT(CO_TRSUM) = __float_as_uint(W.trsum);
         SLOT(CO_SDENS) = __float_as_uint(W.sdens); SLOT(CO_TMIN) = __float_as_uint(W.tmin);
         SLOT(CO_PLEN) = __float_as_uint(plen); SLOT(CO_TROPT) = __float_as_uint(trOpt); if (EXTRA) SLOT(CO_ETA) = __float_as_uint(etaPath);
+        SLOT(CO_WNEXT_LO) = (uint32_t) prng; SLOT(CO_WNEXT_HI) = (uint32_t) (prng >> 32);
         marching = !connecting;
         mq_class = march_class<CURVED, BND>(P, W);
 

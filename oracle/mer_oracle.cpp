@@ -97,6 +97,10 @@ struct Pcg32 {
         state += splitmix64(seedv);
         next();
     }
+    /* The stream of a SIDE WALK (the transmittance walk of a luminaire sample, kind 1, or of an emitter look-up, kind 2): a child of the path's
+       stream at the point where the walk starts.  The path's own stream does not advance while the walk runs, so the walk is an independent piece of
+       work -- the HIP path runs it in a lane of its own while the path goes on (csrc/mer_wavefront.hpp: spawned walks). */
+    Pcg32 fork(uint64_t kind) const { Pcg32 c; c.state = splitmix64(state ^ (kind * 0xD1B54A32D192ED03ULL)); c.inc = inc; return c; }
     uint32_t next() {
         uint64_t old = state;
         state = old * 6364136223846793005ULL + inc;
@@ -1817,6 +1821,14 @@ struct Walker {
         return S.s.rif_double ? evalTransmittanceCurved<double>(o, d) : evalTransmittanceCurved<float>(o, d);
     }
 
+    /* evalTransmittance on the forked stream of a side walk (Pcg32::fork) */
+    Spec sideTransmittance(uint64_t kind, const Vec &o, const Vec &d, Float maxt) {
+        const Pcg32 saved = rng;
+        rng = saved.fork(kind);
+        const Spec tr = evalTransmittance(o, d, maxt);
+        rng = saved;
+        return tr;
+    }
     static inline Float miWeight(Float pdfA, Float pdfB) { pdfA *= pdfA; pdfB *= pdfB; return pdfA / (pdfA + pdfB); } /* volpath.cpp:430-433 */
 
     /* A10: VolumetricPathTracer::Li (src/integrators/path/volpath.cpp:84-343) restricted to the scene
@@ -1891,8 +1903,8 @@ struct Walker {
                         Float tExit = 0;
                         if (!S.curved) {
                             tExit = S.intersectShape(mRec.p, dd, 0.0f, std::numeric_limits<Float>::infinity());
-                            tr = tExit >= 0 ? evalTransmittance(mRec.p, dd, tExit) : Spec(1.0f);
-                        } else tr = evalTransmittance(mRec.p, dd, 0);
+                            tr = tExit >= 0 ? sideTransmittance(1, mRec.p, dd, tExit) : Spec(1.0f);
+                        } else tr = sideTransmittance(1, mRec.p, dd, 0);
                     }
                     if (hasArea && S.rectIntersect(mRec.p, dd, 0.0f, INF) >= 0) tr = Spec(0.0f);     /* the rectangle shadows the environment (Scene::evalTransmittance stops at a non-null surface) */
                     value *= tr;
@@ -1992,9 +2004,9 @@ struct Walker {
                     int maxInteractions = maxDepth - depth - 1;
                     bool blocked = false;
                     if (!S.curved) {
-                        if (itsValid) { tr = evalTransmittance(ro, rd, itsT); if (maxInteractions == 0) blocked = true; }
+                        if (itsValid) { tr = sideTransmittance(2, ro, rd, itsT); if (maxInteractions == 0) blocked = true; }
                     } else {
-                        tr = evalTransmittance(ro, rd, 0);
+                        tr = sideTransmittance(2, ro, rd, 0);
                         if (maxInteractions == 0) blocked = true;
                     }
                     if (dbg) printf("orc LOOKUP depth=%d T=%g L=%g tr=%g rng=%llu\n", depth, throughput[0], Li[0], tr[0], (unsigned long long) rng.state);
