@@ -180,6 +180,8 @@ int  mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu
      connect_launches  K_connect launches per pass: each runs one solver unit (one traced ray) per pending curved-ray connection (default 2)
      adaptive_k     pass length in the tail of a render: 0 fixed (default), 1 longer, 2 shorter
      inline_walks   1 = straight rays in a gridded sigma_t: K_event runs the walks itself instead of handing them to K_march (default), 0 = two kernels
+     spawn_walks    1 = curved rays, steady-state film: the transmittance walks of luminaire samples and emitter look-ups run in side-walk slots while
+                    the path goes on to its next scattering event (default); 0 = every walk in the path's own lane
      tile_deal      1 = image-tile shards dealt on diagonals of the tile grid (default), 0 = plain row-major round robin (whole tile columns)
      small_render_slots  1 = a render with fewer than ~8 paths per slot runs on a quarter of the slots (default)
      pass_events    per-pass HIP events feeding mer_last_render_stats (default 1)

@@ -432,7 +432,7 @@ static int64_t *option_slot(mer_context *ctx, const char *name) {
         {"pipes", &o.pipes}, {"nslots", &o.nslots}, {"ksteps", &o.ksteps}, {"mq_sort", &o.mq_sort}, {"connect_launches", &o.connect_launches},
         {"adaptive_k", &o.adaptive_k}, {"pass_events", &o.pass_events}, {"buffer_loads", &o.buffer_loads}, {"gen_all", &o.gen_all},
         {"prefilter", &o.prefilter}, {"verbose", &o.verbose}, {"debug_pixel", &o.debug_pixel}, {"lds_bricks", &o.lds_bricks}, {"march_lds_kb", &o.march_lds_kb},
-        {"tile_deal", &o.tile_deal}, {"small_render_slots", &o.small_render_slots}, {"inline_walks", &o.inline_walks}};
+        {"tile_deal", &o.tile_deal}, {"small_render_slots", &o.small_render_slots}, {"inline_walks", &o.inline_walks}, {"spawn_walks", &o.spawn_walks}};
     for (const auto &t : table) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -449,7 +449,7 @@ int mer_context_set_option(mer_context *ctx, const char *name, int64_t value) {
         (n == "prefilter" && (value < 0 || value > 5)) || (n == "mq_sort" && (value < -1 || value > 1)) ||
         (n == "march_lds_kb" && (value < 0 || value > 64)) ||          // dynamic LDS above 64 KiB would need hipFuncSetAttribute
         (n == "debug_pixel" && (value < -1 || value > ((int64_t) 1 << 31) - 1)) || (n == "tile_deal" && (value < 0 || value > 1)) ||
-        (n == "small_render_slots" && (value < 0 || value > 1)) || (n == "inline_walks" && (value < 0 || value > 1)) || (n == "adaptive_k" && (value < 0 || value > 2)))
+        (n == "small_render_slots" && (value < 0 || value > 1)) || (n == "inline_walks" && (value < 0 || value > 1)) || (n == "spawn_walks" && (value < 0 || value > 1)) || (n == "adaptive_k" && (value < 0 || value > 2)))
         return fail(ctx, std::string("option '") + name + "': value out of range");
     *p = value;
     return 0;

@@ -626,6 +626,8 @@ struct Params {
     int32_t dbg_pixel;
     // wavefront path-state slots (struct of arrays, word k of slot i at slots[k*nslots + i])
     uint32_t *slots; uint32_t nslots; int32_t ksteps;
+    uint32_t nslots_all;                // nslots path slots + the side-walk slots behind them (4 per path when walks are spawned, else 0): extent of `slots` and of the work lists' item ids
+    int32_t spawn;                      // 1: K_event hands luminaire-sample / look-up transmittance walks to side-walk slots and goes on with the path (mer_wavefront.hpp)
     uint32_t *live;                     // live[0]: number of finished slots
     SegQueue eq, mq[2], sq[2];          // event queue, march lists (by pass parity), starved lists (by pass parity)
     DGrid sdf; float sdf_eps;           // boundary = MER_BOUNDARY_SDF: signed-distance grid (negative inside), 1e-4 x its diagonal

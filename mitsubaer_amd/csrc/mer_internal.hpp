@@ -52,6 +52,7 @@ struct Options {
     int64_t march_lds_kb = 0;     // KiB of (unused) dynamic LDS per K_march block: caps its occupancy (160 KiB per CU; 33 -> 4 blocks, 41 -> 3) for A/B runs
     int64_t tile_deal = 1;        // tile shards dealt on diagonals (1, default) or in plain row-major round robin (0): decode_work
     int64_t inline_walks = 1;     // straight rays in a gridded sigma_t: K_event runs the walks itself (persistent lanes) instead of handing them to K_march
+    int64_t spawn_walks = 1;      // curved rays, steady-state film: luminaire-sample / look-up walks run in side-walk slots while the path goes on (mer_wavefront.hpp)
     int64_t small_render_slots = 1;   // a render with few paths per slot uses fewer slots / pipelines, so that the wavefront stays full while it drains
     int64_t lds_bricks = 0;       // K_march keeps every lane's current BRICK27 record in LDS (BRICK27 below 4 GiB only; measured slower)
 };

@@ -88,6 +88,12 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         if (!inside) ks.connect = ks.connect_cross;
     }
 
+    // spawned side walks (mer_wavefront.hpp): the plain curved kernels hand luminaire-sample / look-up walks to side-walk slots -- four per path, behind
+    // the path slots -- when the render is a steady-state film with an environment to reach (per-path output keeps every walk in the path's own lane:
+    // one value per path, written once, bit-reproducible)
+    const bool has_env = scene->env_radiance[0] != 0 || scene->env_radiance[1] != 0 || scene->env_radiance[2] != 0;
+    const bool spawn = opt.spawn_walks && curved && !extra && has_env && !path_out_dev && scene->decomposition == MER_DECOMPOSITION_NONE;
+    const uint32_t slot_mult = spawn ? 5u : 1u;
     int npipes = (int) opt.pipes;
     if (shard->spp_count < npipes) npipes = std::max(1, shard->spp_count);
     uint32_t want = opt.nslots > 0 ? (uint32_t) opt.nslots : (uint32_t) ctx->prop.multiProcessorCount * 2048u * 4u;   // 4 x the resident lanes of the chip, over all pipelines
@@ -121,8 +127,9 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         // event-queue segments: a segment of class c receives the lanes of the waves w = s (mod segments per class) of EVERY producer launch of
         // the row -- K_march plus connect_launches K_connect launches, each of which re-packs its pending lanes into its first waves
         auto eq_segcap = [&](uint32_t cap) { return std::min<uint64_t>((uint64_t) cap, (uint64_t) ((connect_stage ? connect_launches : 0) + 2) * (cap / (MER_NSEG / MER_EV_CLASSES))) + 256u; };
-        if (pp.nslots < want || pp.hitq_cap < ring || (pp.nslots && pp.eq.segcap < eq_segcap(pp.nslots))) {                 // capacity: grows, never shrinks
-            const uint32_t cap = std::max(want, pp.nslots);
+        // pp.nslots counts RECORDS (path slots + side-walk slots); the lists hold record ids and are sized by it
+        if (pp.nslots < want * slot_mult || pp.hitq_cap < ring || (pp.nslots && pp.eq.segcap < eq_segcap(pp.nslots))) {                 // capacity: grows, never shrinks
+            const uint32_t cap = std::max(want * slot_mult, pp.nslots);
             if (pp.slots) (void) hipFree(pp.slots);
             if (pp.hitq) (void) hipFree(pp.hitq);
             pp.slots = nullptr; pp.hitq = nullptr; pp.nslots = 0;
@@ -158,9 +165,9 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         R.nslots = want;
         const uint64_t need_slots = (R.P.total_work + MER_BLOCK - 1) / MER_BLOCK * MER_BLOCK;
         if (need_slots < R.nslots) R.nslots = (uint32_t) need_slots;
-        R.P.slots = pp.slots; R.P.nslots = R.nslots; R.P.live = pp.live; R.P.eq = pp.eq; R.P.mq[0] = pp.mq[0]; R.P.mq[1] = pp.mq[1];
+        R.P.slots = pp.slots; R.P.nslots = R.nslots; R.P.nslots_all = R.nslots * slot_mult; R.P.spawn = spawn ? 1 : 0; R.P.live = pp.live; R.P.eq = pp.eq; R.P.mq[0] = pp.mq[0]; R.P.mq[1] = pp.mq[1];
         R.P.sq[0] = pp.sq[0]; R.P.sq[1] = pp.sq[1]; R.P.cq[0] = pp.cq[0]; R.P.cq[1] = pp.cq[1];
-        if (connect_stage && pp.cstate_slots < pp.nslots) {
+        if (connect_stage && pp.cstate_slots < pp.nslots) {      // (never together with spawned walks: a point emitter selects the EXTRA kernels)
             if (pp.cstate) (void) hipFree(pp.cstate);
             pp.cstate = nullptr; pp.cstate_slots = 0;
             HIP_CHECK(ctx, hipMalloc((void **) &pp.cstate, (size_t) pp.nslots * MER_CSTATE_WORDS * sizeof(uint32_t)));
@@ -171,9 +178,9 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         R.P.ksteps = ksteps0; R.P.cq_row = 0;
         R.done = R.P.total_work == 0;
         if (R.done) continue;
-        R.blocks = R.nslots / MER_BLOCK;
+        R.blocks = R.nslots * slot_mult / MER_BLOCK;                 // the lists may hold every record
         R.gen_blocks = std::max(1u, std::min(R.nslots / MER_BLOCK, gen_blocks_max));
-        HIP_CHECK(ctx, hipMemsetAsync(pp.slots, 0, (size_t) R.nslots * MER_SLOT_WORDS * sizeof(uint32_t), pp.stream));
+        HIP_CHECK(ctx, hipMemsetAsync(pp.slots, 0, (size_t) R.nslots * slot_mult * MER_SLOT_WORDS * sizeof(uint32_t), pp.stream));
         HIP_CHECK(ctx, hipMemsetAsync(pp.live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), pp.stream));
         for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq[0], &pp.cq[1]})
             HIP_CHECK(ctx, hipMemsetAsync(sq->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), pp.stream));
@@ -205,7 +212,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
             R.pass++;
         }
         HIP_CHECK(ctx, hipGetLastError());
-        HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 4 * rb, pp.live, sizeof(uint32_t), hipMemcpyDeviceToHost, pp.stream));
+        HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 4 * rb, pp.live, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, pp.stream));     // finished path slots, side walks in flight
         HIP_CHECK(ctx, hipMemcpyAsync(pp.host_live + 4 * rb + 2, R.P.work_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, pp.stream));
         HIP_CHECK(ctx, hipEventRecord(pp.readback[rb], pp.stream));
         return 0;
@@ -231,7 +238,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
             if (opt.verbose >= 2)        // drain timeline: host time, pipeline, passes issued, slots finished, work ids handed out
                 fprintf(stderr, "[mer] t=%8.3f ms pipe %d passes %u finished %u / %u work %llu / %llu K=%d\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(),
                         q, R.pass, finished_slots, R.nslots, *(unsigned long long *) (pp.host_live + 4 * rb + 2), (unsigned long long) R.P.total_work, R.P.ksteps);
-            if (finished_slots >= R.nslots) { R.done = true; continue; }
+            if (finished_slots >= R.nslots && pp.host_live[4 * rb + 1] == 0u) { R.done = true; continue; }      // every path done and no side walk in flight
             R.work_left = *(unsigned long long *) (pp.host_live + 4 * rb + 2) < R.P.total_work;
             // Pass length in the tail.  The tail of a render is the serial latency of its deepest paths, and a path advances by ONE walk (free
             // flight, NEE or look-up: ~65 steps) per pass however long the pass may be, so a pass should end when most lanes have parked.

@@ -22,7 +22,9 @@ enum { CO_PXF = H_COUNT, CO_PYF, CO_LX, CO_LY, CO_LZ, CO_TX, CO_TY, CO_TZ, CO_DE
        CO_DSX, CO_DSY, CO_DSZ, CO_DDX, CO_DDY, CO_DDZ, CO_WIX, CO_WIY, CO_WIZ, CO_PHASEPDF, CO_ITST, CO_N0, CO_TRSUM,
        CO_SDENS, CO_TMIN, CO_WNEXT_LO, CO_WNEXT_HI, CO_WLEFT, CO_PLEN, CO_TROPT, CO_ETA, SLOT_WORDS };
 
-// H_FLAGS: st[1:0] ev[5:2] kind[7:6] seg_inf[8] backstep[9] walk[11:10] agg[12]
+// H_FLAGS: st[1:0] ev[5:2] kind[7:6] seg_inf[8] backstep[9] walk[11:10] agg[12] init[13] (a spawned side walk that K_march has yet to begin)
+#define MER_FLAG_INIT (1u << 13)
+#define MER_FLAG_CHILD (1u << 14)      // the record is a spawned side walk (hot copy of CO_PFLAGS' F_CHILD: K_march reads hot words only)
 __device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg_inf, int backstep, int walk, int agg) {
     return (uint32_t) st | ((uint32_t) ev << 2) | ((uint32_t) kind << 6) | ((uint32_t) seg_inf << 8) | ((uint32_t) backstep << 9) |
            ((uint32_t) walk << 10) | ((uint32_t) agg << 12);
@@ -36,12 +38,12 @@ __device__ __forceinline__ uint32_t pack_flags(int st, int ev, int kind, int seg
 #ifndef MER_WORK_BATCH
 #define MER_WORK_BATCH 8
 #endif
-#define SLOT(k) P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots) * MER_SLOT_WORDS + (k)]
+#define SLOT(k) P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots_all) * MER_SLOT_WORDS + (k)]
 #define SLOTF(k) __uint_as_float(SLOT(k))
 
 template <class WalkT>
 __device__ __forceinline__ void load_hot(const Params &P, uint32_t i, uint32_t &fl, WalkT &W, Rng &rng, uint32_t &pixel, uint32_t &sample, float &sigma) {
-    const uint4 *r = (const uint4 *) (P.slots + (size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots) * MER_SLOT_WORDS);
+    const uint4 *r = (const uint4 *) (P.slots + (size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots_all) * MER_SLOT_WORDS);
     const uint4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4];
     W.p = f3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
     W.v = f3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
@@ -56,16 +58,50 @@ __device__ __forceinline__ void load_hot(const Params &P, uint32_t i, uint32_t &
 }
 template <class WalkT>
 __device__ __forceinline__ void store_hot(const Params &P, uint32_t i, int st, int ev, const WalkT &W, const Rng &rng,
-                                          uint32_t pixel, uint32_t sample, float sigma) {
-    uint4 *r = (uint4 *) (P.slots + (size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots) * MER_SLOT_WORDS);
+                                          uint32_t pixel, uint32_t sample, float sigma, uint32_t keep_bits = 0u) {
+    uint4 *r = (uint4 *) (P.slots + (size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots_all) * MER_SLOT_WORDS);
     r[0] = make_uint4(__float_as_uint(W.p.x), __float_as_uint(W.p.y), __float_as_uint(W.p.z), __float_as_uint(W.v.x));
     r[1] = make_uint4(__float_as_uint(W.v.y), __float_as_uint(W.v.z), __float_as_uint(W.opt), __float_as_uint(W.dist));
     r[2] = make_uint4(__float_as_uint(W.rem), __float_as_uint(W.hprev), __float_as_uint(W.Tr), __float_as_uint(W.t));
     const bool agg = WalkT::kBND == 1 && W.agg != 0;
-    r[3] = make_uint4(__float_as_uint(W.tmax), (uint32_t) W.steps_left, pack_flags(st, ev, W.kind, W.seg_inf, W.backstep, W.walk, agg ? 1 : 0),
+    r[3] = make_uint4(__float_as_uint(W.tmax), (uint32_t) W.steps_left, pack_flags(st, ev, W.kind, W.seg_inf, W.backstep, W.walk, agg ? 1 : 0) | keep_bits,
                       (uint32_t) rng.state);
     r[4] = make_uint4((uint32_t) (rng.state >> 32), pixel, sample, __float_as_uint((WalkT::kBND == 1 && ev == EV_NONE) ? W.dleft : sigma));
 }
+
+// ---- spawned side walks ---------------------------------------------------------------------------------------------------------
+// The transmittance walk of a luminaire sample and the walk of an emitter look-up run to the BOUNDARY of the medium (hundreds of steps: 2 - 7
+// passes each), and the path has to wait for neither: their result only scales a contribution that is already fully known when the walk starts
+// (throughput x emitter x phase function x MIS weight), and since round 3 they draw from a forked sampler stream (Rng::fork), so the path's own
+// draws do not depend on them.  K_event therefore hands such a walk to a SIDE-WALK SLOT -- a record of the same layout behind the path slots, four
+// per path (luminaire / look-up x two in alternation) -- puts it on the march list and goes straight on with the path (phase sample, Russian
+// roulette, next free flight) in the same visit.  The side walk's lane marches in K_march like any other, and at the end of the walk K_event
+// splats prefactor x transmittance into the film (RGB only; alpha and weight arrive once, with the path) and frees the slot.  A path thus
+// advances one SCATTERING EVENT per pass instead of one walk per pass: the critical path of a render -- what its drain at the end, and a
+// small render as a whole, wait for -- is ~6 x shorter.  If the side-walk slot is still busy the walk runs in the path's own lane as before:
+// same streams, same contribution, so the film does not depend on which way a walk went (up to float summation order).  live[1] counts the
+// side walks in flight: a render is over when every path slot is done AND that count is zero.
+// writes the record of a side walk: hot words = (origin, direction, kind, forked sampler state) with the INIT flag -- K_march sets up its first
+// segment (Walk::begin) --, cold words = what K_event needs when the walk has ended (film position, prefactor, the ray for a second Woodcock walk)
+__device__ __forceinline__ void spawn_side_walk(const Params &P, uint32_t c, int kind, f3 o, f3 d, float rayT, f3 pref, float px, float py, uint64_t rng_state,
+                                                uint32_t pixel, uint32_t sample) {
+    uint32_t *rec = P.slots + (size_t) MER_CHK(P.chk, CHK_SLOT, c, P.nslots_all) * MER_SLOT_WORDS;
+    uint4 *r = (uint4 *) rec;
+    r[0] = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(d.x));
+    r[1] = make_uint4(__float_as_uint(d.y), __float_as_uint(d.z), 0u, 0u);
+    r[2] = make_uint4(0u, 0u, __float_as_uint(1.0f), __float_as_uint(rayT));
+    r[3] = make_uint4(0u, 0u, pack_flags(ST_MARCH, EV_NONE, kind, 0, 0, 0, 0) | MER_FLAG_INIT | MER_FLAG_CHILD, (uint32_t) rng_state);
+    r[4] = make_uint4((uint32_t) (rng_state >> 32), pixel, sample, 0u);
+    rec[CO_PXF] = __float_as_uint(px); rec[CO_PYF] = __float_as_uint(py);
+    rec[CO_LX] = __float_as_uint(pref.x); rec[CO_LY] = __float_as_uint(pref.y); rec[CO_LZ] = __float_as_uint(pref.z);
+    rec[CO_PFLAGS] = 64u /* F_CHILD */; rec[CO_DEPTH] = 0u;
+    rec[CO_PSX] = __float_as_uint(o.x); rec[CO_PSY] = __float_as_uint(o.y); rec[CO_PSZ] = __float_as_uint(o.z);
+    rec[CO_DSX] = __float_as_uint(d.x); rec[CO_DSY] = __float_as_uint(d.y); rec[CO_DSZ] = __float_as_uint(d.z);
+    rec[CO_DDX] = __float_as_uint(d.x); rec[CO_DDY] = __float_as_uint(d.y); rec[CO_DDZ] = __float_as_uint(d.z);
+    rec[CO_ITST] = __float_as_uint(rayT); rec[CO_N0] = __float_as_uint(1.0f); rec[CO_TRSUM] = 0u; rec[CO_SDENS] = 0u; rec[CO_TMIN] = 0u;
+}
+#define CSLOT(c, k) P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, c, P.nslots_all) * MER_SLOT_WORDS + (k)]
+enum { F_NEE_PAR = 16, F_LK_PAR = 32, F_CHILD = 64 };      // path flags (CO_PFLAGS) beside K_event's own: alternation bits of the two side-walk kinds; the record is a side walk
 
 // Counter flush: one set of atomics per wave, spread over MER_COUNTER_REPLICAS copies (summed on the host) so that a
 // pass of thousands of waves does not serialise on nine addresses (one word sustains ~88 atomics/us).  No barrier:
@@ -298,7 +334,7 @@ __device__ __forceinline__ void queue_clear_row(const SegQueue &q, uint32_t row,
 template <bool CURVED, int RIF, int STEPPER, int SIGMA, int BND = 0>
 __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const Params P, uint32_t pass) {
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
-    if (j >= P.nslots) return;
+    if (j >= P.nslots_all) return;
     // K_event pops the hit ring with a bare atomicAdd and overshoots its tail when it starves; nothing touches the ring
     // while K_march runs, so this is the race-free place to clamp the head before K_gen produces again
     if (j == 0) { const unsigned long long t = P.hitq_ctr[0], h = P.hitq_ctr[MER_HITQ_HEAD]; if (h > t) P.hitq_ctr[MER_HITQ_HEAD] = t; }
@@ -306,7 +342,7 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
     const uint32_t count = queue_total(P.mq[pass & 1u], pass);
     LaneCounters C; C.clear();
     uint32_t iters = 0, i = 0;
-    bool has_event = false, still_marching = false; int ev_class = 0, mq_class = 0;
+    bool has_event = false, still_marching = false, child_ended = false; int ev_class = 0, mq_class = 0;
     if (j < count) {
         i = queue_item(P.mq[pass & 1u], pass, j);
         uint32_t fl;
@@ -315,7 +351,9 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
         load_hot(P, i, fl, W, rng, pixel, sample, sigma);
         W.cc.reset(); W.n0 = 1.0f; W.tmin = 0.0f; W.trsum = 0.0f; W.sdens = 0.0f;
         int ev = EV_NONE; sigma = 0.0f;
-        const int K = P.ksteps;
+        // a side walk spawned by K_event arrives as (origin, direction, kind, forked sampler): its first segment is set up here, in the lean kernel
+        if (CURVED && (fl & MER_FLAG_INIT)) ev = W.begin(P, rng, C, W.kind, W.p, W.v, W.t);
+        const int K = ev == EV_NONE ? P.ksteps : 0;          // (a side walk whose start failed -- outside the spline's limits -- goes straight to K_event)
         if (CURVED) {
             // A lane reaches a tentative collision about once in 65 steps, so at nearly every trip ONE lane of the wave would drag all
             // 64 through the collision code (sigma_t fetch, ratio / Woodcock test, next exponential segment: ~125 VALU against ~320 for
@@ -339,15 +377,30 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
             iters++;
             if (ev != EV_NONE) break;
         }
-        store_hot(P, i, ST_MARCH, ev, W, rng, pixel, sample, sigma);
+        // A spawned side walk that has reached its end is finished HERE when one walk is the whole estimate (ratio tracking; homogeneous sigma_t):
+        // contribution = prefactor x transmittance into the film, and the slot is idle again -- no trip through the event queue and K_event.
+        const bool child = CURVED && BND == 0 && (fl & MER_FLAG_CHILD) != 0u;
+        if (child && ev != EV_NONE && !(SIGMA == MER_SIGMA_GRID && P.sc.tr_estimator == MER_TR_WOODCOCK2)) {
+            f3 tr = SIGMA == MER_SIGMA_GRID ? f3(W.Tr, W.Tr, W.Tr) : homogeneous_transmittance(P, -W.dist);
+            if (ev == EV_GATE_FAIL) tr = f3(0, 0, 0);
+            const f3 c = f3(SLOTF(CO_LX), SLOTF(CO_LY), SLOTF(CO_LZ)) * tr;
+            if (!is_zero(c)) film_splat(P, SLOTF(CO_PXF), SLOTF(CO_PYF), c, 0.0f, 0, 1);
+            SLOT(H_FLAGS) = 0u;
+            child_ended = true; ev = EV_NONE;
+        } else
+        store_hot(P, i, ST_MARCH, ev, W, rng, pixel, sample, sigma, fl & MER_FLAG_CHILD);
         has_event = ev != EV_NONE;
         ev_class = ev == EV_REAL ? 0 : (W.kind == K_NEE ? 1 : (W.kind == K_LOOKUP ? 2 : 3));
         mq_class = march_class<CURVED, BND>(P, W);
-        still_marching = !has_event;
+        still_marching = !has_event && !child_ended;
     }
     // compaction: lanes parked on an event go to K_event's queue (by class), the others straight to the next march list
     queue_push_class<MER_EV_CLASSES>(P.eq, pass + 1, has_event, i, ev_class);
     queue_push_class<MER_MQ_CLASSES>(P.mq[(pass + 1) & 1u], pass + 1, still_marching, i, mq_class);
+    if (CURVED && BND == 0) {                    // side walks finished in this launch leave the in-flight count (one atomic per wave)
+        const int ended = __popcll(__ballot(child_ended));
+        if ((threadIdx.x & 63) == 0 && ended) atomicAdd(P.live + 1, (uint32_t) (-ended));
+    }
     // lane-slot accounting: every lane of the wave is held for as many trips as its slowest lane
     uint32_t wave_iters = iters;
 #pragma unroll
@@ -376,10 +429,10 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
 #define MER_INLINE_EVENT_WAVES 1
 #endif
 template <bool CURVED, int RIF, int STEPPER, int SIGMA, bool EXTRA, int BND = 0, bool INLINE = false>
-__global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1) event_kernel(const Params P, uint32_t pass) {
+__global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2) event_kernel(const Params P, uint32_t pass) {
     typedef Walk<CURVED, RIF, STEPPER, SIGMA, BND> WalkT;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
-    if (j >= P.nslots) return;
+    if (j >= P.nslots_all) return;
     // pass 0: every slot is new; later passes: the compacted list of slots K_march parked on an event
     const uint32_t nq = pass == 0 ? P.nslots : queue_total(P.eq, pass);
     const uint32_t ns = pass == 0 ? 0u : queue_total(P.sq[pass & 1u], pass);      // slots left without work last pass
@@ -388,6 +441,9 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
     queue_clear_row(P.eq, pass + 2, j); queue_clear_row(P.mq[pass & 1u], pass + 2, j); queue_clear_row(P.sq[pass & 1u], pass + 2, j);
     LaneCounters C; C.clear();
     bool marching = false, starved_out = false, connecting = false; uint32_t i = 0; int mq_class = 0, cq_class = 0;
+    bool child_done = false;
+    uint32_t child0 = 0, child1 = 0; int c0class = 0, c1class = 0;           // side walks this lane has just spawned (0 = none): they join the march list below
+    constexpr bool SPAWNABLE = CURVED && !EXTRA;                             // the plain curved kernels (the bench kernels) spawn side walks when P.spawn says so
     if (j < count) {
     i = pass == 0 ? j : (j < nq ? queue_item(P.eq, pass, j) : queue_item(P.sq[pass & 1u], pass, j - nq));
     const uint32_t fl = SLOT(H_FLAGS);
@@ -572,13 +628,36 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
                     if (tExit >= 0) {
                         itsT = tExit;
                         if (!CURVED) trOpt = tExit * S.rif_const;
+                        bool spawned = false;
+                        if (SPAWNABLE && P.spawn) {
+                            const uint32_t c = P.nslots + ((i * 2u + 0u) * 2u + (((uint32_t) flags >> 4) & 1u));
+                            if ((CSLOT(c, H_FLAGS) & 3u) == 0u) {                     // the side-walk slot is free: the walk goes there, the path goes on
+                                const float phaseVal = phase_eval(S.phase, S.g, wi, dd);
+                                const f3 pref = T * (env / MER_INV_FOURPI) * phaseVal * mi_weight(MER_INV_FOURPI, phaseVal);
+                                if (!is_zero(pref)) {
+                                    spawn_side_walk(P, c, K_NEE, ps, dd, tExit, pref, px, py, rng.fork(1).state, pixel, sample);
+                                    W.p = ps; W.v = dd;                                // (W is idle between the collision and the next free flight: borrowed for the class estimate)
+                                    child0 = c; c0class = march_class<CURVED, BND>(P, W);
+                                    flags ^= F_NEE_PAR;
+                                }
+                                spawned = true; ev = EV_PHASE;
+                            }
+                        }
+                        if (!spawned) {
                         prng = rng.state; rng = rng.fork(1); SET_FLAG(F_FORKED, true);       // the walk runs on a child stream (the oracle's sideTransmittance)
                         ev = W.begin(P, rng, C, K_NEE, ps, dd, tExit);
                         if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - tExit);
+                        }
                     } else { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
                 } else { trv = f3(0, 0, 0); ev = EV_TR_DONE; }
             } else ev = EV_PHASE;
         } else if (ev == EV_TR_DONE) {
+            if (SPAWNABLE && (flags & F_CHILD)) {                                            // a spawned side walk has ended: its contribution, and the slot is free again
+                const f3 c = L * trv;                                                        // L holds the prefactor (throughput x emitter x phase x MIS weight)
+                if (!is_zero(c)) film_splat(P, px, py, c, 0.0f, 0, 1);
+                child_done = true;
+                break;
+            }
             if (flags & F_FORKED) { rng.state = prng; SET_FLAG(F_FORKED, false); }           // the side walk is over: back on the path's own stream
             f3 tr = trv;
             if (W.kind == K_NEE) {
@@ -674,9 +753,26 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
                 trOpt = (!CURVED && itsValid) ? itsT * S.rif_const : 0.0f;
                 if (!CURVED && !itsValid) { trv = f3(1, 1, 1); ev = EV_TR_DONE; }
                 else {
+                    bool spawned = false;
+                    if (SPAWNABLE && P.spawn) {
+                        const uint32_t c = P.nslots + ((i * 2u + 1u) * 2u + (((uint32_t) flags >> 5) & 1u));
+                        if ((CSLOT(c, H_FLAGS) & 3u) == 0u) {
+                            const bool blocked = (maxDepth - depth - 1 == 0);                    // curved rays: the look-up always crosses the boundary once
+                            const f3 pref = blocked ? f3(0, 0, 0) : T * env * mi_weight(phasePdf, MER_INV_FOURPI);
+                            if (!is_zero(pref)) {
+                                spawn_side_walk(P, c, K_LOOKUP, ps, wo, itsT, pref, px, py, rng.fork(2).state, pixel, sample);
+                                W.p = ps; W.v = wo;
+                                child1 = c; c1class = march_class<CURVED, BND>(P, W);
+                                flags ^= F_LK_PAR;
+                            }
+                            spawned = true; ev = EV_AFTER_LOOKUP;
+                        }
+                    }
+                    if (!spawned) {
                     prng = rng.state; rng = rng.fork(2); SET_FLAG(F_FORKED, true);
                     ev = W.begin(P, rng, C, K_LOOKUP, ps, wo, itsT);
                     if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - itsT);
+                    }
                 }
             } else ev = EV_AFTER_LOOKUP;
         } else if (ev == EV_AFTER_LOOKUP) {
@@ -750,10 +846,11 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
 #undef SET_FLAG
 
     // ---- park the lane
-    if (st == ST_DONE) { SLOT(H_FLAGS) = ST_DONE; atomicAdd(P.live, 1u); }      // live[0] counts finished slots
+    if (child_done) SLOT(H_FLAGS) = 0u;                                           // side-walk slot idle again
+    else if (st == ST_DONE) { SLOT(H_FLAGS) = ST_DONE; atomicAdd(P.live, 1u); }      // live[0] counts finished slots
     else if (starved) { SLOT(H_FLAGS) = ST_NEW; starved_out = true; }
     else {
-        store_hot(P, i, ST_MARCH, connecting ? EV_PHASE2 : EV_NONE, W, rng, pixel, sample, 0.0f);
+        store_hot(P, i, ST_MARCH, connecting ? EV_PHASE2 : EV_NONE, W, rng, pixel, sample, 0.0f, (SPAWNABLE && (flags & F_CHILD)) ? MER_FLAG_CHILD : 0u);
         SLOT(CO_PXF) = __float_as_uint(px); SLOT(CO_PYF) = __float_as_uint(py);
         SLOT(CO_LX) = __float_as_uint(L.x); SLOT(CO_LY) = __float_as_uint(L.y); SLOT(CO_LZ) = __float_as_uint(L.z);
         SLOT(CO_TX) = __float_as_uint(T.x); SLOT(CO_TY) = __float_as_uint(T.y); SLOT(CO_TZ) = __float_as_uint(T.z);
@@ -775,6 +872,13 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 1
     // a new connection joins the pending ones of the next K_connect launch, grouped by the length of the rays its solver will trace
     if (EXTRA && CURVED) queue_push_class<MER_CQ_CLASSES>(pick_queue(P.cq, P.cq_row), P.cq_row, connecting, i, cq_class);
     queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class);
+    if (SPAWNABLE) {                                                           // the side walks spawned in this visit march with everybody else
+        queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, child0 != 0u, child0, c0class);
+        queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, child1 != 0u, child1, c1class);
+        // live[1] = side walks in flight: one atomic per wave (spawned minus ended), not one per walk -- a single word sustains ~90 atomics per microsecond
+        const int delta = __popcll(__ballot(child0 != 0u)) + __popcll(__ballot(child1 != 0u)) - __popcll(__ballot(child_done));
+        if ((threadIdx.x & 63) == 0 && delta != 0) atomicAdd(P.live + 1, (uint32_t) delta);
+    }
     queue_push(P.sq[(pass + 1) & 1u], pass + 1, starved_out, i);
     flush_counters(P, C, 0);
 }
