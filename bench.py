@@ -468,7 +468,8 @@ def main():
                                   "lane_slots": counters[capi.C_LOOP_ITERS] / max(args.steps, 1), "active_lane_steps": counters[capi.C_ACTIVE_LANES] / max(args.steps, 1),
                                   "connections": counters[capi.C_NEE] / max(args.steps, 1) if any(p.point_intensity) else 0.0,
                                   "connect_units": counters[capi.C_CONNECT_UNITS] / max(args.steps, 1), "connect_steps": counters[capi.C_CONNECT_STEPS] / max(args.steps, 1),
-                                  "connect_lane_slots": counters[capi.C_CONNECT_LANE_SLOTS] / max(args.steps, 1)},
+                                  "connect_lane_slots": counters[capi.C_CONNECT_LANE_SLOTS] / max(args.steps, 1),
+                                  "side_walks_spawned": counters[capi.C_SIDE_SPAWNED] / max(args.steps, 1), "side_walks_in_the_paths_lane": counters[capi.C_SIDE_INLINE] / max(args.steps, 1)},
         }
         if solo is not None:
             timed = (float(np.mean(kernel_ms)), float(np.mean(march_ms)), float(np.mean(event_ms)), float(np.mean(passes)),

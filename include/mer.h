@@ -154,6 +154,8 @@ enum {
     MER_C_CONNECT_UNITS,        /* solver units (traced rays) K_connect ran: a connection costs 3 ... 100+ */
     MER_C_CONNECT_STEPS,        /* sensitivity / Verlet steps inside them */
     MER_C_CONNECT_LANE_SLOTS,   /* 64 x the steps of the longest unit of every K_connect wave: CONNECT_STEPS / this = its active-lane fraction */
+    MER_C_SIDE_SPAWNED,         /* luminaire-sample / look-up walks handed to a side-walk slot (option spawn_walks) */
+    MER_C_SIDE_INLINE,          /* ... and those that ran in the path's own lane because the side-walk slot was still busy */
     MER_C_COUNT = 16
 };
 

@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("MER_LIB", os.path.join(_HERE, "libmer.so"))
 CHECK_LIB_PATH = os.path.join(_HERE, "libmer_check.so")     # same sources, -DMER_BOUNDS_CHECK (Context(check=True))
 _LIBS = {}
 
-C_PATHS, C_STEPS, C_RIF_EVALS, C_TENTATIVE, C_REAL, C_SEGMENTS, C_NEE, C_LOOP_ITERS, C_ACTIVE_LANES, C_CONNECT_UNITS, C_CONNECT_STEPS, C_CONNECT_LANE_SLOTS = range(12)
+C_PATHS, C_STEPS, C_RIF_EVALS, C_TENTATIVE, C_REAL, C_SEGMENTS, C_NEE, C_LOOP_ITERS, C_ACTIVE_LANES, C_CONNECT_UNITS, C_CONNECT_STEPS, C_CONNECT_LANE_SLOTS, C_SIDE_SPAWNED, C_SIDE_INLINE = range(14)
 C_COUNT = 16
 LAYOUT_DENSE, LAYOUT_CELL8, LAYOUT_BRICK27, LAYOUT_BRICK125, LAYOUT_AUTO = 0, 1, 2, 3, 4
 

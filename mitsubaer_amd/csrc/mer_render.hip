@@ -42,6 +42,11 @@ int tile_skew_for(int tiles_x, int tile_count, int tile_deal) {
     return 1 % tiles_x;
 }
 
+__global__ void clear_side_flags_kernel(uint32_t *slots, uint32_t first, uint32_t end) {
+    const uint32_t c = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < end) slots[(size_t) c * MER_SLOT_WORDS + H_FLAGS] = 0u;
+}
+
 int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed, float *film_dev, float *path_out_dev,
                   uint64_t n_film, uint64_t n_path_out) {
     Params P;
@@ -93,7 +98,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
     // one value per path, written once, bit-reproducible)
     const bool has_env = scene->env_radiance[0] != 0 || scene->env_radiance[1] != 0 || scene->env_radiance[2] != 0;
     const bool spawn = opt.spawn_walks && curved && !extra && has_env && !path_out_dev && scene->decomposition == MER_DECOMPOSITION_NONE;
-    const uint32_t slot_mult = spawn ? 5u : 1u;
+    const uint32_t slot_mult = spawn ? 1u + 2u * MER_SIDE_PER_KIND : 1u;
     int npipes = (int) opt.pipes;
     if (shard->spp_count < npipes) npipes = std::max(1, shard->spp_count);
     uint32_t want = opt.nslots > 0 ? (uint32_t) opt.nslots : (uint32_t) ctx->prop.multiProcessorCount * 2048u * 4u;   // 4 x the resident lanes of the chip, over all pipelines
@@ -180,7 +185,9 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         if (R.done) continue;
         R.blocks = R.nslots * slot_mult / MER_BLOCK;                 // the lists may hold every record
         R.gen_blocks = std::max(1u, std::min(R.nslots / MER_BLOCK, gen_blocks_max));
-        HIP_CHECK(ctx, hipMemsetAsync(pp.slots, 0, (size_t) R.nslots * slot_mult * MER_SLOT_WORDS * sizeof(uint32_t), pp.stream));
+        HIP_CHECK(ctx, hipMemsetAsync(pp.slots, 0, (size_t) R.nslots * MER_SLOT_WORDS * sizeof(uint32_t), pp.stream));
+        // side-walk records: only their state word must read "idle" (the region may hold stale records of a render with another slot count)
+        if (spawn) hipLaunchKernelGGL(clear_side_flags_kernel, dim3(nblocks((int64_t) R.nslots * (slot_mult - 1u))), dim3(256), 0, pp.stream, pp.slots, R.nslots, R.nslots * slot_mult);
         HIP_CHECK(ctx, hipMemsetAsync(pp.live, 0, MER_LIVE_SLOTS * sizeof(uint32_t), pp.stream));
         for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq[0], &pp.cq[1]})
             HIP_CHECK(ctx, hipMemsetAsync(sq->counts, 0, (size_t) MER_LIVE_SLOTS * MER_NSEG * sizeof(uint32_t), pp.stream));

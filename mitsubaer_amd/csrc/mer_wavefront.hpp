@@ -73,8 +73,8 @@ __device__ __forceinline__ void store_hot(const Params &P, uint32_t i, int st, i
 // The transmittance walk of a luminaire sample and the walk of an emitter look-up run to the BOUNDARY of the medium (hundreds of steps: 2 - 7
 // passes each), and the path has to wait for neither: their result only scales a contribution that is already fully known when the walk starts
 // (throughput x emitter x phase function x MIS weight), and since round 3 they draw from a forked sampler stream (Rng::fork), so the path's own
-// draws do not depend on them.  K_event therefore hands such a walk to a SIDE-WALK SLOT -- a record of the same layout behind the path slots, four
-// per path (luminaire / look-up x two in alternation) -- puts it on the march list and goes straight on with the path (phase sample, Russian
+// draws do not depend on them.  K_event therefore hands such a walk to a SIDE-WALK SLOT -- a record of the same layout behind the path slots, 2 x MER_SIDE_PER_KIND
+// per path (luminaire / look-up x three searched in rotation) -- puts it on the march list and goes straight on with the path (phase sample, Russian
 // roulette, next free flight) in the same visit.  The side walk's lane marches in K_march like any other, and at the end of the walk K_event
 // splats prefactor x transmittance into the film (RGB only; alpha and weight arrive once, with the path) and frees the slot.  A path thus
 // advances one SCATTERING EVENT per pass instead of one walk per pass: the critical path of a render -- what its drain at the end, and a
@@ -101,7 +101,19 @@ __device__ __forceinline__ void spawn_side_walk(const Params &P, uint32_t c, int
     rec[CO_ITST] = __float_as_uint(rayT); rec[CO_N0] = __float_as_uint(1.0f); rec[CO_TRSUM] = 0u; rec[CO_SDENS] = 0u; rec[CO_TMIN] = 0u;
 }
 #define CSLOT(c, k) P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, c, P.nslots_all) * MER_SLOT_WORDS + (k)]
-enum { F_NEE_PAR = 16, F_LK_PAR = 32, F_CHILD = 64 };      // path flags (CO_PFLAGS) beside K_event's own: alternation bits of the two side-walk kinds; the record is a side walk
+#define MER_SIDE_PER_KIND 3                                   // side-walk slots per path and kind (luminaire sample / look-up): 2 left 11 - 15 % of the walks in the path's lane, 3 leave ~2 %
+enum { F_NEE_ROT = 16 /* bits 4-5 */, F_CHILD = 64, F_LK_ROT = 128 /* bits 7-8 */ };      // path flags (CO_PFLAGS) beside K_event's own: where the search for a free side-walk slot of each kind starts; the record is a side walk
+// first free side-walk slot of (path i, kind k), searched from rotation r: its record id, or 0
+__device__ __forceinline__ uint32_t free_side_slot(const Params &P, uint32_t i, uint32_t k, uint32_t r, uint32_t &r_next) {
+    const uint32_t base = P.nslots + (i * 2u + k) * MER_SIDE_PER_KIND;
+#pragma unroll
+    for (uint32_t t = 0; t < MER_SIDE_PER_KIND; t++) {
+        const uint32_t q = (r + t) % MER_SIDE_PER_KIND, c = base + q;
+        if ((P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, c, P.nslots_all) * MER_SLOT_WORDS + H_FLAGS] & 3u) == 0u) { r_next = (q + 1u) % MER_SIDE_PER_KIND; return c; }
+    }
+    r_next = r;
+    return 0u;
+}
 
 // Counter flush: one set of atomics per wave, spread over MER_COUNTER_REPLICAS copies (summed on the host) so that a
 // pass of thousands of waves does not serialise on nine addresses (one word sustains ~88 atomics/us).  No barrier:
@@ -441,7 +453,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2
     queue_clear_row(P.eq, pass + 2, j); queue_clear_row(P.mq[pass & 1u], pass + 2, j); queue_clear_row(P.sq[pass & 1u], pass + 2, j);
     LaneCounters C; C.clear();
     bool marching = false, starved_out = false, connecting = false; uint32_t i = 0; int mq_class = 0, cq_class = 0;
-    bool child_done = false;
+    bool child_done = false; uint32_t side_inline = 0;
     uint32_t child0 = 0, child1 = 0; int c0class = 0, c1class = 0;           // side walks this lane has just spawned (0 = none): they join the march list below
     constexpr bool SPAWNABLE = CURVED && !EXTRA;                             // the plain curved kernels (the bench kernels) spawn side walks when P.spawn says so
     if (j < count) {
@@ -630,20 +642,21 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2
                         if (!CURVED) trOpt = tExit * S.rif_const;
                         bool spawned = false;
                         if (SPAWNABLE && P.spawn) {
-                            const uint32_t c = P.nslots + ((i * 2u + 0u) * 2u + (((uint32_t) flags >> 4) & 1u));
-                            if ((CSLOT(c, H_FLAGS) & 3u) == 0u) {                     // the side-walk slot is free: the walk goes there, the path goes on
+                            uint32_t rn; const uint32_t c = free_side_slot(P, i, 0u, ((uint32_t) flags >> 4) & 3u, rn);
+                            if (c != 0u) {                                            // a side-walk slot is free: the walk goes there, the path goes on
                                 const float phaseVal = phase_eval(S.phase, S.g, wi, dd);
                                 const f3 pref = T * (env / MER_INV_FOURPI) * phaseVal * mi_weight(MER_INV_FOURPI, phaseVal);
                                 if (!is_zero(pref)) {
                                     spawn_side_walk(P, c, K_NEE, ps, dd, tExit, pref, px, py, rng.fork(1).state, pixel, sample);
                                     W.p = ps; W.v = dd;                                // (W is idle between the collision and the next free flight: borrowed for the class estimate)
                                     child0 = c; c0class = march_class<CURVED, BND>(P, W);
-                                    flags ^= F_NEE_PAR;
+                                    flags = (int) (((uint32_t) flags & ~(3u << 4)) | (rn << 4));
                                 }
                                 spawned = true; ev = EV_PHASE;
                             }
                         }
                         if (!spawned) {
+                        if (SPAWNABLE && P.spawn) side_inline++;
                         prng = rng.state; rng = rng.fork(1); SET_FLAG(F_FORKED, true);       // the walk runs on a child stream (the oracle's sideTransmittance)
                         ev = W.begin(P, rng, C, K_NEE, ps, dd, tExit);
                         if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - tExit);
@@ -755,20 +768,21 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2
                 else {
                     bool spawned = false;
                     if (SPAWNABLE && P.spawn) {
-                        const uint32_t c = P.nslots + ((i * 2u + 1u) * 2u + (((uint32_t) flags >> 5) & 1u));
-                        if ((CSLOT(c, H_FLAGS) & 3u) == 0u) {
+                        uint32_t rn; const uint32_t c = free_side_slot(P, i, 1u, ((uint32_t) flags >> 7) & 3u, rn);
+                        if (c != 0u) {
                             const bool blocked = (maxDepth - depth - 1 == 0);                    // curved rays: the look-up always crosses the boundary once
                             const f3 pref = blocked ? f3(0, 0, 0) : T * env * mi_weight(phasePdf, MER_INV_FOURPI);
                             if (!is_zero(pref)) {
                                 spawn_side_walk(P, c, K_LOOKUP, ps, wo, itsT, pref, px, py, rng.fork(2).state, pixel, sample);
                                 W.p = ps; W.v = wo;
                                 child1 = c; c1class = march_class<CURVED, BND>(P, W);
-                                flags ^= F_LK_PAR;
+                                flags = (int) (((uint32_t) flags & ~(3u << 7)) | (rn << 7));
                             }
                             spawned = true; ev = EV_AFTER_LOOKUP;
                         }
                     }
                     if (!spawned) {
+                    if (SPAWNABLE && P.spawn) side_inline++;
                     prng = rng.state; rng = rng.fork(2); SET_FLAG(F_FORKED, true);
                     ev = W.begin(P, rng, C, K_LOOKUP, ps, wo, itsT);
                     if (ev == EV_TR_DONE) trv = (SIGMA == MER_SIGMA_GRID) ? f3(1, 1, 1) : homogeneous_transmittance(P, 0.0f - itsT);
@@ -878,6 +892,12 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2
         // live[1] = side walks in flight: one atomic per wave (spawned minus ended), not one per walk -- a single word sustains ~90 atomics per microsecond
         const int delta = __popcll(__ballot(child0 != 0u)) + __popcll(__ballot(child1 != 0u)) - __popcll(__ballot(child_done));
         if ((threadIdx.x & 63) == 0 && delta != 0) atomicAdd(P.live + 1, (uint32_t) delta);
+        const uint32_t nsp = (uint32_t) (__popcll(__ballot(child0 != 0u)) + __popcll(__ballot(child1 != 0u))), nin = wave_sum(side_inline);
+        if ((threadIdx.x & 63) == 0 && (nsp | nin)) {
+            unsigned long long *dst = P.counters + (size_t) ((j >> 6) % MER_COUNTER_REPLICAS) * MER_C_COUNT;
+            if (nsp) atomicAdd(dst + MER_C_SIDE_SPAWNED, (unsigned long long) nsp);
+            if (nin) atomicAdd(dst + MER_C_SIDE_INLINE, (unsigned long long) nin);
+        }
     }
     queue_push(P.sq[(pass + 1) & 1u], pass + 1, starved_out, i);
     flush_counters(P, C, 0);

@@ -250,6 +250,27 @@ def test_inline_walks_change_no_path(ctx, name):
         v.destroy()
 
 
+@pytest.mark.parametrize("name", ["cfg3_curved_rk4_trilinear", "cfg4_radial_rk4", "curved_woodcock2", "refractive_homogeneous_sigma", "parity_verlet_bspline", "sphere_boundary"])
+def test_spawned_side_walks_change_no_film(ctx, orc, name):
+    """curved rays, steady-state film: the transmittance walks of luminaire samples and emitter look-ups are handed to side-walk slots while the path
+    goes on (option spawn_walks = 1, the default) or run in the path's own lane (0).  Both draw from the same forked sampler streams, so the film is
+    the same up to float summation order -- also when nearly every walk finds its side-walk slot busy (a tiny slot pool) -- and equals the oracle's."""
+    p = CASES[name]()
+    sc, vols = ctx.upload_scene(p)
+    spp = 8
+    ctx.counters_reset(); fa = ctx.render_to_host(sc, 0, spp, seed=5); ca = ctx.counters()
+    assert ca[capi.C_SIDE_SPAWNED] > 0
+    with ctx.options(spawn_walks=0):
+        ctx.counters_reset(); fb = ctx.render_to_host(sc, 0, spp, seed=5); cb = ctx.counters()
+    assert cb[capi.C_SIDE_SPAWNED] == 0 and cb[capi.C_SIDE_INLINE] == 0
+    assert np.allclose(fa, fb, rtol=2e-4, atol=2e-5)
+    assert ca[capi.C_PATHS] == cb[capi.C_PATHS] and ca[capi.C_REAL] == cb[capi.C_REAL] and ca[capi.C_TENTATIVE] == cb[capi.C_TENTATIVE]
+    ref, _ = orc.render(p, 0, spp, 5, nthreads=8)
+    assert _rel_l2(fa[..., :3], ref[..., :3]) < 2e-2
+    for v in vols:
+        v.destroy()
+
+
 def test_determinism(ctx):
     p = scenes.straight_scene(N=24)
     sc, vols = ctx.upload_scene(p)
