@@ -101,7 +101,9 @@ __device__ __forceinline__ void spawn_side_walk(const Params &P, uint32_t c, int
     rec[CO_ITST] = __float_as_uint(rayT); rec[CO_N0] = __float_as_uint(1.0f); rec[CO_TRSUM] = 0u; rec[CO_SDENS] = 0u; rec[CO_TMIN] = 0u;
 }
 #define CSLOT(c, k) P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, c, P.nslots_all) * MER_SLOT_WORDS + (k)]
+#ifndef MER_SIDE_PER_KIND
 #define MER_SIDE_PER_KIND 3                                   // side-walk slots per path and kind (luminaire sample / look-up): 2 left 11 - 15 % of the walks in the path's lane, 3 leave ~2 %
+#endif
 enum { F_NEE_ROT = 16 /* bits 4-5 */, F_CHILD = 64, F_LK_ROT = 128 /* bits 7-8 */ };      // path flags (CO_PFLAGS) beside K_event's own: where the search for a free side-walk slot of each kind starts; the record is a side walk
 // first free side-walk slot of (path i, kind k), searched from rotation r: its record id, or 0
 __device__ __forceinline__ uint32_t free_side_slot(const Params &P, uint32_t i, uint32_t k, uint32_t r, uint32_t &r_next) {
