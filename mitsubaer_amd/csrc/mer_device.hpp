@@ -567,6 +567,7 @@ struct SegQueue {
     uint32_t *counts;         // [MER_LIVE_SLOTS][MER_NSEG], row = pass & (MER_LIVE_SLOTS-1)
     uint32_t segcap;
     unsigned long long *chk;  // MER_BOUNDS_CHECK: violation record (NULL in the product build)
+    uint16_t *keys;           // march lists under option march_sort: the cell of each item's position, same indexing as items (else NULL)
 };
 
 // One of a pair of ping-pong queues, by value (K_connect / the EXTRA K_event, whose kernel arguments must stay out of scratch).  Written with constant indices and a select: an address-taken `P.cq[row & 1]` can make the compiler copy the
@@ -638,6 +639,10 @@ struct Params {
     int32_t gen_iters, gen_all;
     uint32_t cq_row;                    // index l of the next K_connect launch: K_event appends its requests to cq[l & 1] row l
     int32_t mq_sort;                    // 1: march lists sorted by estimated steps to the boundary (option mq_sort = 0 turns it off for A/B runs)
+    // spatial sort of the march list (option march_sort; mer_wavefront.hpp, msort_* kernels): bits per axis of the cell grid over the RIF's world box (0 = off),
+    // bin order (0: cell-major, 1: class-major), the sorted list K_march sweeps, and the counting sort's scratch
+    int32_t msort, msort_major; float msort_o[3], msort_s[3];
+    uint32_t *msorted, *msort_hist, *msort_cursor, *msort_count;
     unsigned long long *chk;            // MER_BOUNDS_CHECK: violation record (NULL in the product build)
     uint64_t n_film, n_path_out;        // float counts of film / path_out: the extents the checks use
     // emitter `area` on a `rectangle` (EXTRA kernels, straight rays): objectToWorld, its inverse, the frame normal, 1 / area (make_params)

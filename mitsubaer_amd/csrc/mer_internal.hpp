@@ -33,6 +33,7 @@ struct Pipe {
     unsigned long long *hitq = nullptr, *hitq_ctr = nullptr; unsigned long long hitq_cap = 0;
     hipEvent_t readback[2] = {nullptr, nullptr}, finished = nullptr;     // two batches in flight per pipeline
     std::vector<hipEvent_t> pass_events;          // 3 per pass: before K_event, between, after K_march
+    uint32_t *msort = nullptr; uint32_t msort_cap = 0;            // spatial sort of the march list: sorted ids, gathered ids, keys (cap each), histogram, cursors, count
 };
 
 // Tuning / A-B switches of a context (mer_context_set_option).  Defaults are the measured optima of DESIGN.md section 4.
@@ -54,6 +55,9 @@ struct Options {
     int64_t inline_walks = 1;     // straight rays in a gridded sigma_t: K_event runs the walks itself (persistent lanes) instead of handing them to K_march
     int64_t spawn_walks = 1;      // curved rays, steady-state film: luminaire-sample / look-up walks run in side-walk slots while the path goes on (mer_wavefront.hpp)
     int64_t small_render_slots = 1;   // a render with few paths per slot uses fewer slots / pipelines, so that the wavefront stays full while it drains
+    int64_t grid_fit = 1;         // launch grids sized by what the lists can still hold (live path slots x records per path + side walks in flight at the last read-back) instead of by every record
+    int64_t march_sort = 0;       // curved rays, record layouts: march list also sorted by position (bits per axis of the cell grid, 1..3; 0 = off) and swept in XCD-contiguous chunks
+    int64_t march_sort_major = 0; // bin order of that sort: 0 = cell-major (all exit-time classes of a cell together), 1 = class-major
     int64_t lds_bricks = 0;       // K_march keeps every lane's current BRICK27 record in LDS (BRICK27 below 4 GiB only; measured slower)
 };
 
@@ -102,6 +106,7 @@ int rif_fetch_kind(mer_context *ctx, const mer_scene_desc *sc);
 struct Run {
     Params P; uint32_t nslots = 0, pass = 0; unsigned blocks = 0, gen_blocks = 0;
     int cur = 0; bool work_left = true, done = false;
+    uint32_t alive_bound = 0, child_bound = 0;      // from the last read-back: path slots not yet finished (never grows), side walks then in flight
 };
 // the kernels of one (CURVED, RIF, STEPPER, SIGMA, BND) combination, as launchable function pointers
 typedef void (*GenKernel)(const Params);

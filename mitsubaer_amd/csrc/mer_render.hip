@@ -47,6 +47,71 @@ __global__ void clear_side_flags_kernel(uint32_t *slots, uint32_t first, uint32_
     if (c < end) slots[(size_t) c * MER_SLOT_WORDS + H_FLAGS] = 0u;
 }
 
+// counting sort of a pass's march list by (cell, exit-time class): see "Spatial sort of the march list" in mer_wavefront.hpp
+// where item j of the concatenated segments of a row lives
+__device__ __forceinline__ size_t msort_locate(const SegQueue &q, uint32_t row, uint32_t j, uint32_t &cls) {
+    const uint32_t *c = q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG;
+    uint32_t seg = 0, off = j;
+#pragma unroll
+    for (int s = 0; s < MER_NSEG - 1; s++) { const uint32_t n = c[s]; if (seg == (uint32_t) s && off >= n) { off -= n; seg = s + 1; } }
+    cls = seg / (MER_NSEG / MER_MQ_CLASSES);
+    return (size_t) seg * q.segcap + MER_CHK(q.chk, CHK_QUEUE_ITEM, off, q.segcap);
+}
+__global__ void __launch_bounds__(MER_BLOCK) msort_hist_kernel(const Params P, uint32_t row) {
+    __shared__ uint32_t h[MER_SORT_MAXBINS];
+    const SegQueue q = pick_queue(P.mq, row);
+    const uint32_t count = queue_total(q, row), base = blockIdx.x * MER_SORT_CHUNK, nb = msort_bins(P);
+    if (base >= count) return;
+    for (uint32_t b = threadIdx.x; b < nb; b += MER_BLOCK) h[b] = 0u;
+    __syncthreads();
+    for (uint32_t k = 0; k < MER_SORT_CHUNK / MER_BLOCK; k++) {
+        const uint32_t j = base + k * MER_BLOCK + threadIdx.x;
+        if (j < count) { uint32_t cls; const size_t at = msort_locate(q, row, j, cls); atomicAdd(&h[msort_bin(P, q.keys[at], cls)], 1u); }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += MER_BLOCK) if (h[b]) atomicAdd(P.msort_hist + b, h[b]);
+}
+__global__ void __launch_bounds__(1024) msort_scan_kernel(const Params P) {
+    __shared__ uint32_t part[1024];
+    const uint32_t nb = msort_bins(P), t = threadIdx.x;
+    uint32_t loc[MER_SORT_MAXBINS / 1024], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < MER_SORT_MAXBINS / 1024; k++) { const uint32_t b = t * (MER_SORT_MAXBINS / 1024) + k; loc[k] = sum; sum += b < nb ? P.msort_hist[b] : 0u; }
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = t >= off ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = part[t] - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < MER_SORT_MAXBINS / 1024; k++) { const uint32_t b = t * (MER_SORT_MAXBINS / 1024) + k; if (b < nb) { P.msort_cursor[b] = excl + loc[k]; P.msort_hist[b] = 0u; } }
+    if (t == 1023) P.msort_count[0] = part[1023];
+}
+__global__ void __launch_bounds__(MER_BLOCK) msort_scatter_kernel(const Params P, uint32_t row) {
+    __shared__ uint32_t h[MER_SORT_MAXBINS];
+    const SegQueue q = pick_queue(P.mq, row);
+    const uint32_t count = P.msort_count[0], base = blockIdx.x * MER_SORT_CHUNK, nb = msort_bins(P);
+    if (base >= count) return;
+    for (uint32_t b = threadIdx.x; b < nb; b += MER_BLOCK) h[b] = 0u;
+    __syncthreads();
+    uint32_t item[MER_SORT_CHUNK / MER_BLOCK], key[MER_SORT_CHUNK / MER_BLOCK], rank[MER_SORT_CHUNK / MER_BLOCK];
+#pragma unroll
+    for (uint32_t k = 0; k < MER_SORT_CHUNK / MER_BLOCK; k++) {
+        const uint32_t j = base + k * MER_BLOCK + threadIdx.x;
+        key[k] = 0xffffffffu;
+        if (j < count) { uint32_t cls; const size_t at = msort_locate(q, row, j, cls); item[k] = q.items[at]; key[k] = msort_bin(P, q.keys[at], cls); rank[k] = atomicAdd(&h[key[k]], 1u); }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < nb; b += MER_BLOCK) { const uint32_t c = h[b]; if (c) h[b] = atomicAdd(P.msort_cursor + b, c); }     // the block's run inside bin b
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < MER_SORT_CHUNK / MER_BLOCK; k++)
+        if (key[k] != 0xffffffffu) P.msorted[MER_CHK(P.chk, CHK_QUEUE_ITEM, h[key[k]] + rank[k], P.nslots_all)] = item[k];
+}
+
 int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard *shard, uint64_t seed, float *film_dev, float *path_out_dev,
                   uint64_t n_film, uint64_t n_path_out) {
     Params P;
@@ -99,6 +164,8 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
     const bool has_env = scene->env_radiance[0] != 0 || scene->env_radiance[1] != 0 || scene->env_radiance[2] != 0;
     const bool spawn = opt.spawn_walks && curved && !extra && has_env && !path_out_dev && scene->decomposition == MER_DECOMPOSITION_NONE;
     const uint32_t slot_mult = spawn ? 1u + 2u * MER_SIDE_PER_KIND : 1u;
+    // spatial sort of the march lists (msort_* kernels): plain curved kernels on a gridded RIF inside a box or sphere
+    const int msort_bits = (curved && !extra && scene->boundary != MER_BOUNDARY_SDF && P.rif.res[0] > 1 && P.rif.wmax[0] > P.rif.wmin[0]) ? (int) opt.march_sort : 0;
     int npipes = (int) opt.pipes;
     if (shard->spp_count < npipes) npipes = std::max(1, shard->spp_count);
     uint32_t want = opt.nslots > 0 ? (uint32_t) opt.nslots : (uint32_t) ctx->prop.multiProcessorCount * 2048u * 4u;   // 4 x the resident lanes of the chip, over all pipelines
@@ -141,7 +208,8 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
             HIP_CHECK(ctx, hipMalloc((void **) &pp.slots, (size_t) cap * MER_SLOT_WORDS * sizeof(uint32_t)));
             for (SegQueue *sq : {&pp.eq, &pp.mq[0], &pp.mq[1], &pp.sq[0], &pp.sq[1], &pp.cq[0], &pp.cq[1]}) {
                 if (sq->items) (void) hipFree(sq->items);
-                sq->items = nullptr;
+                if (sq->keys) (void) hipFree(sq->keys);
+                sq->items = nullptr; sq->keys = nullptr;
                 sq->segcap = 2u * (cap / MER_NSEG) + 256u;          // two producer kernels may feed one segment
                 if (sq == &pp.eq) sq->segcap = (uint32_t) eq_segcap(cap);                        // every lane may be of one event class
                 if (sq == &pp.mq[0] || sq == &pp.mq[1]) sq->segcap = 2u * (cap / (MER_NSEG / MER_MQ_CLASSES)) + 256u;   // ... or of one march class
@@ -179,11 +247,30 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
             pp.cstate_slots = pp.nslots;
         }
         R.P.cstate = pp.cstate;
+        R.P.msort = 0; R.P.mq[0].keys = nullptr; R.P.mq[1].keys = nullptr;
+        if (msort_bits) {              // spatial sort of the march list: a cell per list entry (written with the entry), the sorted list, histogram, cursors, count
+            if (pp.msort_cap < pp.nslots) {
+                if (pp.msort) (void) hipFree(pp.msort);
+                pp.msort = nullptr; pp.msort_cap = 0;
+                HIP_CHECK(ctx, hipMalloc((void **) &pp.msort, ((size_t) pp.nslots + 2 * MER_SORT_MAXBINS + 16) * sizeof(uint32_t)));
+                pp.msort_cap = pp.nslots;
+            }
+            for (int k = 0; k < 2; k++) {
+                if (!pp.mq[k].keys) HIP_CHECK(ctx, hipMalloc((void **) &pp.mq[k].keys, (size_t) pp.mq[k].segcap * MER_NSEG * sizeof(uint16_t)));
+                R.P.mq[k].keys = pp.mq[k].keys;
+            }
+            R.P.msort = std::min(msort_bits, P.mq_sort ? 3 : 4); R.P.msort_major = (int) opt.march_sort_major;
+            R.P.msorted = pp.msort;
+            R.P.msort_hist = pp.msort + pp.msort_cap; R.P.msort_cursor = R.P.msort_hist + MER_SORT_MAXBINS; R.P.msort_count = R.P.msort_cursor + MER_SORT_MAXBINS;
+            for (int k = 0; k < 3; k++) { R.P.msort_o[k] = P.rif.wmin[k]; const float e = P.rif.wmax[k] - P.rif.wmin[k]; R.P.msort_s[k] = e > 0 ? (float) (1 << R.P.msort) / e : 0.0f; }
+            HIP_CHECK(ctx, hipMemsetAsync(R.P.msort_hist, 0, (2 * MER_SORT_MAXBINS + 16) * sizeof(uint32_t), pp.stream));
+        }
         R.P.hitq = pp.hitq; R.P.hitq_cap = pp.hitq_cap; R.P.hitq_ctr = pp.hitq_ctr; R.P.work_counter = pp.hitq_ctr + 48;
         R.P.ksteps = ksteps0; R.P.cq_row = 0;
         R.done = R.P.total_work == 0;
         if (R.done) continue;
         R.blocks = R.nslots * slot_mult / MER_BLOCK;                 // the lists may hold every record
+        R.alive_bound = R.nslots; R.child_bound = R.nslots * (slot_mult - 1u);
         R.gen_blocks = std::max(1u, std::min(R.nslots / MER_BLOCK, gen_blocks_max));
         HIP_CHECK(ctx, hipMemsetAsync(pp.slots, 0, (size_t) R.nslots * MER_SLOT_WORDS * sizeof(uint32_t), pp.stream));
         // side-walk records: only their state word must read "idle" (the region may hold stale records of a render with another slot count)
@@ -199,8 +286,19 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
     // one batch = check_every passes of a pipeline followed by the read-back of its finished-slot count into slot `rb`.  Two batches
     // are kept in flight per pipeline, so that a pipeline never runs dry while the host waits for another one's read-back (a
     // finished render thus carries one batch of empty passes: ~0.5 ms)
+    // Grid sizes.  A list can hold every record, but a launch of R.blocks blocks costs its dispatch whether or not they find work (~0.17 ms for the
+    // 14 336 blocks of a 512 K-slot pipeline with side walks: the whole duration of a pass in the drain of a render).  What the lists CAN hold is
+    // known: finished path slots never come back, so from the last read-back on there are at most `alive` paths, each with its side-walk slots, plus
+    // the side walks that were in flight then; and a side walk returns to K_event only under the two-walk Woodcock estimator.
+    const bool side_walks_return = scene->sigma_mode == MER_SIGMA_GRID && scene->tr_estimator == MER_TR_WOODCOCK2;
     auto enqueue_batch = [&](int q, int rb) -> int {
         Pipe &pp = ctx->pipes[q]; Run &R = runs[q];
+        unsigned march_blocks = R.blocks, event_blocks = R.blocks;
+        if (opt.grid_fit) {
+            const uint64_t records = std::min<uint64_t>((uint64_t) R.nslots * slot_mult, (uint64_t) R.alive_bound * slot_mult + R.child_bound);
+            march_blocks = (unsigned) std::max<uint64_t>(1, (records + MER_BLOCK - 1) / MER_BLOCK);
+            event_blocks = side_walks_return ? march_blocks : (unsigned) std::max<uint64_t>(1, ((uint64_t) R.alive_bound + MER_BLOCK - 1) / MER_BLOCK);
+        }
         for (uint32_t b = 0; b < check_every; b++) {
             const uint32_t pass = R.pass;
             while (pp.pass_events.size() < (size_t) (pass + 1) * 3) {
@@ -208,13 +306,19 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
             }
             if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 0], pp.stream));
             for (int g = 0; R.work_left && g < (pass == 0 ? 6 : 1); g++) hipLaunchKernelGGL(ks.gen, dim3(R.gen_blocks), dim3(MER_BLOCK), 0, pp.stream, R.P);
-            hipLaunchKernelGGL(ks.event, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+            hipLaunchKernelGGL(ks.event, dim3(event_blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
             for (int l = 0; connect_stage && l < connect_launches; l++) {
-                hipLaunchKernelGGL(ks.connect, dim3(R.blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+                hipLaunchKernelGGL(ks.connect, dim3(event_blocks), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
                 R.P.cq_row++;
             }
             if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 1], pp.stream));
-            hipLaunchKernelGGL(ks.march, dim3(R.blocks), dim3(MER_BLOCK), (size_t) opt.march_lds_kb * 1024, pp.stream, R.P, pass);   // dynamic LDS: an occupancy cap for A/B runs
+            if (R.P.msort) {
+                const unsigned sb = (unsigned) (((uint64_t) march_blocks * MER_BLOCK + MER_SORT_CHUNK - 1) / MER_SORT_CHUNK);
+                hipLaunchKernelGGL(msort_hist_kernel, dim3(sb), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+                hipLaunchKernelGGL(msort_scan_kernel, dim3(1), dim3(1024), 0, pp.stream, R.P);
+                hipLaunchKernelGGL(msort_scatter_kernel, dim3(sb), dim3(MER_BLOCK), 0, pp.stream, R.P, pass);
+            }
+            hipLaunchKernelGGL(ks.march, dim3(march_blocks), dim3(MER_BLOCK), (size_t) opt.march_lds_kb * 1024, pp.stream, R.P, pass);   // dynamic LDS: an occupancy cap for A/B runs
             if (pass_events) HIP_CHECK(ctx, hipEventRecord(pp.pass_events[pass * 3 + 2], pp.stream));
             R.pass++;
         }
@@ -246,6 +350,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
                 fprintf(stderr, "[mer] t=%8.3f ms pipe %d passes %u finished %u / %u work %llu / %llu K=%d\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(),
                         q, R.pass, finished_slots, R.nslots, *(unsigned long long *) (pp.host_live + 4 * rb + 2), (unsigned long long) R.P.total_work, R.P.ksteps);
             if (finished_slots >= R.nslots && pp.host_live[4 * rb + 1] == 0u) { R.done = true; continue; }      // every path done and no side walk in flight
+            R.alive_bound = R.nslots - std::min(finished_slots, R.nslots); R.child_bound = pp.host_live[4 * rb + 1];
             R.work_left = *(unsigned long long *) (pp.host_live + 4 * rb + 2) < R.P.total_work;
             // Pass length in the tail.  The tail of a render is the serial latency of its deepest paths, and a path advances by ONE walk (free
             // flight, NEE or look-up: ~65 steps) per pass however long the pass may be, so a pass should end when most lanes have parked.

@@ -267,7 +267,7 @@ __device__ __forceinline__ int connect_class_of(const Params &P, const ConnState
     return connect_class(P, S.phase == CP_PATHLEN ? 1 : 0, dot(d, dir) * __builtin_amdgcn_rsqf(dot(dir, dir)));
 }
 template <int NCLS>
-__device__ __forceinline__ void queue_push_class(const SegQueue &q, uint32_t row, bool pred, uint32_t i, int cls) {
+__device__ __forceinline__ void queue_push_class(const SegQueue &q, uint32_t row, bool pred, uint32_t i, int cls, uint32_t key = 0u) {
     constexpr uint32_t SPC = MER_NSEG / NCLS;
     static_assert(SPC >= 1 && SPC * NCLS == MER_NSEG, "classes must divide the segments");
     const unsigned long long any = __ballot(pred);
@@ -286,15 +286,34 @@ __device__ __forceinline__ void queue_push_class(const SegQueue &q, uint32_t row
         if (lane < NCLS && lane_mask)
             base = atomicAdd(q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG + (uint32_t) lane * SPC + (wave & (SPC - 1)), (uint32_t) __popcll(lane_mask));
         base = (uint32_t) __shfl((int) base, c, 64);
-        if (pred) q.items[(size_t) ((uint32_t) c * SPC + (wave & (SPC - 1))) * q.segcap + MER_CHK(q.chk, CHK_QUEUE_SEG, base + (uint32_t) __popcll(mine & ((1ULL << lane) - 1ULL)), q.segcap)] = i;
+        if (pred) {
+            const size_t at = (size_t) ((uint32_t) c * SPC + (wave & (SPC - 1))) * q.segcap + MER_CHK(q.chk, CHK_QUEUE_SEG, base + (uint32_t) __popcll(mine & ((1ULL << lane) - 1ULL)), q.segcap);
+            q.items[at] = i;
+            if (q.keys) q.keys[at] = (uint16_t) key;          // march lists under option march_sort: the cell of the lane's position (msort_cell)
+        }
     }
 }
 // Class of a marching lane: 0 = at least one whole pass (ksteps trips) left before the ray can leave the shape, 1 .. 7 = sevenths
 // of a pass, longest first (the long waves of a launch start first).  Curved rays: the chord to the boundary along the current
 // direction over the step size (the bench scene's rays bend by ~0.1 rad per unit length: good to ~10 %); straight rays: the
 // expected number of tentative collisions up to tmax.  The signed-distance boundary is not estimated (class 0).
+// cell of a position in the 2^b x 2^b x 2^b grid over the RIF's world box, in Morton order (option march_sort: b = P.msort bits per axis, at most 4)
+__device__ __forceinline__ uint32_t msort_spread3(uint32_t v) { v &= 15u; return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6); }
+__device__ __forceinline__ uint32_t msort_cell(const Params &P, f3 p) {
+    const int nc = 1 << P.msort;
+    const int cx = min(max((int) ((p.x - P.msort_o[0]) * P.msort_s[0]), 0), nc - 1), cy = min(max((int) ((p.y - P.msort_o[1]) * P.msort_s[1]), 0), nc - 1),
+              cz = min(max((int) ((p.z - P.msort_o[2]) * P.msort_s[2]), 0), nc - 1);
+    return msort_spread3((uint32_t) cx) | (msort_spread3((uint32_t) cy) << 1) | (msort_spread3((uint32_t) cz) << 2);
+}
+template <bool CURVED, int BND, class WalkT> __device__ __forceinline__ int march_class_only(const Params &P, const WalkT &W);
+/// what a lane joins the march list with: its exit-time class in bits 0-7 and, under option march_sort, the cell of its position above them
 template <bool CURVED, int BND, class WalkT>
 __device__ __forceinline__ int march_class(const Params &P, const WalkT &W) {
+    const int c = march_class_only<CURVED, BND>(P, W);
+    return (CURVED && P.msort) ? c | (int) (msort_cell(P, W.p) << 8) : c;
+}
+template <bool CURVED, int BND, class WalkT>
+__device__ __forceinline__ int march_class_only(const Params &P, const WalkT &W) {
     if (BND != 0 || !P.mq_sort) return 0;
     const mer_scene_desc &S = P.sc;
     float r;
@@ -337,6 +356,22 @@ __device__ __forceinline__ void queue_clear_row(const SegQueue &q, uint32_t row,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Spatial sort of the march list (option march_sort).  K_march is bound by the rate at which the fabric serves random 128-byte lines (DESIGN
+// section 4): the only way to take lines off it is to have them answered by the XCD's L2, and the L2 turns over every few microseconds, so two
+// lanes share a line only if they are near one another in the volume AND resident on the same XCD at the same time.  Between K_event and K_march
+// the list of a pass is therefore counting-sorted by (cell of a 2^b x 2^b x 2^b grid over the RIF's world box in Morton order, exit-time class), and
+// K_march deals the sorted list to the XCDs in eight contiguous chunks (blocks b and b + 8 share an XCD): the ~41 K lanes an XCD holds at any time
+// come from one neighbourhood of the volume.  Three small launches per pass: histogram (+ the gather of ids and keys), scan, scatter.
+#define MER_SORT_CHUNK 2048u             // list items per block of the histogram / scatter kernels (256 threads x 8)
+#define MER_SORT_MAXBINS 4096u           // 8 classes x 8^3 cells
+__device__ __forceinline__ uint32_t msort_bin(const Params &P, uint32_t cell, uint32_t cls) {
+    if (!P.mq_sort) return cell;                 // no exit-time classes (fields beyond 2^28 voxels): cells only
+    return P.msort_major ? (cls << (3 * P.msort)) + cell : cell * MER_MQ_CLASSES + cls;
+}
+__device__ __forceinline__ uint32_t msort_bins(const Params &P) { return (P.mq_sort ? (uint32_t) MER_MQ_CLASSES : 1u) << (3 * P.msort); }
+// (the three kernels of the sort live in mer_render.hip: one translation unit)
+
+// ---------------------------------------------------------------------------------------------------
 // K_march: the hot loop.  trace() / traceTillBoundary (heterogeneousrefractive.cpp:671-691,742-776) and the
 // delta-tracking loop (heterogeneous.cpp:633-656, :562-585) for whichever ray the lane is on.
 #ifndef MER_MARCH_WAVES
@@ -353,12 +388,17 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
     // while K_march runs, so this is the race-free place to clamp the head before K_gen produces again
     if (j == 0) { const unsigned long long t = P.hitq_ctr[0], h = P.hitq_ctr[MER_HITQ_HEAD]; if (h > t) P.hitq_ctr[MER_HITQ_HEAD] = t; }
     // sweep the compacted list of marching slots: dense waves in the steady state and in the tail alike
-    const uint32_t count = queue_total(P.mq[pass & 1u], pass);
+    const uint32_t count = P.msort ? P.msort_count[0] : queue_total(P.mq[pass & 1u], pass);
+    uint32_t jl = j;                         // position in the list
+    if (P.msort) {                           // the spatially sorted list in eight contiguous chunks, one per XCD (blocks b, b + 8, ... share one): bijective over the T blocks with work
+        const uint32_t T = (count + MER_BLOCK - 1) / MER_BLOCK, b = blockIdx.x, x = b & 7u, qd = T >> 3, r = T & 7u;
+        jl = b < T ? ((x < r ? x * (qd + 1u) : r * (qd + 1u) + (x - r) * qd) + (b >> 3)) * MER_BLOCK + threadIdx.x : 0xffffffffu;
+    }
     LaneCounters C; C.clear();
     uint32_t iters = 0, i = 0;
     bool has_event = false, still_marching = false, child_ended = false; int ev_class = 0, mq_class = 0;
-    if (j < count) {
-        i = queue_item(P.mq[pass & 1u], pass, j);
+    if (jl < count) {
+        i = P.msort ? P.msorted[jl] : queue_item(P.mq[pass & 1u], pass, jl);
         uint32_t fl;
         Walk<CURVED, RIF, STEPPER, SIGMA, BND> W;
         Rng rng; uint32_t pixel, sample; float sigma;
@@ -410,7 +450,7 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
     }
     // compaction: lanes parked on an event go to K_event's queue (by class), the others straight to the next march list
     queue_push_class<MER_EV_CLASSES>(P.eq, pass + 1, has_event, i, ev_class);
-    queue_push_class<MER_MQ_CLASSES>(P.mq[(pass + 1) & 1u], pass + 1, still_marching, i, mq_class);
+    queue_push_class<MER_MQ_CLASSES>(P.mq[(pass + 1) & 1u], pass + 1, still_marching, i, mq_class & 255, (uint32_t) mq_class >> 8);
     if (CURVED && BND == 0) {                    // side walks finished in this launch leave the in-flight count (one atomic per wave)
         const int ended = __popcll(__ballot(child_ended));
         if ((threadIdx.x & 63) == 0 && ended) atomicAdd(P.live + 1, (uint32_t) (-ended));
@@ -887,10 +927,10 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2
     }   // j < count
     // a new connection joins the pending ones of the next K_connect launch, grouped by the length of the rays its solver will trace
     if (EXTRA && CURVED) queue_push_class<MER_CQ_CLASSES>(pick_queue(P.cq, P.cq_row), P.cq_row, connecting, i, cq_class);
-    queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class);
+    queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class & 255, (uint32_t) mq_class >> 8);
     if (SPAWNABLE) {                                                           // the side walks spawned in this visit march with everybody else
-        queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, child0 != 0u, child0, c0class);
-        queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, child1 != 0u, child1, c1class);
+        queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, child0 != 0u, child0, c0class & 255, (uint32_t) c0class >> 8);
+        queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, child1 != 0u, child1, c1class & 255, (uint32_t) c1class >> 8);
         // live[1] = side walks in flight: one atomic per wave (spawned minus ended), not one per walk -- a single word sustains ~90 atomics per microsecond
         const int delta = __popcll(__ballot(child0 != 0u)) + __popcll(__ballot(child1 != 0u)) - __popcll(__ballot(child_done));
         if ((threadIdx.x & 63) == 0 && delta != 0) atomicAdd(P.live + 1, (uint32_t) delta);
