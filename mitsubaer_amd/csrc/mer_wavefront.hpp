@@ -108,13 +108,20 @@ enum { F_NEE_ROT = 16 /* bits 4-5 */, F_CHILD = 64, F_LK_ROT = 128 /* bits 7-8 *
 // first free side-walk slot of (path i, kind k), searched from rotation r: its record id, or 0
 __device__ __forceinline__ uint32_t free_side_slot(const Params &P, uint32_t i, uint32_t k, uint32_t r, uint32_t &r_next) {
     const uint32_t base = P.nslots + (i * 2u + k) * MER_SIDE_PER_KIND;
+    uint32_t fl[MER_SIDE_PER_KIND];
 #pragma unroll
-    for (uint32_t t = 0; t < MER_SIDE_PER_KIND; t++) {
-        const uint32_t q = (r + t) % MER_SIDE_PER_KIND, c = base + q;
-        if ((P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, c, P.nslots_all) * MER_SLOT_WORDS + H_FLAGS] & 3u) == 0u) { r_next = (q + 1u) % MER_SIDE_PER_KIND; return c; }
+    for (uint32_t t = 0; t < MER_SIDE_PER_KIND; t++)          // every state word in ONE round trip (a probe per trip made the wave wait for its unluckiest lane)
+        fl[t] = P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, base + t, P.nslots_all) * MER_SLOT_WORDS + H_FLAGS];
+    uint32_t found = 0u; r_next = r;
+#pragma unroll
+    for (uint32_t t = MER_SIDE_PER_KIND; t-- > 0u; ) {         // last to first, so that the first free slot in rotation order wins
+        const uint32_t q = (r + t) % MER_SIDE_PER_KIND;
+        uint32_t f = fl[0];
+#pragma unroll
+        for (uint32_t u = 1; u < MER_SIDE_PER_KIND; u++) f = q == u ? fl[u] : f;
+        if ((f & 3u) == 0u) { found = base + q; r_next = (q + 1u) % MER_SIDE_PER_KIND; }
     }
-    r_next = r;
-    return 0u;
+    return found;
 }
 
 // Counter flush: one set of atomics per wave, spread over MER_COUNTER_REPLICAS copies (summed on the host) so that a
@@ -297,6 +304,36 @@ __device__ __forceinline__ void queue_push_class(const SegQueue &q, uint32_t row
 // of a pass, longest first (the long waves of a launch start first).  Curved rays: the chord to the boundary along the current
 // direction over the step size (the bench scene's rays bend by ~0.1 rad per unit length: good to ~10 %); straight rays: the
 // expected number of tentative collisions up to tmax.  The signed-distance boundary is not estimated (class 0).
+// Three pushes into one class-sorted list with ONE returning atomic per class (K_event: the path and the two side walks it has just spawned join the
+// same march list; three queue_push_class calls are three dependent round trips for the wave).  Inside a class segment the wave's items lie in the
+// order (all of a, all of b, all of c).
+template <int NCLS>
+__device__ __forceinline__ void queue_push_class3(const SegQueue &q, uint32_t row, bool pa, uint32_t ia, int ca, uint32_t ka,
+                                                  bool pb, uint32_t ib, int cb, uint32_t kb, bool pc, uint32_t ic, int cc, uint32_t kc) {
+    constexpr uint32_t SPC = MER_NSEG / NCLS;
+    if (!__ballot(pa || pb || pc)) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * MER_BLOCK + threadIdx.x) >> 6, sub = wave & (SPC - 1);
+    ca = ca < 0 ? 0 : (ca >= NCLS ? NCLS - 1 : ca); cb = cb < 0 ? 0 : (cb >= NCLS ? NCLS - 1 : cb); cc = cc < 0 ? 0 : (cc >= NCLS ? NCLS - 1 : cc);
+    unsigned long long mine_a = 0, mine_b = 0, mine_c = 0; uint32_t na = 0, nb = 0, nc = 0;      // lane k < NCLS: the wave's counts of class k
+#pragma unroll
+    for (int k = 0; k < NCLS; k++) {
+        const unsigned long long ma = __ballot(pa && ca == k), mb = __ballot(pb && cb == k), mc = __ballot(pc && cc == k);
+        if (ca == k) mine_a = ma;
+        if (cb == k) mine_b = mb;
+        if (cc == k) mine_c = mc;
+        if (lane == k) { na = (uint32_t) __popcll(ma); nb = (uint32_t) __popcll(mb); nc = (uint32_t) __popcll(mc); }
+    }
+    uint32_t base = 0;
+    if (lane < NCLS && na + nb + nc) base = atomicAdd(q.counts + (size_t) (row & (MER_LIVE_SLOTS - 1)) * MER_NSEG + (uint32_t) lane * SPC + sub, na + nb + nc);
+    const unsigned long long below = (1ULL << lane) - 1ULL;
+    const uint32_t pos_a = (uint32_t) __shfl((int) base, ca, 64) + (uint32_t) __popcll(mine_a & below);
+    const uint32_t pos_b = (uint32_t) __shfl((int) (base + na), cb, 64) + (uint32_t) __popcll(mine_b & below);
+    const uint32_t pos_c = (uint32_t) __shfl((int) (base + na + nb), cc, 64) + (uint32_t) __popcll(mine_c & below);
+    if (pa) { const size_t at = (size_t) ((uint32_t) ca * SPC + sub) * q.segcap + MER_CHK(q.chk, CHK_QUEUE_SEG, pos_a, q.segcap); q.items[at] = ia; if (q.keys) q.keys[at] = (uint16_t) ka; }
+    if (pb) { const size_t at = (size_t) ((uint32_t) cb * SPC + sub) * q.segcap + MER_CHK(q.chk, CHK_QUEUE_SEG, pos_b, q.segcap); q.items[at] = ib; if (q.keys) q.keys[at] = (uint16_t) kb; }
+    if (pc) { const size_t at = (size_t) ((uint32_t) cc * SPC + sub) * q.segcap + MER_CHK(q.chk, CHK_QUEUE_SEG, pos_c, q.segcap); q.items[at] = ic; if (q.keys) q.keys[at] = (uint16_t) kc; }
+}
 // cell of a position in the 2^b x 2^b x 2^b grid over the RIF's world box, in Morton order (option march_sort: b = P.msort bits per axis, at most 4)
 __device__ __forceinline__ uint32_t msort_spread3(uint32_t v) { v &= 15u; return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6); }
 __device__ __forceinline__ uint32_t msort_cell(const Params &P, f3 p) {
@@ -479,11 +516,14 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
 // launch, pops the next sample from the hit ring and goes on until the ring is empty -- a persistent-lane megakernel, which for curved rays
 // (hundreds of 350-instruction steps per walk) was the slowest form of all (section 4's table) and for straight rays is the fastest.  Same
 // sampler draws in the same order: per-path results do not change (tested).
+#ifndef MER_EVENT_WAVES
+#define MER_EVENT_WAVES 2              // waves per SIMD K_event is compiled for (256 VGPR): 3 and 4 measured, see DESIGN section 4
+#endif
 #ifndef MER_INLINE_EVENT_WAVES
 #define MER_INLINE_EVENT_WAVES 1
 #endif
 template <bool CURVED, int RIF, int STEPPER, int SIGMA, bool EXTRA, int BND = 0, bool INLINE = false>
-__global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2) event_kernel(const Params P, uint32_t pass) {
+__global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : MER_EVENT_WAVES) event_kernel(const Params P, uint32_t pass) {
     typedef Walk<CURVED, RIF, STEPPER, SIGMA, BND> WalkT;
     const uint32_t j = blockIdx.x * MER_BLOCK + threadIdx.x;
     if (j >= P.nslots_all) return;
@@ -500,8 +540,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2
     constexpr bool SPAWNABLE = CURVED && !EXTRA;                             // the plain curved kernels (the bench kernels) spawn side walks when P.spawn says so
     if (j < count) {
     i = pass == 0 ? j : (j < nq ? queue_item(P.eq, pass, j) : queue_item(P.sq[pass & 1u], pass, j - nq));
-    const uint32_t fl = SLOT(H_FLAGS);
-    int st = fl & 3u, ev = (fl >> 2) & 15u;
+    int st, ev;                                // from the record's state word (below: it arrives with the rest of the record, in one round trip)
 
     const mer_scene_desc &S = P.sc;
     const f3 env(S.env_radiance[0], S.env_radiance[1], S.env_radiance[2]);
@@ -527,9 +566,11 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2
     f3 L(0, 0, 0), T(1, 1, 1), ps(0, 0, 0), dsave(0, 0, 1), dd(0, 0, 1), wi(0, 0, 1), trv(1, 1, 1);
     int depth = 1, flags = F_EMITTED, px_i = 0, py_i = 0;
     bool starved = false;
-    if (st == ST_MARCH) {
-        uint32_t fl2;
-        load_hot(P, i, fl2, W, rng, pixel, sample, sigma);
+    {   // The whole record is read before its state word is looked at: a lane whose slot holds no path (new, starved) reads a stale or zeroed record and
+        // throws it away -- one round trip for the wave instead of two (state word, then the record of the lanes that have one).
+        uint32_t fl;
+        load_hot(P, i, fl, W, rng, pixel, sample, sigma);
+        st = fl & 3u; ev = (fl >> 2) & 15u;
         px = SLOTF(CO_PXF); py = SLOTF(CO_PYF);
         L = f3(SLOTF(CO_LX), SLOTF(CO_LY), SLOTF(CO_LZ)); T = f3(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ));
         depth = (int) SLOT(CO_DEPTH); flags = (int) SLOT(CO_PFLAGS);
@@ -539,12 +580,17 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2
         W.sdens = SLOTF(CO_SDENS); W.tmin = SLOTF(CO_TMIN);
         plen = SLOTF(CO_PLEN); trOpt = SLOTF(CO_TROPT); if (EXTRA) etaPath = SLOTF(CO_ETA);
         prng = (uint64_t) SLOT(CO_WNEXT_LO) | ((uint64_t) SLOT(CO_WNEXT_HI) << 32);
+    }
+    if (st == ST_MARCH) {
         px_i = (int) (pixel % (uint32_t) S.width); py_i = (int) (pixel / (uint32_t) S.width);
     } else {
         W.kind = K_FREE; W.steps_left = 0; W.rem = 0; W.seg_inf = 0; W.t = 0; W.tmin = 0; W.tmax = 0; W.n0 = 1; W.dist = 0;
         W.opt = 0; W.sdens = 0; W.Tr = 1; W.trsum = 0; W.walk = 0; W.p = f3(0, 0, 0); W.v = f3(0, 0, 1); W.backstep = 0; W.hprev = 0;
         W.agg = 0; W.dleft = 0;
         rng.state = 0; rng.inc = 1;
+        pixel = 0; sample = 0; prng = 0; px = 0; py = 0; sigma = 0; phasePdf = 0; itsT = 0; etaPath = 1.0f; plen = 0; trOpt = 0;
+        L = f3(0, 0, 0); T = f3(1, 1, 1); ps = f3(0, 0, 0); dsave = f3(0, 0, 1); dd = f3(0, 0, 1); wi = f3(0, 0, 1);
+        depth = 1; flags = F_EMITTED;
     }
 
     // ring tail and work counter are stable while K_event runs (K_gen is not running): read them once, and keep them on
@@ -555,7 +601,14 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2
         if (st == ST_NEW) {
             // K_gen has already retired the camera samples that never reach the medium; what is left to do here is to
             // pop one sample that does (a work id from the hit ring) and replay its deterministic prologue
-            const unsigned long long idx = atomicAdd(P.hitq_ctr + MER_HITQ_HEAD, 1ULL);
+            // one returning atomic per WAVE for the lanes that regenerate in this trip (64 per-lane atomics on the one head word serialise in L2, and every
+            // wave of the launch pops from it)
+            const unsigned long long regen = __ballot(true);
+            const int rl = threadIdx.x & 63, rleader = __ffsll((long long) regen) - 1;
+            unsigned long long rbase = 0;
+            if (rl == rleader) rbase = atomicAdd(P.hitq_ctr + MER_HITQ_HEAD, (unsigned long long) __popcll(regen));
+            rbase = ((unsigned long long) (uint32_t) __shfl((int) (rbase >> 32), rleader, 64) << 32) | (uint32_t) __shfl((int) (uint32_t) rbase, rleader, 64);
+            const unsigned long long idx = rbase + (unsigned long long) __popcll(regen & ((1ULL << rl) - 1ULL));
             if (idx >= tail) {
                 // nothing to pop: finished if the work counter is exhausted too, otherwise wait for the next pass
                 if (work_issued >= P.total_work) st = ST_DONE; else starved = true;
@@ -927,10 +980,10 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : 2
     }   // j < count
     // a new connection joins the pending ones of the next K_connect launch, grouped by the length of the rays its solver will trace
     if (EXTRA && CURVED) queue_push_class<MER_CQ_CLASSES>(pick_queue(P.cq, P.cq_row), P.cq_row, connecting, i, cq_class);
-    queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class & 255, (uint32_t) mq_class >> 8);
+    if (!SPAWNABLE) queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class & 255, (uint32_t) mq_class >> 8);
     if (SPAWNABLE) {                                                           // the side walks spawned in this visit march with everybody else
-        queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, child0 != 0u, child0, c0class & 255, (uint32_t) c0class >> 8);
-        queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, child1 != 0u, child1, c1class & 255, (uint32_t) c1class >> 8);
+        queue_push_class3<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class & 255, (uint32_t) mq_class >> 8,
+                                          child0 != 0u, child0, c0class & 255, (uint32_t) c0class >> 8, child1 != 0u, child1, c1class & 255, (uint32_t) c1class >> 8);
         // live[1] = side walks in flight: one atomic per wave (spawned minus ended), not one per walk -- a single word sustains ~90 atomics per microsecond
         const int delta = __popcll(__ballot(child0 != 0u)) + __popcll(__ballot(child1 != 0u)) - __popcll(__ballot(child_done));
         if ((threadIdx.x & 63) == 0 && delta != 0) atomicAdd(P.live + 1, (uint32_t) delta);
