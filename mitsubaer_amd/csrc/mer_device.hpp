@@ -202,6 +202,8 @@ __device__ __forceinline__ f3 lookup_spectrum(const DGrid &g, f3 p) {
 // Trilinear RIF: value + analytic gradient of the interpolant; cell clamped to the grid (new --
 // gridvolume has no value()/gradient(), src/librender/volume.cpp:57-80).  Being new functionality, its
 // arithmetic is DEFINED here (and restated identically in the oracle): monomial coefficients per cell (CellCache::set), fused Horner evaluation.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // The 8 corner values of the last cell are kept in registers: the 4 RK4 stages of a half-voxel step land in
 // the same cell most of the time, so the gather is re-issued only when the cell index changes.
 struct CellCache {
@@ -213,7 +215,10 @@ struct CellCache {
     // add / fma operations of nested lerps that re-derive the corner differences every time
     float a0, ax, ay, az, axy, axz, ayz, axyz;
     int brick;                // RIFK_BRICK27_LDS: the brick whose record this lane holds in LDS, -1 = none
-    __device__ __forceinline__ void reset() { cell = -1; brick = -1; cx = cy = cz = -1.0e30f; a0 = ax = ay = az = axy = axz = ayz = axyz = 0.0f; }
+    // predicted-cell fetch (K_march's RK4 step on BRICK27 buffer loads, trilinear_value_grad_pf): the corners of the cell the ray is expected to enter
+    // next, requested half a step ahead and not waited for; ncell = its linear index, -1 = nothing pending
+    int ncell; u32x2 n00, n01, n10, n11;
+    __device__ __forceinline__ void reset() { cell = -1; brick = -1; ncell = -1; cx = cy = cz = -1.0e30f; a0 = ax = ay = az = axy = axz = ayz = axyz = 0.0f; }
     // corners d[z][y][x] -> coefficients; this operation order is part of the definition of the interpolant's arithmetic (oracle: TriCoeff)
     __device__ __forceinline__ void set(float d000, float d001, float d010, float d011, float d100, float d101, float d110, float d111) {
         a0 = d000; ax = d001 - d000; ay = d010 - d000; az = d100 - d000;
@@ -236,9 +241,6 @@ struct CellCache {
 #define RIFK_DENSE_BUF 3
 #define RIFK_CELL8 4
 #define RIFK_CELL8_BUF 5
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 // MER_ALWAYS_LOAD (experiment): no cell cache, every evaluation gathers its cell -- straight-line code, no exec-mask regions
 #ifdef MER_ALWAYS_LOAD
 #define MER_CELL_TEST(cond) true
@@ -374,6 +376,81 @@ __device__ __forceinline__ void trilinear_value_grad(const DGrid &g, CellCache &
     grad = f3(gx * g.s[0], gy * g.s[1], gz * g.s[2]);
 }
 
+// ---- predicted-cell fetch -------------------------------------------------------------------------------------------------------------------
+// K_march is latency-bound: a wave waits twice per RK4 step -- at stage 2 and at stage 4, where some of its lanes have crossed
+// a cell face -- for the slowest of those lanes' misses, and fabric, L2 and VALU all have room.  The ray's next cell is predictable half a step
+// ahead (the stage-4 point from the stage-1 slope; the next step's stage-2 point from the stage-3 slope), so the gather of that cell is ISSUED
+// at the previous fetch point -- after that point's own loads, which return first -- into a second set of 8 registers that nobody waits for; when
+// the ray arrives and the cell is the predicted one the corners are (usually) there.  A wrong prediction costs one wasted gather of a line that
+// is needed a step later anyway; the corners are the same floats either way: bit-identical results.  BRICK27 with buffer loads only.
+// MEASURED (profiles/round3/ab_predicted_cell_fetch.txt): bit-identical (186 parity tests), and SLOWER -- 106 VGPR / 4 waves per SIMD: 287 against 369
+// Mpaths/s on the headline job; forced to 96 VGPR / 5 waves (10 spills): 316; 512^3: 153 / 163 against 179.  The two predictions add ~50 VALU
+// instructions and four exec-mask regions to a 344-instruction step, and the time goes up in proportion: with 2-3 of 5 waves waiting on memory at
+// any time the ready ones already keep the SIMD's issue port about as busy as their dependent chains allow, so the loop pays for instructions as
+// well as for latency.  Kept behind this macro (off) as the record of the variant.
+#ifndef MER_PREFETCH
+#define MER_PREFETCH 0
+#endif
+__device__ __forceinline__ int brick27_word(const DGrid &g, int x1, int y1, int z1) {
+    const int bs = g.bshift, bm = (1 << bs) - 1, bw = g.bw;
+    const int brick = (int) (__umul24(__umul24(z1 >> bs, g.nby) + (y1 >> bs), g.nbx) + (x1 >> bs));
+    return (int) MER_CHK(g.chk, CHK_GRID_RECORD, (size_t) (uint32_t) brick * (uint32_t) g.recw + (uint32_t) (((z1 & bm) * bw + (y1 & bm)) * bw + (x1 & bm)),
+                         g.n_record - (uint64_t) (bw * bw + bw) - 1u);
+}
+// PRED: `pred` (world / volume coordinates like p) is where the ray is expected to need a cell next
+template <bool PRED>
+__device__ __forceinline__ void trilinear_value_grad_pf(const DGrid &g, CellCache &cc, f3 p, f3 pred, float &val, f3 &grad) {
+    const float px = __builtin_fmaf(g.s[0], p.x, g.t[0]), py = __builtin_fmaf(g.s[1], p.y, g.t[1]), pz = __builtin_fmaf(g.s[2], p.z, g.t[2]);
+    float fx = px - cc.cx, fy = py - cc.cy, fz = pz - cc.cz;
+    const bool miss = cell_left(fx, fy, fz);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *) g.cell8, 0, (int) g.buf_bytes, 0x00020000);
+    const int bw = g.bw;
+    u32x2 r00 = {0u, 0u}, r01 = {0u, 0u}, r10 = {0u, 0u}, r11 = {0u, 0u};
+    if (miss) {
+        cc.cx = __builtin_amdgcn_fmed3f(floorf(px), 0.0f, (float) (g.res[0] - 2));
+        cc.cy = __builtin_amdgcn_fmed3f(floorf(py), 0.0f, (float) (g.res[1] - 2));
+        cc.cz = __builtin_amdgcn_fmed3f(floorf(pz), 0.0f, (float) (g.res[2] - 2));
+        const int x1 = (int) cc.cx, y1 = (int) cc.cy, z1 = (int) cc.cz;
+        const int base = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);
+        cc.cell = base;
+        if (base == cc.ncell) { r00 = cc.n00; r01 = cc.n01; r10 = cc.n10; r11 = cc.n11; cc.ncell = -1; }      // the predicted cell: its corners were requested half a step ago
+        else {
+            const int o = brick27_word(g, x1, y1, z1);
+            r00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, 0, 0);
+            r01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * 4, 0);
+            r10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * bw * 4, 0);
+            r11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, (bw * bw + bw) * 4, 0);
+        }
+    }
+    if (PRED) {                 // request the cell of the predicted point, behind this point's own loads
+        const float qx = __builtin_amdgcn_fmed3f(floorf(__builtin_fmaf(g.s[0], pred.x, g.t[0])), 0.0f, (float) (g.res[0] - 2)),
+                    qy = __builtin_amdgcn_fmed3f(floorf(__builtin_fmaf(g.s[1], pred.y, g.t[1])), 0.0f, (float) (g.res[1] - 2)),
+                    qz = __builtin_amdgcn_fmed3f(floorf(__builtin_fmaf(g.s[2], pred.z, g.t[2])), 0.0f, (float) (g.res[2] - 2));
+        const int x1 = (int) qx, y1 = (int) qy, z1 = (int) qz;
+        const int nb = (int) (__umul24(__umul24(z1, g.res[1]) + y1, g.res[0]) + x1);
+        if (nb != cc.cell && nb != cc.ncell) {
+            const int o = brick27_word(g, x1, y1, z1);
+            cc.n00 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, 0, 0);
+            cc.n01 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * 4, 0);
+            cc.n10 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, bw * bw * 4, 0);
+            cc.n11 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o * 4, (bw * bw + bw) * 4, 0);
+            cc.ncell = nb;
+        }
+    }
+    if (miss) {
+        cc.set(__uint_as_float(r00.x), __uint_as_float(r00.y), __uint_as_float(r01.x), __uint_as_float(r01.y),
+               __uint_as_float(r10.x), __uint_as_float(r10.y), __uint_as_float(r11.x), __uint_as_float(r11.y));
+        fx = px - cc.cx; fy = py - cc.cy; fz = pz - cc.cz;
+    }
+    const float A = __builtin_fmaf(cc.axyz, fz, cc.axy), B = __builtin_fmaf(cc.axz, fz, cc.ax),
+                C = __builtin_fmaf(cc.ayz, fz, cc.ay), D = __builtin_fmaf(cc.az, fz, cc.a0);
+    const float gx = __builtin_fmaf(A, fy, B);
+    val = __builtin_fmaf(gx, fx, __builtin_fmaf(C, fy, D));
+    const float gy = __builtin_fmaf(A, fx, C);
+    const float gz = __builtin_fmaf(__builtin_fmaf(cc.axyz, fx, cc.ayz), fy, __builtin_fmaf(cc.axz, fx, cc.az));
+    grad = f3(gx * g.s[0], gy * g.s[1], gz * g.s[2]);
+}
+
 // Cubic B-spline basis and derivative at the 4 taps around x (include/mitsuba/core/basisspline.h:40-72).
 // t = x - floor(x) in [0,1); tap distances t+1, t, t-1, t-2.
 __device__ __forceinline__ void bspline_weights(float t, float w[4], float dw[4]) {
@@ -494,18 +571,26 @@ __device__ __forceinline__ void er_step(const DGrid &g, CellCache &cc, f3 &p, f3
     } else {
         float n; f3 gr;
         const float hh = 0.5f * h;
+        // predicted-cell fetch (trilinear_value_grad_pf): same evaluations at the same points; stages 2 and 4 also REQUEST the cell the ray is expected in at
+        // the other of the two (stage 4 from the stage-1 slope, the next step's stage 2 from the stage-3 slope)
+        constexpr bool PF = MER_PREFETCH && RIF == RIFK_BRICK27_BUF;
+        const bool pf = PF && !g.affine;
+        if (pf) trilinear_value_grad_pf<false>(g, cc, p, p, n, gr); else
         rif_value_grad<RIF>(g, cc, p, n, gr);                       // k1
         f3 kp = v * MER_RCP(n);
         f3 ps = kp, vs = gr; float ns = n;
         f3 vv = fma3(hh, gr, v);
+        if (pf) trilinear_value_grad_pf<true>(g, cc, fma3(hh, kp, p), fma3(h, kp, p), n, gr); else
         rif_value_grad<RIF>(g, cc, fma3(hh, kp, p), n, gr);          // k2
         kp = vv * MER_RCP(n);
         ps = fma3(2.0f, kp, ps); vs = fma3(2.0f, gr, vs); ns = __builtin_fmaf(2.0f, n, ns);
         vv = fma3(hh, gr, v);
+        if (pf) trilinear_value_grad_pf<false>(g, cc, fma3(hh, kp, p), p, n, gr); else
         rif_value_grad<RIF>(g, cc, fma3(hh, kp, p), n, gr);          // k3
         kp = vv * MER_RCP(n);
         ps = fma3(2.0f, kp, ps); vs = fma3(2.0f, gr, vs); ns = __builtin_fmaf(2.0f, n, ns);
         vv = fma3(h, gr, v);
+        if (pf) trilinear_value_grad_pf<true>(g, cc, fma3(h, kp, p), fma3(1.5f * h, kp, p), n, gr); else
         rif_value_grad<RIF>(g, cc, fma3(h, kp, p), n, gr);           // k4
         kp = vv * MER_RCP(n);
         ps = ps + kp; vs = vs + gr; ns = ns + n;

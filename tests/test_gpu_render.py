@@ -296,6 +296,30 @@ def test_spatially_sorted_march_list_changes_no_path(ctx, name, bits, major):
         v.destroy()
 
 
+@pytest.mark.parametrize("name", ["cfg3_curved_rk4_trilinear", "curved_woodcock2", "cfg2_straight_ratio", "point_curved_trilinear"])
+def test_fitted_launch_grids_change_no_path(ctx, name):
+    """option grid_fit (default 1): K_event / K_connect / K_march are launched with as many blocks as their lists can still hold (live path slots x
+    records per path + the side walks in flight at the last read-back) instead of one block per 256 records.  The bound is never below a list's
+    length, so nothing changes but the number of blocks that find no work: per-path radiance bit-identical, equal work counters, the same film --
+    also under the two-walk Woodcock estimator (side walks return to K_event) and with the connection kernel in the pass."""
+    p = CASES[name]()
+    sc, vols = ctx.upload_scene(p)
+    a = ctx.render_paths(sc, 0, seed=3)
+    with ctx.options(grid_fit=0):
+        b = ctx.render_paths(sc, 0, seed=3)
+    assert np.array_equal(a, b)
+    spp = 12
+    ctx.counters_reset(); fa = ctx.render_to_host(sc, 0, spp, seed=5); ca = ctx.counters()
+    with ctx.options(grid_fit=0):
+        ctx.counters_reset(); fb = ctx.render_to_host(sc, 0, spp, seed=5); cb = ctx.counters()
+    assert np.allclose(fa, fb, rtol=2e-4, atol=2e-5)
+    for k in (capi.C_PATHS, capi.C_REAL, capi.C_TENTATIVE, capi.C_STEPS, capi.C_CONNECT_UNITS):
+        assert ca[k] == cb[k]
+    assert fa[..., 4].min() >= 0 and abs(fa[..., 4].sum() - fb[..., 4].sum()) < 1e-3 * fb[..., 4].sum()     # every sample landed
+    for v in vols:
+        v.destroy()
+
+
 def test_determinism(ctx):
     p = scenes.straight_scene(N=24)
     sc, vols = ctx.upload_scene(p)
