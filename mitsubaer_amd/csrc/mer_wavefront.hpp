@@ -603,12 +603,17 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
             // pop one sample that does (a work id from the hit ring) and replay its deterministic prologue
             // one returning atomic per WAVE for the lanes that regenerate in this trip (64 per-lane atomics on the one head word serialise in L2, and every
             // wave of the launch pops from it)
-            const unsigned long long regen = __ballot(true);
-            const int rl = threadIdx.x & 63, rleader = __ffsll((long long) regen) - 1;
-            unsigned long long rbase = 0;
-            if (rl == rleader) rbase = atomicAdd(P.hitq_ctr + MER_HITQ_HEAD, (unsigned long long) __popcll(regen));
-            rbase = ((unsigned long long) (uint32_t) __shfl((int) (rbase >> 32), rleader, 64) << 32) | (uint32_t) __shfl((int) (uint32_t) rbase, rleader, 64);
-            const unsigned long long idx = rbase + (unsigned long long) __popcll(regen & ((1ULL << rl) - 1ULL));
+            // (INLINE: lanes regenerate in different trips of the loop, a group is a few lanes -- per-lane atomics measured 2 % faster there)
+            unsigned long long idx;
+            if (INLINE) idx = atomicAdd(P.hitq_ctr + MER_HITQ_HEAD, 1ULL);
+            else {
+                const unsigned long long regen = __ballot(true);
+                const int rl = threadIdx.x & 63, rleader = __ffsll((long long) regen) - 1;
+                unsigned long long rbase = 0;
+                if (rl == rleader) rbase = atomicAdd(P.hitq_ctr + MER_HITQ_HEAD, (unsigned long long) __popcll(regen));
+                rbase = ((unsigned long long) (uint32_t) __shfl((int) (rbase >> 32), rleader, 64) << 32) | (uint32_t) __shfl((int) (uint32_t) rbase, rleader, 64);
+                idx = rbase + (unsigned long long) __popcll(regen & ((1ULL << rl) - 1ULL));
+            }
             if (idx >= tail) {
                 // nothing to pop: finished if the work counter is exhausted too, otherwise wait for the next pass
                 if (work_issued >= P.total_work) st = ST_DONE; else starved = true;

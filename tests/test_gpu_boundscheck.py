@@ -84,6 +84,26 @@ def test_transient_and_odd_films_stay_in_bounds(cctx):
         v.destroy()
 
 
+@pytest.mark.parametrize("opts", [dict(march_sort=2), dict(march_sort=3, march_sort_major=1), dict(march_sort=4, mq_sort=0), dict(grid_fit=1, nslots=4096), dict(grid_fit=0, nslots=4096)])
+def test_sorted_march_list_and_fitted_grids_stay_in_bounds(cctx, ctx, opts):
+    """the counting sort of the march list (keys written with the pushes, histogram / scan / scatter kernels, the XCD-contiguous sweep) and launch
+    grids sized by the lists' bound, under the index checks: spawned side walks, four pipelines, a slot pool small enough to be refilled many times"""
+    p = scenes.curved_scene(N=32, w=40, h=28, rfilter=P.FILTER_BOX)
+    sc, vols = cctx.upload_scene(p)
+    s2, v2 = ctx.upload_scene(p)
+    with cctx.options(**opts):
+        a = cctx.render_paths(sc, 0, seed=3)
+        _clean(cctx, "paths %s" % opts)
+        f = cctx.render_to_host(sc, 0, 16, seed=2)
+        _clean(cctx, "film %s" % opts)
+    assert np.array_equal(a, ctx.render_paths(s2, 0, seed=3))
+    g = ctx.render_to_host(s2, 0, 16, seed=2)
+    assert np.allclose(f, g, rtol=2e-4, atol=2e-5)
+    assert abs(float(f[..., 4].sum()) - 40 * 28 * 16) < 1e-2 * 40 * 28 * 16          # every sample landed (box filter: weight 1 each)
+    for v in vols + v2:
+        v.destroy()
+
+
 def test_connect_leaf_with_degenerate_pairs_stays_in_bounds(cctx):
     """mer_connect on pairs that make the shooting problem singular or hopeless: coincident points, points a rounding error apart,
     the far corners of the shape, a target outside it (reached through the boundary).  Rejected or solved -- never out of range, never non-finite."""
