@@ -184,6 +184,7 @@ int  mer_device_info(mer_context *ctx, char *name, int32_t name_len, int32_t *cu
      inline_walks   1 = straight rays in a gridded sigma_t: K_event runs the walks itself instead of handing them to K_march (default), 0 = two kernels
      spawn_walks    1 = curved rays, steady-state film: the transmittance walks of luminaire samples and emitter look-ups run in side-walk slots while
                     the path goes on to its next scattering event (default); 0 = every walk in the path's own lane
+     check_every    passes per batch of launches; the host reads the finished-slot count back once per batch, two batches in flight (default 4)
      grid_fit       1 = launch grids sized by what the work lists can still hold -- live path slots x records per path + side walks in flight at
                     the last read-back -- instead of by every record (default); 0 = full grids (A/B)
      march_sort     curved rays: the march list of every pass is also counting-sorted by position (cells of a 2^b x 2^b x 2^b grid over the RIF's

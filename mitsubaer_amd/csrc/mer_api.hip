@@ -433,7 +433,7 @@ static int64_t *option_slot(mer_context *ctx, const char *name) {
         {"adaptive_k", &o.adaptive_k}, {"pass_events", &o.pass_events}, {"buffer_loads", &o.buffer_loads}, {"gen_all", &o.gen_all},
         {"prefilter", &o.prefilter}, {"verbose", &o.verbose}, {"debug_pixel", &o.debug_pixel}, {"lds_bricks", &o.lds_bricks}, {"march_lds_kb", &o.march_lds_kb},
         {"tile_deal", &o.tile_deal}, {"small_render_slots", &o.small_render_slots}, {"inline_walks", &o.inline_walks}, {"spawn_walks", &o.spawn_walks},
-        {"grid_fit", &o.grid_fit}, {"march_sort", &o.march_sort}, {"march_sort_major", &o.march_sort_major}};
+        {"grid_fit", &o.grid_fit}, {"check_every", &o.check_every}, {"march_sort", &o.march_sort}, {"march_sort_major", &o.march_sort_major}};
     for (const auto &t : table) if (std::strcmp(t.n, name) == 0) return t.p;
     return nullptr;
 }
@@ -451,7 +451,7 @@ int mer_context_set_option(mer_context *ctx, const char *name, int64_t value) {
         (n == "march_lds_kb" && (value < 0 || value > 64)) ||          // dynamic LDS above 64 KiB would need hipFuncSetAttribute
         (n == "debug_pixel" && (value < -1 || value > ((int64_t) 1 << 31) - 1)) || (n == "tile_deal" && (value < 0 || value > 1)) ||
         (n == "small_render_slots" && (value < 0 || value > 1)) || (n == "inline_walks" && (value < 0 || value > 1)) || (n == "spawn_walks" && (value < 0 || value > 1)) || (n == "adaptive_k" && (value < 0 || value > 2)) ||
-        (n == "grid_fit" && (value < 0 || value > 1)) || (n == "march_sort" && (value < 0 || value > 4)) || (n == "march_sort_major" && (value < 0 || value > 1)))
+        (n == "grid_fit" && (value < 0 || value > 1)) || (n == "check_every" && (value < 1 || value > 64)) || (n == "march_sort" && (value < 0 || value > 4)) || (n == "march_sort_major" && (value < 0 || value > 1)))
         return fail(ctx, std::string("option '") + name + "': value out of range");
     *p = value;
     return 0;

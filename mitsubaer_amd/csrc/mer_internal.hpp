@@ -55,6 +55,7 @@ struct Options {
     int64_t inline_walks = 1;     // straight rays in a gridded sigma_t: K_event runs the walks itself (persistent lanes) instead of handing them to K_march
     int64_t spawn_walks = 1;      // curved rays, steady-state film: luminaire-sample / look-up walks run in side-walk slots while the path goes on (mer_wavefront.hpp)
     int64_t small_render_slots = 1;   // a render with few paths per slot uses fewer slots / pipelines, so that the wavefront stays full while it drains
+    int64_t check_every = 4;      // passes per batch: the host reads the finished-slot count back once per batch, two batches in flight per pipeline (8 until round 3: 4 is +4 % on configs[1], +1 % on small renders, neutral on long ones)
     int64_t grid_fit = 1;         // launch grids sized by what the lists can still hold (live path slots x records per path + side walks in flight at the last read-back) instead of by every record
     int64_t march_sort = 0;       // curved rays, record layouts: march list also sorted by position (bits per axis of the cell grid, 1..3; 0 = off) and swept in XCD-contiguous chunks
     int64_t march_sort_major = 0; // bin order of that sort: 0 = cell-major (all exit-time classes of a cell together), 1 = class-major

@@ -281,7 +281,7 @@ int launch_render(mer_context *ctx, const mer_scene_desc *scene, const mer_shard
         HIP_CHECK(ctx, hipMemsetAsync(pp.hitq_ctr, 0, 64 * sizeof(unsigned long long), pp.stream));
     }
 
-    const uint32_t check_every = 8;
+    const uint32_t check_every = (uint32_t) opt.check_every;      // passes per batch (one read-back of the finished-slot count each)
     const bool pass_events = opt.pass_events != 0;          // per-kernel timing of every pass (mer_last_render_stats)
     // one batch = check_every passes of a pipeline followed by the read-back of its finished-slot count into slot `rb`.  Two batches
     // are kept in flight per pipeline, so that a pipeline never runs dry while the host waits for another one's read-back (a
