@@ -59,3 +59,24 @@ def test_product_does_not_import_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 for pat in ("import orc", "from oracle", "import oracle", "libmer_oracle", "mer_oracle.h", "orc_render", "orc."):
                     assert pat not in txt, (dirpath, f, pat)
+
+
+def test_every_option_is_documented_in_the_header():
+    """the names mer_context_set_option accepts (the table in csrc/mer_api.hip) and the names include/mer.h documents are the same set"""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api = open(os.path.join(root, "mitsubaer_amd", "csrc", "mer_api.hip")).read()
+    table = api[api.index("option_slot("):]
+    table = table[:table.index("for (const auto &t : table)")]
+    accepted = set(re.findall(r'\{"([a-z_]+)",\s*&o\.', table))
+    assert len(accepted) >= 20
+    hdr = open(os.path.join(root, "include", "mer.h")).read()
+    doc = hdr[hdr.index("Scheduling / A-B options of a context"):]
+    doc = doc[:doc.index("*/")]
+    names = doc[doc.index("Names:"):]
+    documented = set(re.findall(r"^\s{5}([a-z_]+)\s", names, re.M)) | set(re.findall(r"([a-z_]+)", names.strip().splitlines()[-1]))
+    assert accepted <= documented, sorted(accepted - documented)
+    # and the struct that holds them has a field per accepted name
+    internal = open(os.path.join(root, "mitsubaer_amd", "csrc", "mer_internal.hpp")).read()
+    fields = set(re.findall(r"int64_t ([a-z_]+) =", internal[internal.index("struct Options"):]))
+    assert accepted == fields, sorted(accepted ^ fields)

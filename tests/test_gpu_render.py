@@ -320,6 +320,19 @@ def test_fitted_launch_grids_change_no_path(ctx, name):
         v.destroy()
 
 
+def test_options_are_range_checked(ctx):
+    """mer_context_set_option refuses unknown names and values outside the documented range, and leaves the option unchanged"""
+    bad = dict(pipes=0, ksteps=0, nslots=100, mq_sort=2, adaptive_k=3, grid_fit=2, check_every=0, march_sort=5, march_sort_major=2, spawn_walks=2, connect_launches=0, prefilter=9)
+    for name, v in bad.items():
+        before = ctx.get_option(name)
+        with pytest.raises(capi.MerError):
+            ctx.set_option(name, v)
+        assert ctx.get_option(name) == before
+    with pytest.raises(capi.MerError):
+        ctx.set_option("no_such_option", 1)
+    assert ctx.get_option("check_every") == 4 and ctx.get_option("grid_fit") == 1 and ctx.get_option("march_sort") == 0 and ctx.get_option("spawn_walks") == 1
+
+
 def test_determinism(ctx):
     p = scenes.straight_scene(N=24)
     sc, vols = ctx.upload_scene(p)
