@@ -74,3 +74,31 @@ def test_random_scene_configuration_matches_oracle(ctx, orc, seed):
     assert close.mean() > (0.90 if connections else 0.99), (seed, close.mean(), {k: v for k, v in p.__dict__.items() if not hasattr(v, "shape")})
     for v in vols:
         v.destroy()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scene_film_does_not_depend_on_the_scheduling(ctx, seed):
+    """The same random configurations as FILMS, under the scheduling the render picks by itself (four pipelines, spawned side walks where they apply,
+    fitted launch grids, batches of 4 passes) and under its opposite (one pipeline, every walk in the path's lane, full grids, batches of 8, a slot
+    pool small enough to be refilled dozens of times; the march list spatially sorted when the rays are curved): the film is the same up to float summation
+    order, every sample lands, and the work counters agree -- the scheduler moves work around, it never changes or loses any."""
+    p, layout, connections = _random_scene(seed)
+    sc, vols = ctx.upload_scene(p, layout=layout)
+    spp = 6
+    ctx.counters_reset(); fa = ctx.render_to_host(sc, 0, spp, seed=seed); ca = ctx.counters()
+    with ctx.options(pipes=1, spawn_walks=0, grid_fit=0, check_every=8, nslots=2048, march_sort=2 if p.rif_mode != P.RIF_CONST else 0):
+        ctx.counters_reset(); fb = ctx.render_to_host(sc, 0, spp, seed=seed); cb = ctx.counters()
+    assert np.isfinite(fa).all() and np.isfinite(fb).all()
+    scale = max(float(np.abs(fb[..., :3]).max()), 1e-6)
+    assert np.abs(fa[..., :3] - fb[..., :3]).max() <= 5e-4 * scale, (seed, float(np.abs(fa[..., :3] - fb[..., :3]).max()), scale)
+    assert np.allclose(fa[..., 3:], fb[..., 3:], rtol=1e-4, atol=1e-5)                      # alpha and weight
+    for k in (capi.C_PATHS, capi.C_REAL):
+        assert ca[k] == cb[k], (seed, k, ca[k], cb[k])
+    # a side walk whose prefactor is zero (a look-up that the depth limit blocks) is not spawned at all, where the in-lane form walks and then discards
+    # the result: the spawning render does at most the other one's marching work (equal when nothing is blocked)
+    for k in (capi.C_TENTATIVE, capi.C_STEPS):
+        assert ca[k] <= cb[k], (seed, k, ca[k], cb[k])
+        if p.max_depth < 0:
+            assert ca[k] == cb[k], (seed, k, ca[k], cb[k])
+    for v in vols:
+        v.destroy()
