@@ -69,6 +69,23 @@ __device__ __forceinline__ void store_hot(const Params &P, uint32_t i, int st, i
     r[4] = make_uint4((uint32_t) (rng.state >> 32), pixel, sample, __float_as_uint((WalkT::kBND == 1 && ev == EV_NONE) ? W.dleft : sigma));
 }
 
+// The cold words [H_COUNT, H_COUNT + 36) of a record as nine 16-byte pieces.  K_event used to read and write them one dword at a time: ~30 vector-memory
+// instructions per visit, each of which sends 64 lanes to 64 different lines -- ~2 100 L2 requests per wave for 128 lines (the section profile of K_event,
+// scratch/kevent_profile.py, had a third of a visit's time in the record load).
+#define MER_COLD_WORDS 36
+__device__ __forceinline__ void load_cold(const Params &P, uint32_t i, uint32_t (&cw)[MER_COLD_WORDS]) {
+    const uint4 *r = (const uint4 *) (P.slots + (size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots_all) * MER_SLOT_WORDS + H_COUNT);
+#pragma unroll
+    for (int k = 0; k < MER_COLD_WORDS / 4; k++) { const uint4 q = r[k]; cw[4 * k] = q.x; cw[4 * k + 1] = q.y; cw[4 * k + 2] = q.z; cw[4 * k + 3] = q.w; }
+}
+__device__ __forceinline__ void store_cold(const Params &P, uint32_t i, const uint32_t (&cw)[MER_COLD_WORDS]) {
+    uint4 *r = (uint4 *) (P.slots + (size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots_all) * MER_SLOT_WORDS + H_COUNT);
+#pragma unroll
+    for (int k = 0; k < MER_COLD_WORDS / 4; k++) r[k] = make_uint4(cw[4 * k], cw[4 * k + 1], cw[4 * k + 2], cw[4 * k + 3]);
+}
+#define CW(k) cw[(k) - H_COUNT]
+#define CWF(k) __uint_as_float(cw[(k) - H_COUNT])
+
 // ---- spawned side walks ---------------------------------------------------------------------------------------------------------
 // The transmittance walk of a luminaire sample and the walk of an emitter look-up run to the BOUNDARY of the medium (hundreds of steps: 2 - 7
 // passes each), and the path has to wait for neither: their result only scales a contribution that is already fully known when the walk starts
@@ -92,13 +109,18 @@ __device__ __forceinline__ void spawn_side_walk(const Params &P, uint32_t c, int
     r[2] = make_uint4(0u, 0u, __float_as_uint(1.0f), __float_as_uint(rayT));
     r[3] = make_uint4(0u, 0u, pack_flags(ST_MARCH, EV_NONE, kind, 0, 0, 0, 0) | MER_FLAG_INIT | MER_FLAG_CHILD, (uint32_t) rng_state);
     r[4] = make_uint4((uint32_t) (rng_state >> 32), pixel, sample, 0u);
-    rec[CO_PXF] = __float_as_uint(px); rec[CO_PYF] = __float_as_uint(py);
-    rec[CO_LX] = __float_as_uint(pref.x); rec[CO_LY] = __float_as_uint(pref.y); rec[CO_LZ] = __float_as_uint(pref.z);
-    rec[CO_PFLAGS] = 64u /* F_CHILD */; rec[CO_DEPTH] = 0u;
-    rec[CO_PSX] = __float_as_uint(o.x); rec[CO_PSY] = __float_as_uint(o.y); rec[CO_PSZ] = __float_as_uint(o.z);
-    rec[CO_DSX] = __float_as_uint(d.x); rec[CO_DSY] = __float_as_uint(d.y); rec[CO_DSZ] = __float_as_uint(d.z);
-    rec[CO_DDX] = __float_as_uint(d.x); rec[CO_DDY] = __float_as_uint(d.y); rec[CO_DDZ] = __float_as_uint(d.z);
-    rec[CO_ITST] = __float_as_uint(rayT); rec[CO_N0] = __float_as_uint(1.0f); rec[CO_TRSUM] = 0u; rec[CO_SDENS] = 0u; rec[CO_TMIN] = 0u;
+    uint32_t cw[MER_COLD_WORDS];
+#pragma unroll
+    for (int k = 0; k < MER_COLD_WORDS; k++) cw[k] = 0u;
+    CW(CO_PXF) = __float_as_uint(px); CW(CO_PYF) = __float_as_uint(py);
+    CW(CO_LX) = __float_as_uint(pref.x); CW(CO_LY) = __float_as_uint(pref.y); CW(CO_LZ) = __float_as_uint(pref.z);
+    CW(CO_PFLAGS) = 64u /* F_CHILD */;
+    CW(CO_PSX) = __float_as_uint(o.x); CW(CO_PSY) = __float_as_uint(o.y); CW(CO_PSZ) = __float_as_uint(o.z);
+    CW(CO_DSX) = __float_as_uint(d.x); CW(CO_DSY) = __float_as_uint(d.y); CW(CO_DSZ) = __float_as_uint(d.z);
+    CW(CO_DDX) = __float_as_uint(d.x); CW(CO_DDY) = __float_as_uint(d.y); CW(CO_DDZ) = __float_as_uint(d.z);
+    CW(CO_ITST) = __float_as_uint(rayT); CW(CO_N0) = __float_as_uint(1.0f);
+    store_cold(P, c, cw);           // (the words a side walk never reads are written as zeros: whole 16-byte pieces)
+    (void) rec;
 }
 #define CSLOT(c, k) P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, c, P.nslots_all) * MER_SLOT_WORDS + (k)]
 #ifndef MER_SIDE_PER_KIND
@@ -474,8 +496,9 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
         if (child && ev != EV_NONE && !(SIGMA == MER_SIGMA_GRID && P.sc.tr_estimator == MER_TR_WOODCOCK2)) {
             f3 tr = SIGMA == MER_SIGMA_GRID ? f3(W.Tr, W.Tr, W.Tr) : homogeneous_transmittance(P, -W.dist);
             if (ev == EV_GATE_FAIL) tr = f3(0, 0, 0);
-            const f3 c = f3(SLOTF(CO_LX), SLOTF(CO_LY), SLOTF(CO_LZ)) * tr;
-            if (!is_zero(c)) film_splat(P, SLOTF(CO_PXF), SLOTF(CO_PYF), c, 0.0f, 0, 1);
+            const uint4 q = *(const uint4 *) (P.slots + (size_t) MER_CHK(P.chk, CHK_SLOT, i, P.nslots_all) * MER_SLOT_WORDS + CO_PXF);      // film position, prefactor x y
+            const f3 c = f3(__uint_as_float(q.z), __uint_as_float(q.w), SLOTF(CO_LZ)) * tr;
+            if (!is_zero(c)) film_splat(P, __uint_as_float(q.x), __uint_as_float(q.y), c, 0.0f, 0, 1);
             SLOT(H_FLAGS) = 0u;
             child_ended = true; ev = EV_NONE;
         } else
@@ -516,6 +539,18 @@ __global__ void __launch_bounds__(MER_BLOCK, MER_MARCH_WAVES) march_kernel(const
 // launch, pops the next sample from the hit ring and goes on until the ring is empty -- a persistent-lane megakernel, which for curved rays
 // (hundreds of 350-instruction steps per walk) was the slowest form of all (section 4's table) and for straight rays is the fastest.  Same
 // sampler draws in the same order: per-path results do not change (tested).
+// Section profile of K_event (compile with -DMER_PROFILE; scratch/kevent_profile.sh): wave time between marks (s_memtime) summed per section into
+// mer_prof[], read back by mer_debug_prof (mer_render_brick.hip).  Off in the product build: PROF() expands to nothing.
+#ifdef MER_PROFILE
+static __device__ unsigned long long mer_prof[256 * 16];      // 256 replicas (by wave id), summed by mer_debug_prof: one word sustains ~90 atomics per microsecond
+#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int prof_cur = 0;
+#define PROF(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); _Pragma("unroll") for (int q_ = 0; q_ < 10; q_++) prof_acc[q_] += prof_cur == q_ ? t_ - prof_t : 0ull; prof_t = t_; prof_cur = (k); } while (0)
+#define PROF_FLUSH(active) do { PROF(9); if ((threadIdx.x & 63) == 0 && __ballot(active)) { unsigned long long *d_ = mer_prof + (((blockIdx.x * MER_BLOCK + threadIdx.x) >> 6) & 255u) * 16u; _Pragma("unroll") for (int q_ = 0; q_ < 10; q_++) atomicAdd(d_ + q_, prof_acc[q_]); atomicAdd(d_ + 15, 1ull); } } while (0)
+#else
+#define PROF_DECL
+#define PROF(k) do { } while (0)
+#define PROF_FLUSH(active) do { } while (0)
+#endif
 #ifndef MER_EVENT_WAVES
 #define MER_EVENT_WAVES 2              // waves per SIMD K_event is compiled for (256 VGPR): 3 and 4 measured, see DESIGN section 4
 #endif
@@ -534,6 +569,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
     // ring hygiene: the rows K_march / K_event of pass+1 will add to
     queue_clear_row(P.eq, pass + 2, j); queue_clear_row(P.mq[pass & 1u], pass + 2, j); queue_clear_row(P.sq[pass & 1u], pass + 2, j);
     LaneCounters C; C.clear();
+    PROF_DECL
     bool marching = false, starved_out = false, connecting = false; uint32_t i = 0; int mq_class = 0, cq_class = 0;
     bool child_done = false; uint32_t side_inline = 0;
     uint32_t child0 = 0, child1 = 0; int c0class = 0, c1class = 0;           // side walks this lane has just spawned (0 = none): they join the march list below
@@ -571,15 +607,17 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
         uint32_t fl;
         load_hot(P, i, fl, W, rng, pixel, sample, sigma);
         st = fl & 3u; ev = (fl >> 2) & 15u;
-        px = SLOTF(CO_PXF); py = SLOTF(CO_PYF);
-        L = f3(SLOTF(CO_LX), SLOTF(CO_LY), SLOTF(CO_LZ)); T = f3(SLOTF(CO_TX), SLOTF(CO_TY), SLOTF(CO_TZ));
-        depth = (int) SLOT(CO_DEPTH); flags = (int) SLOT(CO_PFLAGS);
-        ps = f3(SLOTF(CO_PSX), SLOTF(CO_PSY), SLOTF(CO_PSZ)); dsave = f3(SLOTF(CO_DSX), SLOTF(CO_DSY), SLOTF(CO_DSZ));
-        dd = f3(SLOTF(CO_DDX), SLOTF(CO_DDY), SLOTF(CO_DDZ)); wi = f3(SLOTF(CO_WIX), SLOTF(CO_WIY), SLOTF(CO_WIZ));
-        phasePdf = SLOTF(CO_PHASEPDF); itsT = SLOTF(CO_ITST); W.n0 = SLOTF(CO_N0); W.trsum = SLOTF(CO_TRSUM);
-        W.sdens = SLOTF(CO_SDENS); W.tmin = SLOTF(CO_TMIN);
-        plen = SLOTF(CO_PLEN); trOpt = SLOTF(CO_TROPT); if (EXTRA) etaPath = SLOTF(CO_ETA);
-        prng = (uint64_t) SLOT(CO_WNEXT_LO) | ((uint64_t) SLOT(CO_WNEXT_HI) << 32);
+        uint32_t cw[MER_COLD_WORDS];
+        load_cold(P, i, cw);                       // nine 16-byte loads (was ~30 dword loads)
+        px = CWF(CO_PXF); py = CWF(CO_PYF);
+        L = f3(CWF(CO_LX), CWF(CO_LY), CWF(CO_LZ)); T = f3(CWF(CO_TX), CWF(CO_TY), CWF(CO_TZ));
+        depth = (int) CW(CO_DEPTH); flags = (int) CW(CO_PFLAGS);
+        ps = f3(CWF(CO_PSX), CWF(CO_PSY), CWF(CO_PSZ)); dsave = f3(CWF(CO_DSX), CWF(CO_DSY), CWF(CO_DSZ));
+        dd = f3(CWF(CO_DDX), CWF(CO_DDY), CWF(CO_DDZ)); wi = f3(CWF(CO_WIX), CWF(CO_WIY), CWF(CO_WIZ));
+        phasePdf = CWF(CO_PHASEPDF); itsT = CWF(CO_ITST); W.n0 = CWF(CO_N0); W.trsum = CWF(CO_TRSUM);
+        W.sdens = CWF(CO_SDENS); W.tmin = CWF(CO_TMIN);
+        plen = CWF(CO_PLEN); trOpt = CWF(CO_TROPT); if (EXTRA) etaPath = CWF(CO_ETA);
+        prng = (uint64_t) CW(CO_WNEXT_LO) | ((uint64_t) CW(CO_WNEXT_HI) << 32);
     }
     if (st == ST_MARCH) {
         px_i = (int) (pixel % (uint32_t) S.width); py_i = (int) (pixel / (uint32_t) S.width);
@@ -599,6 +637,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
     for (;;) {
         // ---------------------------------------------------------------- regeneration (integrator.cpp:162-187)
         if (st == ST_NEW) {
+            PROF(1);
             // K_gen has already retired the camera samples that never reach the medium; what is left to do here is to
             // pop one sample that does (a work id from the hit ring) and replay its deterministic prologue
             // one returning atomic per WAVE for the lanes that regenerate in this trip (64 per-lane atomics on the one head word serialise in L2, and every
@@ -689,6 +728,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
         }
 
         // ---------------------------------------------------------------- one event
+        PROF(6);
         if (ev == EV_ARRIVED) {
             ev = W.on_arrived(P, rng, C, sigma);
         } else if (ev == EV_EXITED) {
@@ -706,6 +746,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
                 ev = EV_TR_DONE;
             }
         } else if (ev == EV_REAL) {
+            PROF(2);
             // ---- medium interaction: volpath.cpp:104-118
             MRec m;
             finish_free_flight(P, C, W, true, sigma, m);
@@ -765,6 +806,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
                 } else { trv = f3(0, 0, 0); ev = EV_TR_DONE; }
             } else ev = EV_PHASE;
         } else if (ev == EV_TR_DONE) {
+            PROF(3);
             if (SPAWNABLE && (flags & F_CHILD)) {                                            // a spawned side walk has ended: its contribution, and the slot is free again
                 const f3 c = L * trv;                                                        // L holds the prefactor (throughput x emitter x phase x MIS weight)
                 if (!is_zero(c)) film_splat(P, px, py, c, 0.0f, 0, 1);
@@ -811,6 +853,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
                 ev = EV_AFTER_LOOKUP;
             }
         } else if (ev == EV_PHASE || ev == EV_PHASE2) {
+            PROF(4);
             // ---- luminaire sampling of the point emitter, if any (after the environment NEE, as in the oracle's draw order).
             // Curved rays: the connection is a shooting problem of hundreds of sensitivity steps -- it gets a kernel of its
             // own (K_connect) in which every lane solves one; the path resumes at EV_PHASE2 in the next pass.
@@ -890,6 +933,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
                 }
             } else ev = EV_AFTER_LOOKUP;
         } else if (ev == EV_AFTER_LOOKUP) {
+            PROF(5);
             SET_FLAG(F_EMITTED, false);                                               // ERadianceNoEmission
             ev = EV_NONE;
             bool alive = true;
@@ -959,30 +1003,35 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
 #undef itsValid
 #undef SET_FLAG
 
+    PROF(7);
     // ---- park the lane
     if (child_done) SLOT(H_FLAGS) = 0u;                                           // side-walk slot idle again
     else if (st == ST_DONE) { SLOT(H_FLAGS) = ST_DONE; atomicAdd(P.live, 1u); }      // live[0] counts finished slots
     else if (starved) { SLOT(H_FLAGS) = ST_NEW; starved_out = true; }
     else {
         store_hot(P, i, ST_MARCH, connecting ? EV_PHASE2 : EV_NONE, W, rng, pixel, sample, 0.0f, (SPAWNABLE && (flags & F_CHILD)) ? MER_FLAG_CHILD : 0u);
-        SLOT(CO_PXF) = __float_as_uint(px); SLOT(CO_PYF) = __float_as_uint(py);
-        SLOT(CO_LX) = __float_as_uint(L.x); SLOT(CO_LY) = __float_as_uint(L.y); SLOT(CO_LZ) = __float_as_uint(L.z);
-        SLOT(CO_TX) = __float_as_uint(T.x); SLOT(CO_TY) = __float_as_uint(T.y); SLOT(CO_TZ) = __float_as_uint(T.z);
-        SLOT(CO_DEPTH) = (uint32_t) depth; SLOT(CO_PFLAGS) = (uint32_t) flags;
-        SLOT(CO_PSX) = __float_as_uint(ps.x); SLOT(CO_PSY) = __float_as_uint(ps.y); SLOT(CO_PSZ) = __float_as_uint(ps.z);
-        SLOT(CO_DSX) = __float_as_uint(dsave.x); SLOT(CO_DSY) = __float_as_uint(dsave.y); SLOT(CO_DSZ) = __float_as_uint(dsave.z);
-        SLOT(CO_DDX) = __float_as_uint(dd.x); SLOT(CO_DDY) = __float_as_uint(dd.y); SLOT(CO_DDZ) = __float_as_uint(dd.z);
-        SLOT(CO_WIX) = __float_as_uint(wi.x); SLOT(CO_WIY) = __float_as_uint(wi.y); SLOT(CO_WIZ) = __float_as_uint(wi.z);
-        SLOT(CO_PHASEPDF) = __float_as_uint(phasePdf); SLOT(CO_ITST) = __float_as_uint(itsT);
-        SLOT(CO_N0) = __float_as_uint(W.n0); SLOT(CO_TRSUM) = __float_as_uint(W.trsum);
-        SLOT(CO_SDENS) = __float_as_uint(W.sdens); SLOT(CO_TMIN) = __float_as_uint(W.tmin);
-        SLOT(CO_PLEN) = __float_as_uint(plen); SLOT(CO_TROPT) = __float_as_uint(trOpt); if (EXTRA) SLOT(CO_ETA) = __float_as_uint(etaPath);
-        SLOT(CO_WNEXT_LO) = (uint32_t) prng; SLOT(CO_WNEXT_HI) = (uint32_t) (prng >> 32);
+        uint32_t cw[MER_COLD_WORDS];
+        CW(CO_PXF) = __float_as_uint(px); CW(CO_PYF) = __float_as_uint(py);
+        CW(CO_LX) = __float_as_uint(L.x); CW(CO_LY) = __float_as_uint(L.y); CW(CO_LZ) = __float_as_uint(L.z);
+        CW(CO_TX) = __float_as_uint(T.x); CW(CO_TY) = __float_as_uint(T.y); CW(CO_TZ) = __float_as_uint(T.z);
+        CW(CO_DEPTH) = (uint32_t) depth; CW(CO_PFLAGS) = (uint32_t) flags;
+        CW(CO_PSX) = __float_as_uint(ps.x); CW(CO_PSY) = __float_as_uint(ps.y); CW(CO_PSZ) = __float_as_uint(ps.z);
+        CW(CO_DSX) = __float_as_uint(dsave.x); CW(CO_DSY) = __float_as_uint(dsave.y); CW(CO_DSZ) = __float_as_uint(dsave.z);
+        CW(CO_DDX) = __float_as_uint(dd.x); CW(CO_DDY) = __float_as_uint(dd.y); CW(CO_DDZ) = __float_as_uint(dd.z);
+        CW(CO_WIX) = __float_as_uint(wi.x); CW(CO_WIY) = __float_as_uint(wi.y); CW(CO_WIZ) = __float_as_uint(wi.z);
+        CW(CO_PHASEPDF) = __float_as_uint(phasePdf); CW(CO_ITST) = __float_as_uint(itsT);
+        CW(CO_N0) = __float_as_uint(W.n0); CW(CO_TRSUM) = __float_as_uint(W.trsum);
+        CW(CO_SDENS) = __float_as_uint(W.sdens); CW(CO_TMIN) = __float_as_uint(W.tmin);
+        CW(CO_WNEXT_LO) = (uint32_t) prng; CW(CO_WNEXT_HI) = (uint32_t) (prng >> 32); CW(CO_WLEFT) = 0u;
+        CW(CO_PLEN) = __float_as_uint(plen); CW(CO_TROPT) = __float_as_uint(trOpt); CW(CO_ETA) = EXTRA ? __float_as_uint(etaPath) : 0u;
+        cw[MER_COLD_WORDS - 2] = 0u; cw[MER_COLD_WORDS - 1] = 0u;
+        store_cold(P, i, cw);                      // nine 16-byte stores
         marching = !connecting;
         mq_class = march_class<CURVED, BND>(P, W);
 
     }
     }   // j < count
+    PROF(8);
     // a new connection joins the pending ones of the next K_connect launch, grouped by the length of the rays its solver will trace
     if (EXTRA && CURVED) queue_push_class<MER_CQ_CLASSES>(pick_queue(P.cq, P.cq_row), P.cq_row, connecting, i, cq_class);
     if (!SPAWNABLE) queue_push_class<MER_MQ_CLASSES>(P.mq[pass & 1u], pass, marching, i, mq_class & 255, (uint32_t) mq_class >> 8);
@@ -1001,6 +1050,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
     }
     queue_push(P.sq[(pass + 1) & 1u], pass + 1, starved_out, i);
     flush_counters(P, C, 0);
+    PROF_FLUSH(j < count);
 }
 
 // ---------------------------------------------------------------------------------------------------
