@@ -128,19 +128,23 @@ __device__ __forceinline__ void spawn_side_walk(const Params &P, uint32_t c, int
 #endif
 enum { F_NEE_ROT = 16 /* bits 4-5 */, F_CHILD = 64, F_LK_ROT = 128 /* bits 7-8 */ };      // path flags (CO_PFLAGS) beside K_event's own: where the search for a free side-walk slot of each kind starts; the record is a side walk
 // first free side-walk slot of (path i, kind k), searched from rotation r: its record id, or 0
-__device__ __forceinline__ uint32_t free_side_slot(const Params &P, uint32_t i, uint32_t k, uint32_t r, uint32_t &r_next) {
-    const uint32_t base = P.nslots + (i * 2u + k) * MER_SIDE_PER_KIND;
-    uint32_t fl[MER_SIDE_PER_KIND];
+// the state words of path i's 2 x MER_SIDE_PER_KIND side-walk slots, read in ONE round trip at the collision (the look-up's search, half a visit later, finds its
+// three already in registers: a slot can only have become free in between, never busy -- the path itself is the only one that fills them)
+__device__ __forceinline__ void side_flags_load(const Params &P, uint32_t i, uint32_t (&fl)[2 * MER_SIDE_PER_KIND]) {
+    const uint32_t base = P.nslots + i * 2u * MER_SIDE_PER_KIND;
 #pragma unroll
-    for (uint32_t t = 0; t < MER_SIDE_PER_KIND; t++)          // every state word in ONE round trip (a probe per trip made the wave wait for its unluckiest lane)
+    for (uint32_t t = 0; t < 2u * MER_SIDE_PER_KIND; t++)
         fl[t] = P.slots[(size_t) MER_CHK(P.chk, CHK_SLOT, base + t, P.nslots_all) * MER_SLOT_WORDS + H_FLAGS];
+}
+__device__ __forceinline__ uint32_t free_side_slot(const Params &P, uint32_t i, uint32_t k, uint32_t r, uint32_t &r_next, const uint32_t (&fl)[2 * MER_SIDE_PER_KIND]) {
+    const uint32_t base = P.nslots + (i * 2u + k) * MER_SIDE_PER_KIND;
     uint32_t found = 0u; r_next = r;
 #pragma unroll
     for (uint32_t t = MER_SIDE_PER_KIND; t-- > 0u; ) {         // last to first, so that the first free slot in rotation order wins
         const uint32_t q = (r + t) % MER_SIDE_PER_KIND;
-        uint32_t f = fl[0];
+        uint32_t f = k ? fl[MER_SIDE_PER_KIND] : fl[0];
 #pragma unroll
-        for (uint32_t u = 1; u < MER_SIDE_PER_KIND; u++) f = q == u ? fl[u] : f;
+        for (uint32_t u = 1; u < MER_SIDE_PER_KIND; u++) f = q == u ? (k ? fl[MER_SIDE_PER_KIND + u] : fl[u]) : f;
         if ((f & 3u) == 0u) { found = base + q; r_next = (q + 1u) % MER_SIDE_PER_KIND; }
     }
     return found;
@@ -572,6 +576,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
     PROF_DECL
     bool marching = false, starved_out = false, connecting = false; uint32_t i = 0; int mq_class = 0, cq_class = 0;
     bool child_done = false; uint32_t side_inline = 0;
+    uint32_t sfl[2 * MER_SIDE_PER_KIND] = {}; bool sfl_ok = false;      // state words of the path's side-walk slots (side_flags_load)
     uint32_t child0 = 0, child1 = 0; int c0class = 0, c1class = 0;           // side walks this lane has just spawned (0 = none): they join the march list below
     constexpr bool SPAWNABLE = CURVED && !EXTRA;                             // the plain curved kernels (the bench kernels) spawn side walks when P.spawn says so
     if (j < count) {
@@ -783,7 +788,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
                         if (!CURVED) trOpt = tExit * S.rif_const;
                         bool spawned = false;
                         if (SPAWNABLE && P.spawn) {
-                            uint32_t rn; const uint32_t c = free_side_slot(P, i, 0u, ((uint32_t) flags >> 4) & 3u, rn);
+                            uint32_t rn; side_flags_load(P, i, sfl); sfl_ok = true; const uint32_t c = free_side_slot(P, i, 0u, ((uint32_t) flags >> 4) & 3u, rn, sfl);
                             if (c != 0u) {                                            // a side-walk slot is free: the walk goes there, the path goes on
                                 const float phaseVal = phase_eval(S.phase, S.g, wi, dd);
                                 const f3 pref = T * (env / MER_INV_FOURPI) * phaseVal * mi_weight(MER_INV_FOURPI, phaseVal);
@@ -911,7 +916,7 @@ __global__ void __launch_bounds__(MER_BLOCK, INLINE ? MER_INLINE_EVENT_WAVES : M
                 else {
                     bool spawned = false;
                     if (SPAWNABLE && P.spawn) {
-                        uint32_t rn; const uint32_t c = free_side_slot(P, i, 1u, ((uint32_t) flags >> 7) & 3u, rn);
+                        uint32_t rn; if (!sfl_ok) side_flags_load(P, i, sfl); const uint32_t c = free_side_slot(P, i, 1u, ((uint32_t) flags >> 7) & 3u, rn, sfl);
                         if (c != 0u) {
                             const bool blocked = (maxDepth - depth - 1 == 0);                    // curved rays: the look-up always crosses the boundary once
                             const f3 pref = blocked ? f3(0, 0, 0) : T * env * mi_weight(phasePdf, MER_INV_FOURPI);
